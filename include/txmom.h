@@ -1,0 +1,209 @@
+/*
+ * txmom.h -- C ABI of libtxmom.so: the MI355X (gfx950) moment engine behind
+ * thermoextrap's central-(co)moment / bootstrap / derivative hot path.
+ *
+ * The reference (usnistgov/thermoextrap @ v0.6.0) has NO FFI for this path: its
+ * boundary is the Python API of the third-party package cmomy 0.24.0 as called
+ * from src/thermoextrap/data.py.  Each entry point below names the cmomy call
+ * (and the reference call site, file:line under /root/reference) it replaces;
+ * INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - return 0 on success, negative txm_status on failure; never throws;
+ *     txm_last_error() gives a thread-local message.
+ *   - every array pointer is a DEVICE pointer (HBM resident) unless the
+ *     parameter name ends in `_host`; the caller owns all buffers; outputs
+ *     are caller-allocated and fully overwritten.
+ *   - all floating point is IEEE binary64, all indices/counts int64_t,
+ *     strides are in ELEMENTS.
+ *   - moment-state layout (cmomy convention, verified against the reference's
+ *     notebook outputs): trailing dims [xmom = 2][umom = K = order + 1]:
+ *        [0][0] = sum of weights   [1][0] = <x>   [0][1] = <u>
+ *        [a][b] = <(x-<x>)^a (u-<u>)^b>  otherwise.
+ *     1-D states: [0] = sum w, [1] = <u>, [k>=2] = <du^k>.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all
+ *     work is enqueued on it and nothing synchronises unless stated.
+ *   - `ws` is scratch in HBM of at least the size the matching *_ws_bytes()
+ *     returns; no entry point allocates or frees device memory, so every call
+ *     is legal inside hipGraph stream capture.
+ */
+#ifndef TXMOM_H
+#define TXMOM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TXM_ABI_VERSION 1
+#define TXM_MAX_ORDER 8 /* K = order + 1 <= 9 */
+
+typedef enum txm_status {
+  TXM_OK = 0,
+  TXM_ERR_INVALID = -1,     /* bad argument (shape, order, null pointer, alignment) */
+  TXM_ERR_HIP = -2,         /* a HIP runtime call failed; see txm_last_error() */
+  TXM_ERR_WORKSPACE = -3,   /* ws too small */
+  TXM_ERR_UNSUPPORTED = -4, /* valid request the library cannot serve */
+  TXM_ERR_NO_DEVICE = -5    /* no gfx950 device visible */
+} txm_status;
+
+typedef void *txm_stream;
+
+/* ---- runtime ------------------------------------------------------------ */
+int txm_abi_version(void);
+const char *txm_last_error(void);
+/* Select the device for the calling thread and check it is a gfx950 part. */
+int txm_init(int device);
+int txm_device_count(int *count_host);
+int txm_malloc(void **ptr_host, size_t bytes);
+int txm_free(void *ptr);
+int txm_memcpy_h2d(void *dst, const void *src_host, size_t bytes, txm_stream stream);
+int txm_memcpy_d2h(void *dst_host, const void *src, size_t bytes, txm_stream stream);
+int txm_memset(void *dst, int value, size_t bytes, txm_stream stream);
+int txm_stream_sync(txm_stream stream);
+
+/* ---- a1/a2: cmomy.wrap_reduce_vals ------------------------------------- */
+/* Weighted central comoments of C observables against u, mom = (1, order).
+ *   replaces cmomy.wrap_reduce_vals(xv, uv, weight=w, dim=rec, mom=(1, order))
+ *   reference call sites: data.py:1632-1640 (DataCentralMomentsVals),
+ *   data.py:1194-1203 (DataCentralMoments.from_vals), data.py:530-532,
+ *   data.py:487-489 (DataValues*).
+ * x[i*ldx_s + c*ldx_c], i < N, c < C.  Either ldx_c == 1 ((rec, val) layout,
+ * core/xrutils.py:73-116) or ldx_s == 1 ((val, rec) layout).  w may be NULL.
+ * out: [C][2][K].
+ */
+size_t txm_reduce_vals_ws_bytes(int64_t N, int64_t C, int order);
+int txm_reduce_vals(const double *x, int64_t ldx_s, int64_t ldx_c, const double *u,
+                    const double *w, int64_t N, int64_t C, int order, double *out, void *ws,
+                    size_t ws_bytes, txm_stream stream);
+
+/* 1-D central moments of R independent series, mom = M - 1.
+ *   replaces cmomy.wrap_reduce_vals(uv, weight=w, mom=order[+1])
+ *   reference call sites: data.py:1183-1191 (x_is_u, mom = order + 1),
+ *   data.py:485, 528; lnpi.py:278-282.
+ * u[r*ldu_r + i*ldu_s]; ldu_s must be 1.  w (nullable) is shared by all rows.
+ * out: [R][M].
+ */
+size_t txm_reduce_vals_1d_ws_bytes(int64_t N, int64_t R, int M);
+int txm_reduce_vals_1d(const double *u, int64_t ldu_r, int64_t ldu_s, const double *w,
+                       int64_t N, int64_t R, int M, double *out, void *ws, size_t ws_bytes,
+                       txm_stream stream);
+
+/* ---- sampler: cmomy.factory_sampler / IndexSampler ---------------------- */
+/* indices[nrep][nsamp] -> freq[nrep][ndat] (histogram; cmomy indices_to_freq).
+ *   reference: sampler built at data.py:1028-1037, 1344-1352, 1782-1789;
+ *   tests/test_data.py:94-112 feeds explicit indices.
+ * Returns TXM_ERR_INVALID if any index is outside [0, ndat) (checked on device,
+ * reported after a stream sync). */
+int txm_indices_to_freq(const int64_t *indices, int64_t nrep, int64_t nsamp, int64_t ndat,
+                        int64_t *freq, txm_stream stream);
+
+/* Device multinomial sampler ("scale mode").  The reference draws
+ *   indices = rng.choice(ndat, (nrep, ndat), replace=True)   
+ * and histograms them, which needs 16*nrep*ndat bytes of tables.  This
+ * generates the SAME DISTRIBUTION of frequency tables (exact multinomial:
+ * nsamp draws with replacement per replicate, integer arithmetic only) from a
+ * counter-based Philox4x32-10 stream keyed by (seed, stage, replicate, tile)
+ * without ever materialising indices; oracle/philox_oracle.c restates the
+ * stream bit for bit.  The sampler object is a plain struct (no hidden state).
+ */
+typedef struct txm_sampler_spec {
+  uint64_t seed;
+  int64_t nrep;  /* replicates */
+  int64_t ndat;  /* samples being resampled */
+  int64_t nsamp; /* draws per replicate; 0 means ndat */
+} txm_sampler_spec;
+
+/* Per-(replicate, tile) draw counts, tile = 1024 consecutive samples.
+ * counts: [nrep][txm_sampler_ntiles(ndat)] uint32. */
+int64_t txm_sampler_ntiles(int64_t ndat);
+size_t txm_sampler_counts_ws_bytes(const txm_sampler_spec *spec_host);
+int txm_sampler_tile_counts(const txm_sampler_spec *spec_host, uint32_t *counts, void *ws,
+                            size_t ws_bytes, txm_stream stream);
+/* Materialise freq[nrep][ndat] int64 from the stream (testing / small sizes). */
+int txm_sampler_freq(const txm_sampler_spec *spec_host, const uint32_t *counts, int64_t *freq,
+                     txm_stream stream);
+
+/* ---- a3/a6: cmomy.wrap_resample_vals ------------------------------------ */
+/* Sample-level bootstrap of central comoments: replicate r is the weighted
+ * comoment state of the data with weights w_i * freq[r][i].
+ *   replaces cmomy.wrap_resample_vals(xv, uv, weight=w, sampler=..., mom=(1, order))
+ *   reference call sites: data.py:1803-1810 (DataCentralMomentsVals.resample),
+ *   data.py:1354-1366 (DataCentralMoments.from_resample_vals).
+ * Exactly one of `freq` (explicit table, [nrep][N] int64: "parity mode") and
+ * `spec_host` + `counts` (device sampler: "scale mode") must be given.
+ * pivot (nullable): [1 + C] doubles {pivot_u, pivot_x[0..C)} near the means;
+ * NULL lets the library estimate one.  Requires ldx_c == 1.
+ * out: [nrep][C][2][K]  (rep-major, i.e. already `.transpose(rep_dim, ...)`,
+ * data.py:1812).
+ */
+size_t txm_resample_vals_ws_bytes(int64_t N, int64_t C, int64_t nrep, int order);
+int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, const double *u,
+                      const double *w, int64_t N, int64_t C, int order, int64_t nrep,
+                      const int64_t *freq, const txm_sampler_spec *spec_host,
+                      const uint32_t *counts, const double *pivot, double *out, void *ws,
+                      size_t ws_bytes, txm_stream stream);
+
+/* ---- a4/a5: CentralMomentsData.reduce / resample_and_reduce ------------- */
+/* data [nrec][C][2][K] -> out [C][2][K]      (data.py:996) */
+int txm_reduce_data(const double *data, int64_t nrec, int64_t C, int order, double *out,
+                    txm_stream stream);
+/* data [nrec][C][2][K], freq [nrep][nrec] -> out [nrep][C][2][K]  (data.py:1048-1052) */
+int txm_resample_data(const double *data, const int64_t *freq, int64_t nrec, int64_t C,
+                      int64_t nrep, int order, double *out, txm_stream stream);
+
+/* ---- a8/a9: cmom()/rmom()/convert.moments_type -------------------------- */
+/* n states [2][K]; to_central = 0: central -> raw (CentralMomentsData.rmom(),
+ * data.py:845-847); 1: raw -> central (convert.moments_type(to="central"),
+ * data.py:1109-1115).  [0][0] (weight) is carried over.  in == out allowed. */
+int txm_convert_cov(const double *in, double *out, int64_t n, int order, int to_central,
+                    txm_stream stream);
+/* n states [M], 1-D moments. */
+int txm_convert_1d(const double *in, double *out, int64_t n, int M, int to_central,
+                   txm_stream stream);
+
+/* ---- a10/a11: Derivatives.derivs ---------------------------------------- */
+/* Table-driven evaluation of the derivative polynomials that the reference
+ * builds with sympy + lambdify and evaluates with one xarray isel per symbol
+ * (models.py:317-383, beta.py:532-573).  A function is
+ *     f = sum_t coef[t] * prod_{k < nfac[t]} atom(fac[t][k])^pow[t][k]   (* optional -log, see flags)
+ * where an atom addresses one scalar per output element e = (rep, val):
+ *     value = src[atom.src][ rep*atom.s_rep + val*atom.s_val + atom.offset ].
+ * Tables are built on the host from the symbolic recursion (thermoextrap_amd/beta.py).
+ */
+typedef struct txm_atom {
+  int32_t src;    /* index into srcs[] */
+  int32_t pad;
+  int64_t offset; /* element offset of the scalar inside one (rep, val) cell */
+  int64_t s_rep;  /* element stride per replicate */
+  int64_t s_val;  /* element stride per value column */
+} txm_atom;
+
+typedef struct txm_poly_table {
+  int32_t n_funcs;           /* number of functions (orders 0..n_funcs-1) */
+  int32_t n_atoms;
+  int32_t n_terms;           /* total terms over all functions */
+  int32_t n_factors;         /* total factors over all terms */
+  const txm_atom *atoms;     /* [n_atoms]                         (device) */
+  const int32_t *func_term0; /* [n_funcs + 1] term range per func (device) */
+  const double *coef;        /* [n_terms]                         (device) */
+  const int32_t *term_fac0;  /* [n_terms + 1] factor range        (device) */
+  const int32_t *fac_atom;   /* [n_factors] atom id               (device) */
+  const int32_t *fac_pow;    /* [n_factors] integer power (may be negative) */
+  const int32_t *func_flags; /* [n_funcs] bit0: add -log(atom[fac_atom of first
+                                factor of the LAST term])... see TXM_FUNC_* */
+} txm_poly_table;
+#define TXM_FUNC_PLAIN 0
+#define TXM_FUNC_MINUS_LOG_ATOM0 1 /* f = -log(atoms[log_atom]) + polynomial part */
+
+/* srcs: device array of n_srcs device pointers (double*).  out: [n_funcs][nrep][nval].
+ * log_atom: atom id used by TXM_FUNC_MINUS_LOG_ATOM0 functions (else ignored). */
+int txm_eval_poly(const txm_poly_table *table_host, const double *const *srcs, int32_t n_srcs,
+                  int32_t log_atom, int64_t nrep, int64_t nval, double *out, txm_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TXMOM_H */

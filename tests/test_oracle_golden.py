@@ -1,0 +1,202 @@
+"""Pin the CPU oracle against the reference's own numbers (CPU only, no GPU).
+
+* seeded notebook outputs of the reference (tests/golden/kat_notebooks.json):
+  reduce_vals layout/values, sampler bookkeeping (Generator.choice on the
+  continued global rng), sample- and block-level bootstrap replicates;
+* the reference's runnable legacy oracle on FixtureData(100, 5, order=5, seed=0)
+  (tests/golden/fixture_legacy.npz): raw moments;
+* the mathematical definition in extended precision (oracle truth_cov).
+"""
+
+import numpy as np
+import pytest
+
+from conftest import rel_close
+
+
+def test_reduce_vals_matches_notebook(orc, kat, idealgas_data):
+    # Data_Organization.ipynb cell 24: data.values for order=2
+    x, u = idealgas_data
+    st = orc.reduce_vals(x, u, order=2)
+    assert st.shape == (2, 3)
+    assert rel_close(st.ravel(), kat["data_org"]["values"], sig=5)
+    # cells 16-22: u, du, xu, dxdu selectors (data.py:854-909)
+    uu, xu = orc.selectors_raw(st)
+    xave, du, dxdu = orc.selectors_central(st)
+    assert rel_close(uu, kat["data_org"]["u"], sig=5)
+    assert rel_close(xu, kat["data_org"]["xu"], sig=5)
+    np.testing.assert_allclose(du, kat["data_org"]["du"], atol=5e-5)
+    np.testing.assert_allclose(dxdu, kat["data_org"]["dxdu"], atol=5e-5)
+    np.testing.assert_allclose(xave, kat["data_org"]["xave"][0], atol=5e-5)
+
+
+def test_vector_observable_matches_notebook(orc, kat, idealgas_data):
+    # cell 47: xv = (x, x^2) -> values[vals=2, 2, 3]
+    x, u = idealgas_data
+    xv = np.stack([x, x**2], axis=1)
+    st = orc.reduce_vals(xv, u, order=2)
+    assert rel_close(st.ravel(), kat["data_org"]["vec_values"], sig=5)
+
+
+def test_sampler_and_bootstrap_match_notebook(orc, kat, idealgas_data, post_data_rng):
+    """cells 35, 41, 48, 52: the reference's `resample({"nrep": 3})` calls, in
+    notebook order, on the global rng continued from the data draw.  Pins
+    sampler == Generator.choice(ndat, (nrep, ndat)) and replicate == weighted
+    central comoments with weights freq[r, i]."""
+    x, u = idealgas_data
+    rng = post_data_rng()
+    N = len(u)
+
+    # cell 35: sample-level bootstrap
+    idx = orc.numpy_sampler_indices(rng, 3, N)
+    freq = orc.indices_to_freq(idx, N)
+    assert (freq.sum(axis=1) == N).all()
+    rep = orc.resample_vals(x, u, freq, order=2)
+    assert rel_close(rep.ravel(), kat["data_org"]["resample_nrep3"], sig=5)
+
+    # cell 39/41: 100 blocks of 1000, block bootstrap (resample_and_reduce)
+    xx = x.reshape(100, -1)
+    uu = u.reshape(100, -1)
+    blocks = np.stack([orc.reduce_vals(xx[b], uu[b], order=2) for b in range(100)])[:, None]  # [100, C=1, 2, 3]
+    first = blocks[:4, 0].ravel()
+    assert rel_close(first, kat["data_org"]["block_values_first6"][: first.size], sig=5)
+    idxb = orc.numpy_sampler_indices(rng, 3, 100)
+    fb = orc.indices_to_freq(idxb, 100)
+    repb = orc.resample_data(blocks, fb, order=2)
+    assert rel_close(repb.ravel(), kat["data_org"]["block_resample_nrep3"], sig=5)
+
+    # cell 48: vector observable, sample-level
+    xv = np.stack([x, x**2], axis=1)
+    idx = orc.numpy_sampler_indices(rng, 3, N)
+    freq = orc.indices_to_freq(idx, N)
+    repv = orc.resample_vals(xv, u, freq, order=2)
+    assert rel_close(repv.ravel(), kat["data_org"]["vec_resample_nrep3"], sig=5)
+
+    # cell 51/52: vector blocks: reduce + block bootstrap
+    xvb = xv.reshape(100, -1, 2)
+    blocksv = np.stack([orc.reduce_vals(xvb[b], uu[b], order=2) for b in range(100)])  # [100, 2, 2, 3]
+    red = orc.reduce_data(blocksv, order=2)
+    assert rel_close(red.ravel(), kat["data_org"]["vec_block_reduce"], sig=5)
+    idxb = orc.numpy_sampler_indices(rng, 3, 100)
+    fb = orc.indices_to_freq(idxb, 100)
+    repvb = orc.resample_data(blocksv, fb, order=2)
+    assert rel_close(repvb.ravel(), kat["data_org"]["vec_block_resample_nrep3"], sig=5)
+
+
+def test_raw_moments_match_legacy(orc, legacy):
+    # tests/test_data.py:7-38 of the reference: rdata.u / rdata.xu vs legacy buildAvgFuncs
+    x, u, order = legacy["x"], legacy["u"], int(legacy["order"])
+    st = orc.reduce_vals(x, u, order)
+    uu, xu = orc.selectors_raw(st)
+    np.testing.assert_allclose(uu[0], legacy["raw_u"], rtol=1e-12)
+    np.testing.assert_allclose(xu.T, legacy["raw_xu"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("order", [1, 4, 6])
+def test_pebay_restatement_vs_definition(orc, order, weighted):
+    rng = np.random.default_rng(10 + order)
+    N, C = 5000, 7
+    u = rng.normal(174.85, 5.31, N)
+    x = 0.3 + 0.01 * u[:, None] + rng.normal(0, 0.2, (N, C))
+    w = rng.random(N) + 0.1 if weighted else None
+    a = orc.reduce_vals(x, u, order, w=w)
+    t = orc.truth_cov(x, u, order, w=w)
+    scale = np.abs(t) + np.std(x) * np.std(u) ** np.arange(order + 1)[None, None, :]
+    assert np.max(np.abs(a - t) / scale) < 1e-11
+
+
+def test_gather_equals_freq(orc):
+    # the reference's DataValues.resample gathers rows by sampler.indices
+    # (data.py:420-431); cmomy's resample_vals weights by freq.  tests/test_data.py:94-112
+    rng = np.random.default_rng(3)
+    N, C, order, nrep = 300, 4, 4, 6
+    u = rng.random(N)
+    x = rng.random((N, C))
+    idx = rng.choice(N, (nrep, N))
+    freq = orc.indices_to_freq(idx, N)
+    a = orc.resample_vals(x, u, freq, order)
+    b = np.stack([orc.reduce_vals(x[i], u[i], order) for i in idx])
+    np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-13)
+
+
+def test_convert_roundtrip_and_definition(orc):
+    rng = np.random.default_rng(5)
+    N, C, order = 1000, 3, 5
+    u = rng.random(N) + 1
+    x = rng.random((N, C))
+    st = orc.reduce_vals(x, u, order)
+    raw = orc.convert_cov(st, to_central=False)
+    for c in range(C):
+        for a in (0, 1):
+            for b in range(order + 1):
+                if a == 0 and b == 0:
+                    continue
+                np.testing.assert_allclose(raw[c, a, b], np.mean(x[:, c] ** a * u**b), rtol=1e-12)
+    back = orc.convert_cov(raw, to_central=True)
+    np.testing.assert_allclose(back, st, rtol=1e-9, atol=1e-12)
+
+
+def test_x_is_u_moments_to_comoments(orc):
+    # data.py:1182-1191: reduce u to order+1 then moments_to_comoments(mom=(1, order))
+    rng = np.random.default_rng(6)
+    u = rng.normal(3.0, 1.0, 2000)
+    order = 4
+    m = orc.reduce_vals_1d(u, order + 1)
+    co = orc.moments_to_comoments(m, order)
+    direct = orc.reduce_vals(u, u, order)
+    np.testing.assert_allclose(co, direct, rtol=1e-10, atol=1e-12)
+    # and back (data.py:899-902): du[0..order+1] from the cmom() form
+    np.testing.assert_allclose(
+        orc.comoments_to_moments_central(orc.cmom(co)), np.r_[1.0, 0.0, m[2:]], rtol=1e-10
+    )
+
+
+def test_philox_known_answers(orc):
+    # Random123 kat_vectors for philox4x32-10
+    kats = [
+        ([0, 0, 0, 0], [0, 0], [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]),
+        ([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2, [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]),
+        ([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0],
+         [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]),
+    ]
+    for ctr, key, want in kats:
+        assert [int(v) for v in orc.philox4x32_10(ctr, key)] == want
+
+
+@pytest.mark.parametrize("ndat", [1, 7, 1023, 1024, 1025, 4097, 30000])
+def test_device_sampler_spec_is_exact_multinomial_shape(orc, ndat):
+    nrep = 4
+    counts = orc.sampler_tile_counts(11, nrep, ndat)
+    assert counts.shape == (nrep, orc.sampler_ntiles(ndat))
+    assert (counts.sum(axis=1) == ndat).all()
+    freq = orc.sampler_freq(11, nrep, ndat, counts=counts)
+    assert (freq >= 0).all() and (freq.sum(axis=1) == ndat).all()
+    # tile sums agree with the stage-2 counts
+    pad = (-ndat) % 1024
+    tiles = np.pad(freq, ((0, 0), (0, pad))).reshape(nrep, -1, 1024).sum(axis=2)
+    assert (tiles == counts).all()
+    # nsamp != ndat
+    f2 = orc.sampler_freq(11, 2, ndat, nsamp=3 * ndat + 1)
+    assert (f2.sum(axis=1) == 3 * ndat + 1).all()
+
+
+def test_device_sampler_statistics(orc):
+    """Counts behave like multinomial(N; 1/N): mean 1, var 1-1/N, pair cov -1/N,
+    and a chi-square over cells pooled across replicates."""
+    ndat, nrep = 5000, 400
+    f = orc.sampler_freq(2024, nrep, ndat).astype(float)
+    assert abs(f.mean() - 1.0) < 1e-12
+    v = f.var(axis=0).mean()
+    assert abs(v - (1 - 1 / ndat)) < 0.01
+    # column totals over replicates ~ Binomial(nrep*ndat, 1/ndat)
+    col = f.sum(axis=0)
+    chi2 = ((col - nrep) ** 2 / nrep).sum()
+    # dof = ndat - 1; 6 sigma band
+    assert abs(chi2 - (ndat - 1)) < 6 * np.sqrt(2 * (ndat - 1))
+    # distribution of single counts ~ Poisson(1) (binomial(N,1/N))
+    hist = np.bincount(f.astype(int).ravel(), minlength=8)[:8] / f.size
+    import math
+
+    pois = np.array([math.exp(-1) / math.factorial(k) for k in range(8)])
+    assert np.max(np.abs(hist - pois)) < 2e-3
