@@ -147,12 +147,16 @@ int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, const doubl
                       size_t ws_bytes, txm_stream stream);
 
 /* ---- a4/a5: CentralMomentsData.reduce / resample_and_reduce ------------- */
-/* data [nrec][C][2][K] -> out [C][2][K]      (data.py:996) */
-int txm_reduce_data(const double *data, int64_t nrec, int64_t C, int order, double *out,
-                    txm_stream stream);
-/* data [nrec][C][2][K], freq [nrep][nrec] -> out [nrep][C][2][K]  (data.py:1048-1052) */
+/* Block bootstrap of pre-reduced states: replicate r merges freq[r][i] copies
+ * of state i.   data [nrec][C][2][K], freq [nrep][nrec] -> out [nrep][C][2][K]
+ *   replaces CentralMomentsData.resample_and_reduce(sampler, dim=rec)
+ *   reference call site: data.py:1048-1052 (DataCentralMoments.resample).
+ * freq == NULL means nrep = 1 with every count 1, i.e.
+ *   CentralMomentsData.reduce(dim=rec)  (data.py:996, DataCentralMoments.reduce). */
+size_t txm_resample_data_ws_bytes(int64_t nrec, int64_t C, int order);
 int txm_resample_data(const double *data, const int64_t *freq, int64_t nrec, int64_t C,
-                      int64_t nrep, int order, double *out, txm_stream stream);
+                      int64_t nrep, int order, double *out, void *ws, size_t ws_bytes,
+                      txm_stream stream);
 
 /* ---- a8/a9: cmom()/rmom()/convert.moments_type -------------------------- */
 /* n states [2][K]; to_central = 0: central -> raw (CentralMomentsData.rmom(),
@@ -181,27 +185,29 @@ typedef struct txm_atom {
   int64_t s_val;  /* element stride per value column */
 } txm_atom;
 
+#define TXM_FUNC_PLAIN 0
+#define TXM_FUNC_MINUS_LOG 1 /* f = -log(atoms[log_atom]) + polynomial part */
+
 typedef struct txm_poly_table {
   int32_t n_funcs;           /* number of functions (orders 0..n_funcs-1) */
   int32_t n_atoms;
   int32_t n_terms;           /* total terms over all functions */
   int32_t n_factors;         /* total factors over all terms */
-  const txm_atom *atoms;     /* [n_atoms]                         (device) */
-  const int32_t *func_term0; /* [n_funcs + 1] term range per func (device) */
-  const double *coef;        /* [n_terms]                         (device) */
-  const int32_t *term_fac0;  /* [n_terms + 1] factor range        (device) */
-  const int32_t *fac_atom;   /* [n_factors] atom id               (device) */
-  const int32_t *fac_pow;    /* [n_factors] integer power (may be negative) */
-  const int32_t *func_flags; /* [n_funcs] bit0: add -log(atom[fac_atom of first
-                                factor of the LAST term])... see TXM_FUNC_* */
+  int32_t log_atom;          /* atom used by TXM_FUNC_MINUS_LOG functions */
+  int32_t pad;
+  const txm_atom *atoms;     /* [n_atoms]                          (device) */
+  const int32_t *func_term0; /* [n_funcs + 1] term range per func  (device) */
+  const int32_t *func_flags; /* [n_funcs] TXM_FUNC_*               (device) */
+  const double *coef;        /* [n_terms]                          (device) */
+  const int32_t *term_fac0;  /* [n_terms + 1] factor range         (device) */
+  const int32_t *fac_atom;   /* [n_factors] atom id                (device) */
+  const int32_t *fac_pow;    /* [n_factors] integer power, may be negative (device) */
 } txm_poly_table;
-#define TXM_FUNC_PLAIN 0
-#define TXM_FUNC_MINUS_LOG_ATOM0 1 /* f = -log(atoms[log_atom]) + polynomial part */
 
-/* srcs: device array of n_srcs device pointers (double*).  out: [n_funcs][nrep][nval].
- * log_atom: atom id used by TXM_FUNC_MINUS_LOG_ATOM0 functions (else ignored). */
+/* srcs: device array of n_srcs device pointers (const double*).
+ * out: [n_funcs][nrep][nval].  The struct itself is read on the host. */
 int txm_eval_poly(const txm_poly_table *table_host, const double *const *srcs, int32_t n_srcs,
-                  int32_t log_atom, int64_t nrep, int64_t nval, double *out, txm_stream stream);
+                  int64_t nrep, int64_t nval, double *out, txm_stream stream);
 
 #ifdef __cplusplus
 }

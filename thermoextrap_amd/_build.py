@@ -1,0 +1,66 @@
+"""Build libtxmom.so (HIP, gfx950 only) in-tree with hipcc.
+
+``python -m thermoextrap_amd._build`` or ``__graft_entry__.build()``.
+hipcc cross-compiles for gfx950 without a GPU present.
+"""
+
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent / "csrc"
+LIB = CSRC / "libtxmom.so"
+SOURCES = ["txm_api.hip", "txm_reduce.hip", "txm_sampler.hip", "txm_small.hip", "txm_resample.hip"]
+HEADERS = ["txm_common.h", "txm_pivot.h", "txm_sampler.h", "../../include/txmom.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (Path(cand).exists() or cand == "hipcc"):
+            return cand
+    return "hipcc"
+
+
+def needs_build() -> bool:
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    return any((CSRC / f).stat().st_mtime > t for f in SOURCES + HEADERS)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> Path:
+    if not force and not needs_build():
+        return LIB
+    objdir = CSRC / "build"
+    objdir.mkdir(exist_ok=True)
+    cc = _hipcc()
+
+    def compile_one(src: str) -> Path:
+        obj = objdir / (src.replace(".hip", ".o"))
+        cmd = [cc, *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    p = build_library(force="--force" in sys.argv, verbose=True)
+    print("built", p)

@@ -1,0 +1,127 @@
+"""ctypes binding of libtxmom.so (include/txmom.h).
+
+There is no CPU fallback: if the library is missing, or no gfx950 device is
+visible when a compute entry point is used, this raises.  Device memory and
+streams are borrowed from torch (plumbing only): arrays cross the ABI as raw
+device pointers and sizes.
+"""
+
+from __future__ import annotations
+
+import ctypes as ct
+from pathlib import Path
+
+from ._build import LIB
+
+c_void_p = ct.c_void_p
+c_i64 = ct.c_int64
+c_int = ct.c_int
+c_size = ct.c_size_t
+
+
+class SamplerSpec(ct.Structure):
+    _fields_ = [("seed", ct.c_uint64), ("nrep", c_i64), ("ndat", c_i64), ("nsamp", c_i64)]
+
+
+class Atom(ct.Structure):
+    _fields_ = [("src", ct.c_int32), ("pad", ct.c_int32), ("offset", c_i64), ("s_rep", c_i64), ("s_val", c_i64)]
+
+
+class PolyTable(ct.Structure):
+    _fields_ = [
+        ("n_funcs", ct.c_int32), ("n_atoms", ct.c_int32), ("n_terms", ct.c_int32), ("n_factors", ct.c_int32),
+        ("log_atom", ct.c_int32), ("pad", ct.c_int32),
+        ("atoms", c_void_p), ("func_term0", c_void_p), ("func_flags", c_void_p), ("coef", c_void_p),
+        ("term_fac0", c_void_p), ("fac_atom", c_void_p), ("fac_pow", c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/txmom.h
+SIGNATURES = {
+    "txm_abi_version": (c_int, []),
+    "txm_last_error": (ct.c_char_p, []),
+    "txm_init": (c_int, [c_int]),
+    "txm_device_count": (c_int, [ct.POINTER(c_int)]),
+    "txm_malloc": (c_int, [ct.POINTER(c_void_p), c_size]),
+    "txm_free": (c_int, [c_void_p]),
+    "txm_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size, c_void_p]),
+    "txm_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size, c_void_p]),
+    "txm_memset": (c_int, [c_void_p, c_int, c_size, c_void_p]),
+    "txm_stream_sync": (c_int, [c_void_p]),
+    "txm_reduce_vals_ws_bytes": (c_size, [c_i64, c_i64, c_int]),
+    "txm_reduce_vals": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p,
+                                c_void_p, c_size, c_void_p]),
+    "txm_reduce_vals_1d_ws_bytes": (c_size, [c_i64, c_i64, c_int]),
+    "txm_reduce_vals_1d": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p,
+                                   c_size, c_void_p]),
+    "txm_indices_to_freq": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_void_p]),
+    "txm_sampler_ntiles": (c_i64, [c_i64]),
+    "txm_sampler_counts_ws_bytes": (c_size, [ct.POINTER(SamplerSpec)]),
+    "txm_sampler_tile_counts": (c_int, [ct.POINTER(SamplerSpec), c_void_p, c_void_p, c_size, c_void_p]),
+    "txm_sampler_freq": (c_int, [ct.POINTER(SamplerSpec), c_void_p, c_void_p, c_void_p]),
+    "txm_resample_vals_ws_bytes": (c_size, [c_i64, c_i64, c_i64, c_int]),
+    "txm_resample_vals": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_i64, c_i64, c_int, c_i64,
+                                  c_void_p, ct.POINTER(SamplerSpec), c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_size, c_void_p]),
+    "txm_resample_data_ws_bytes": (c_size, [c_i64, c_i64, c_int]),
+    "txm_resample_data": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_size,
+                                  c_void_p]),
+    "txm_convert_cov": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p]),
+    "txm_convert_1d": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p]),
+    "txm_eval_poly": (c_int, [ct.POINTER(PolyTable), c_void_p, ct.c_int32, c_i64, c_i64, c_void_p, c_void_p]),
+}
+
+_lib = None
+_gpu_ready = False
+
+
+class TxmError(RuntimeError):
+    pass
+
+
+def load(path: Path | None = None):
+    """Load libtxmom.so and bind every entry point.  No GPU needed for this."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = Path(path) if path else LIB
+    if not p.exists():
+        raise TxmError(
+            f"{p} is missing: the HIP extension has not been built. "
+            "Run `python -m thermoextrap_amd._build` (hipcc, gfx950). There is no CPU fallback."
+        )
+    lib = ct.CDLL(str(p))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == ABI drift: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.txm_abi_version() != 1:
+        raise TxmError(f"ABI version mismatch: library {lib.txm_abi_version()} vs binding 1")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().txm_last_error().decode(errors="replace")
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise TxmError(f"{what or 'libtxmom'} failed (status {rc}): {last_error()}")
+
+
+def require_gpu(device: int | None = None) -> None:
+    """Bind the calling thread to a gfx950 device or raise.  No fallback."""
+    global _gpu_ready
+    lib = load()
+    import torch
+
+    if not torch.cuda.is_available():
+        raise TxmError("no GPU visible to torch: thermoextrap_amd needs an MI355X (gfx950); there is no CPU path")
+    dev = torch.cuda.current_device() if device is None else device
+    check(lib.txm_init(dev), "txm_init")
+    _gpu_ready = True
+
+
+def gpu_ready() -> bool:
+    return _gpu_ready

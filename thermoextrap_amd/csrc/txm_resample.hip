@@ -1,0 +1,342 @@
+// txm_resample.hip -- sample-level bootstrap of central comoments
+// (cmomy.wrap_resample_vals as called from thermoextrap data.py:1803-1810,
+// 1354-1366).
+//
+// out[r] = comoment state of the data with weights w_i * f[r][i].  With the
+// pivot-shifted monomials m[i][c][j] = (x_ic - px_c) (u_i - pu)^j this is a
+// dense contraction over samples
+//        S1[r][c][j] = sum_i f[r][i] * w_i * du_i^j * dx_ic
+//        S0[r][j]    = sum_i f[r][i] * w_i * du_i^j
+// i.e. ~2*K*(C+1) flop per (replicate, sample) against 8*(C+1) bytes per
+// sample read once: FP64-bound for nrep >~ 12, so it runs on the FP64 matrix
+// pipe.  Per wave and per 4 samples:
+//        A_j (16 reps x 4 samples)  = f * w * du^j      one f64 per lane
+//        B   (4 samples x 16 cols)  = dx                one f64 per lane
+//        D_j (16 reps x 16 cols)   += A_j * B           v_mfma_f64_16x16x4_f64
+// so the power index j rides on the A operand (one multiply per j) and B is
+// loaded once per column block; S0 is the row-sum of A_j, kept on the VALU.
+// The MFMA broadcasts f over columns and dx over replicates for free, and the
+// VALU (Philox draws, LDS histogram, u-row sums) co-executes with the matrix
+// pipe of the other resident wave.
+//
+// f comes either from the Philox stage-3 stream (scale mode; the wave fills a
+// private [1024 samples][16 reps] u8 tile in LDS, never touching HBM) or from an
+// explicit int64 freq table (parity mode).
+#include "txm_sampler.h"
+#include "txm_pivot.h"
+
+namespace txm {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+constexpr int RS_BLOCK = 256;          // 4 waves
+constexpr int RS_WAVES = RS_BLOCK / 64;
+constexpr int RS_REPS = 16;            // replicates per wave (MFMA M)
+constexpr int RS_TILE_BYTES = SM_T * RS_REPS;  // u8 [sample][rep]
+
+struct ResampleArgs {
+  const double *x;
+  int64_t ldx_s;
+  const double *u;
+  const double *w;
+  int64_t N;
+  int64_t C;
+  int64_t nrep;
+  const int64_t *freq;      // parity mode
+  const uint32_t *counts;   // scale mode: [nrep][ntiles]
+  uint32_t k0, k1;          // philox key
+  int64_t ntiles;
+  uint32_t last_tile_size;
+  const double *pivot;      // [1 + C]
+  double *part_x;           // [n_chunks][nrep_pad][C_pad][K]
+  double *part_u;           // [n_chunks][nrep_pad][K]
+  int n_chunks;             // multiple of 8
+  int n_rbg;                // replicate-block groups (4 blocks of 16 reps each)
+  int64_t tiles_per_chunk;
+  int64_t nrep_pad;         // n_rbg * 64
+  int64_t C_pad;            // col groups * NBLK * 16
+};
+
+// One wave: 16 replicates x (NBLK*16 columns) x one chunk of tiles.
+template <int K, int NBLK, bool WEIGHTED, bool EXPLICIT>
+__global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = lane & 15;   // A: replicate within block;  B: column within block
+  const int kk = lane >> 4;    // sample slot within the 4-sample step
+
+  // XCD-aware task map: workgroups that share a sample chunk sit on one XCD
+  // (blocks b and b+8 share an XCD) and are dispatched back to back, so the
+  // chunk is streamed from HBM once and re-read from that XCD's L2.
+  const int b = blockIdx.x;
+  const int xcd = b & 7, q = b >> 3;
+  const int chunk = (q / a.n_rbg) * 8 + xcd;
+  const int rbg = q % a.n_rbg;
+  const int colgrp = blockIdx.y;
+  const int64_t rep0 = ((int64_t)rbg * RS_WAVES + wave) * RS_REPS;
+  const int64_t col0 = (int64_t)colgrp * (NBLK * 16);
+
+  const int64_t t_begin = (int64_t)chunk * a.tiles_per_chunk;
+  int64_t t_end = t_begin + a.tiles_per_chunk;
+  if (t_end > a.ntiles) t_end = a.ntiles;
+
+  const double pu = a.pivot[0];
+  double px[NBLK];
+  bool cok[NBLK];
+  int64_t ccol[NBLK];
+#pragma unroll
+  for (int bl = 0; bl < NBLK; ++bl) {
+    const int64_t c = col0 + bl * 16 + row;
+    cok[bl] = c < a.C;
+    ccol[bl] = cok[bl] ? c : 0;
+    px[bl] = a.pivot[1 + ccol[bl]];
+  }
+
+  v4f64 acc[K][NBLK];
+  double usum[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    usum[j] = 0.0;
+#pragma unroll
+    for (int bl = 0; bl < NBLK; ++bl) acc[j][bl] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  }
+
+  unsigned char *tile = lds_raw + (size_t)wave * RS_TILE_BYTES;  // [sample][rep] u8
+  const int64_t my_rep = rep0 + row;
+  const bool rep_ok = my_rep < a.nrep;
+
+  for (int64_t t = t_begin; t < t_end; ++t) {
+    const int64_t i_tile = t * SM_T;
+    const uint32_t tsize = (t == a.ntiles - 1) ? a.last_tile_size : (uint32_t)SM_T;
+
+    if constexpr (!EXPLICIT) {
+      // ---- stage 3 of the sampler: fill this wave's private f tile ---------
+      uint4 *z = reinterpret_cast<uint4 *>(tile);
+#pragma unroll
+      for (int s = 0; s < RS_TILE_BYTES / 16 / 64; ++s) z[s * 64 + lane] = make_uint4(0, 0, 0, 0);
+      __syncthreads();
+      uint32_t *tw = reinterpret_cast<uint32_t *>(tile);
+      for (int rr = 0; rr < RS_REPS; ++rr) {
+        const int64_t r = rep0 + rr;
+        if (r >= a.nrep) break;  // wave-uniform
+        const uint32_t n = a.counts[(size_t)r * a.ntiles + t];
+        const uint32_t inc = 1u << (8 * (rr & 3));
+        const uint32_t wofs = (uint32_t)rr >> 2;
+        sampler_fine_tile(a.k0, a.k1, (uint32_t)r, (uint32_t)t, n, tsize, lane,
+                          [&](uint32_t off) { atomicAdd(&tw[off * (RS_REPS / 4) + wofs], inc); });
+      }
+      __syncthreads();
+    }
+
+    // ---- contraction over the tile, 4 samples per step ----------------------
+    const int nsteps = (int)((tsize + 3u) >> 2);
+#pragma unroll 2
+    for (int s = 0; s < nsteps; ++s) {
+      const uint32_t li = (uint32_t)s * 4u + (uint32_t)kk;  // sample within tile
+      const bool iok = li < tsize;
+      const int64_t i = i_tile + (iok ? li : 0u);
+      double f;
+      if constexpr (EXPLICIT) {
+        f = (iok && rep_ok) ? (double)a.freq[(size_t)my_rep * a.N + i] : 0.0;
+      } else {
+        f = iok ? (double)tile[li * RS_REPS + row] : 0.0;
+      }
+      if constexpr (WEIGHTED) f *= a.w[i];
+      const double du = a.u[i] - pu;
+      double xb[NBLK];
+#pragma unroll
+      for (int bl = 0; bl < NBLK; ++bl) {
+        const double xv = a.x[i * a.ldx_s + ccol[bl]];
+        xb[bl] = cok[bl] ? xv - px[bl] : 0.0;
+      }
+      double av = f;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        usum[j] += av;
+#pragma unroll
+        for (int bl = 0; bl < NBLK; ++bl)
+          acc[j][bl] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, xb[bl], acc[j][bl], 0, 0, 0);
+        av *= du;
+      }
+    }
+    if constexpr (!EXPLICIT) __syncthreads();
+  }
+
+  // ---- write partial sums ---------------------------------------------------
+  // D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+  double *px_out = a.part_x + ((size_t)chunk * a.nrep_pad + rep0) * a.C_pad * K;
+#pragma unroll
+  for (int j = 0; j < K; ++j)
+#pragma unroll
+    for (int bl = 0; bl < NBLK; ++bl)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int rrow = kk + 4 * rg;
+        const int64_t c = col0 + bl * 16 + row;
+        px_out[((size_t)rrow * a.C_pad + c) * K + j] = acc[j][bl][rg];
+      }
+  if (colgrp == 0) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      double v = usum[j];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (kk == 0) a.part_u[((size_t)chunk * a.nrep_pad + rep0 + row) * K + j] = v;
+    }
+  }
+}
+
+// finalize: thread per (rep, col): fixed-order sum over chunks, shift to the
+// cmomy state, out[rep][c][2][K].
+template <int K>
+__global__ __launch_bounds__(256) void resample_finalize_kernel(
+    const double *__restrict__ part_x, const double *__restrict__ part_u, int n_chunks,
+    int64_t nrep_pad, int64_t C_pad, int64_t nrep, int64_t C, const double *__restrict__ pivot,
+    double *__restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nrep * C) return;
+  const int64_t r = e / C, c = e % C;
+  double S0[K], S1[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) S0[j] = S1[j] = 0.0;
+  for (int ch = 0; ch < n_chunks; ++ch) {
+    const double *pu_ = part_u + ((size_t)ch * nrep_pad + r) * K;
+    const double *px_ = part_x + (((size_t)ch * nrep_pad + r) * C_pad + c) * K;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      S0[j] += pu_[j];
+      S1[j] += px_[j];
+    }
+  }
+  double st[2 * K];
+  pivot_sums_to_state<K>(S0, S1, pivot[0], pivot[1 + c], st);
+#pragma unroll
+  for (int q = 0; q < 2 * K; ++q) out[e * 2 * K + q] = st[q];
+}
+
+struct ResamplePlan {
+  int nblk, colgroups, n_rbg, n_chunks;
+  int64_t tiles_per_chunk, nrep_pad, C_pad, ntiles;
+  size_t off_pivot, off_px, off_pu, total;
+};
+
+static ResamplePlan plan_resample(int64_t N, int64_t C, int64_t nrep, int K) {
+  ResamplePlan p;
+  p.nblk = C <= 16 ? 1 : 2;
+  p.colgroups = (int)cdiv(C, p.nblk * 16);
+  p.C_pad = (int64_t)p.colgroups * p.nblk * 16;
+  p.n_rbg = (int)cdiv(nrep, RS_WAVES * RS_REPS);
+  p.nrep_pad = (int64_t)p.n_rbg * RS_WAVES * RS_REPS;
+  p.ntiles = cdiv(N, SM_T);
+  const int64_t target_wgs = (int64_t)num_cus() * 2 * 4;
+  int64_t nc = cdiv(target_wgs, (int64_t)p.n_rbg * p.colgroups);
+  if (nc > p.ntiles) nc = p.ntiles;
+  if (nc < 1) nc = 1;
+  nc = cdiv(nc, 8) * 8;
+  p.tiles_per_chunk = cdiv(p.ntiles, nc);
+  // drop chunk octets that would be entirely empty
+  nc = cdiv(cdiv(p.ntiles, p.tiles_per_chunk), 8) * 8;
+  p.n_chunks = (int)nc;
+  p.off_pivot = 0;
+  p.off_px = align_up((size_t)(1 + C) * sizeof(double), 256);
+  p.off_pu = p.off_px + align_up((size_t)p.n_chunks * p.nrep_pad * p.C_pad * K * sizeof(double), 256);
+  p.total = p.off_pu + align_up((size_t)p.n_chunks * p.nrep_pad * K * sizeof(double), 256);
+  return p;
+}
+
+}  // namespace txm
+
+using namespace txm;
+
+extern "C" size_t txm_resample_vals_ws_bytes(int64_t N, int64_t C, int64_t nrep, int order) {
+  if (N < 1 || C < 1 || nrep < 1 || order < 0 || order > TXM_MAX_ORDER) return 0;
+  return plan_resample(N, C, nrep, order + 1).total;
+}
+
+#define TXM_K_SWITCH(K_, CALL)                          \
+  switch (K_) {                                         \
+    case 1: { constexpr int KK = 1; CALL; } break;      \
+    case 2: { constexpr int KK = 2; CALL; } break;      \
+    case 3: { constexpr int KK = 3; CALL; } break;      \
+    case 4: { constexpr int KK = 4; CALL; } break;      \
+    case 5: { constexpr int KK = 5; CALL; } break;      \
+    case 6: { constexpr int KK = 6; CALL; } break;      \
+    case 7: { constexpr int KK = 7; CALL; } break;      \
+    case 8: { constexpr int KK = 8; CALL; } break;      \
+    case 9: { constexpr int KK = 9; CALL; } break;      \
+    default: set_error("order out of range"); return TXM_ERR_INVALID; \
+  }
+
+namespace txm {
+template <int K>
+static int run_resample(ResampleArgs a, const ResamplePlan &p, bool weighted, bool explicit_,
+                        double *out, hipStream_t st) {
+  dim3 grid((unsigned)(p.n_chunks * p.n_rbg), (unsigned)p.colgroups), block(RS_BLOCK);
+  const size_t lds = explicit_ ? 0 : (size_t)RS_WAVES * RS_TILE_BYTES;
+#define TXM_RS_LAUNCH(NB, WT, EX) \
+  hipLaunchKernelGGL((resample_kernel<K, NB, WT, EX>), grid, block, lds, st, a)
+  if (p.nblk == 1) {
+    if (weighted) { if (explicit_) TXM_RS_LAUNCH(1, true, true); else TXM_RS_LAUNCH(1, true, false); }
+    else          { if (explicit_) TXM_RS_LAUNCH(1, false, true); else TXM_RS_LAUNCH(1, false, false); }
+  } else {
+    if (weighted) { if (explicit_) TXM_RS_LAUNCH(2, true, true); else TXM_RS_LAUNCH(2, true, false); }
+    else          { if (explicit_) TXM_RS_LAUNCH(2, false, true); else TXM_RS_LAUNCH(2, false, false); }
+  }
+#undef TXM_RS_LAUNCH
+  TXM_LAUNCH_CHECK();
+  const int64_t ne = a.nrep * a.C;
+  hipLaunchKernelGGL((resample_finalize_kernel<K>), dim3((unsigned)cdiv(ne, 256)), dim3(256), 0, st,
+                     a.part_x, a.part_u, p.n_chunks, p.nrep_pad, p.C_pad, a.nrep, a.C, a.pivot, out);
+  TXM_LAUNCH_CHECK();
+  return TXM_OK;
+}
+}  // namespace txm
+
+extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, const double *u,
+                                 const double *w, int64_t N, int64_t C, int order, int64_t nrep,
+                                 const int64_t *freq, const txm_sampler_spec *spec,
+                                 const uint32_t *counts, const double *pivot, double *out, void *ws,
+                                 size_t ws_bytes, txm_stream stream) {
+  TXM_REQUIRE(x && u && out && ws, "resample_vals: null pointer");
+  TXM_REQUIRE(N >= 1 && C >= 1 && nrep >= 1, "resample_vals: need N, C, nrep >= 1");
+  TXM_REQUIRE(order >= 0 && order <= TXM_MAX_ORDER, "resample_vals: order %d outside [0, %d]", order,
+              TXM_MAX_ORDER);
+  TXM_REQUIRE(ldx_c == 1 && ldx_s >= C, "resample_vals: x must be (rec, val) row-major (ldx_c == 1)");
+  const bool explicit_ = freq != nullptr;
+  TXM_REQUIRE(explicit_ != (spec != nullptr && counts != nullptr),
+              "resample_vals: give either freq or (spec, counts)");
+  const int K = order + 1;
+  const ResamplePlan p = plan_resample(N, C, nrep, K);
+  if (ws_bytes < p.total) {
+    set_error("resample_vals: workspace too small (%zu < %zu)", ws_bytes, p.total);
+    return TXM_ERR_WORKSPACE;
+  }
+  TXM_REQUIRE((int64_t)p.n_chunks * p.n_rbg < ((int64_t)1 << 31), "resample_vals: grid too large");
+  hipStream_t st = (hipStream_t)stream;
+  double *piv = (double *)((char *)ws + p.off_pivot);
+  if (pivot) {
+    TXM_HIP(hipMemcpyAsync(piv, pivot, sizeof(double) * (size_t)(1 + C), hipMemcpyDeviceToDevice, st));
+  } else {
+    hipLaunchKernelGGL(pivot_kernel, dim3((unsigned)(1 + C)), dim3(256), 0, st, x, ldx_s, (int64_t)1,
+                       u, (int64_t)1, N, piv);
+    TXM_LAUNCH_CHECK();
+  }
+  ResampleArgs a;
+  a.x = x; a.ldx_s = ldx_s; a.u = u; a.w = w; a.N = N; a.C = C; a.nrep = nrep;
+  a.freq = freq; a.counts = counts;
+  a.k0 = a.k1 = 0;
+  a.ntiles = p.ntiles;
+  a.last_tile_size = (uint32_t)(N - (p.ntiles - 1) * SM_T);
+  if (!explicit_) {
+    TXM_REQUIRE(spec->ndat == N && spec->nrep == nrep, "resample_vals: sampler spec does not match N/nrep");
+    a.k0 = (uint32_t)spec->seed;
+    a.k1 = (uint32_t)(spec->seed >> 32);
+  }
+  a.pivot = piv;
+  a.part_x = (double *)((char *)ws + p.off_px);
+  a.part_u = (double *)((char *)ws + p.off_pu);
+  a.n_chunks = p.n_chunks; a.n_rbg = p.n_rbg; a.tiles_per_chunk = p.tiles_per_chunk;
+  a.nrep_pad = p.nrep_pad; a.C_pad = p.C_pad;
+  TXM_K_SWITCH(K, return run_resample<KK>(a, p, w != nullptr, explicit_, out, st));
+  return TXM_OK;
+}

@@ -1,0 +1,100 @@
+// txm_sampler.h -- device side of the counter-based multinomial sampler.
+// Normative statement of the stream: oracle/philox_oracle.c (bit-for-bit).
+#pragma once
+#include "txm_common.h"
+
+namespace txm {
+
+constexpr int SM_LT = 10;
+constexpr int SM_T = 1 << SM_LT;  // samples per tile
+constexpr int SM_V1 = 16384;      // stage-1 virtual lanes per replicate
+constexpr int SM_NB1_MAX = 16384; // coarse bins (u32 in 64 KiB of LDS)
+
+struct SamplerGeom {
+  int64_t ntiles, nb1, BS, last_bin_size, last_tile_size;
+  int s, k1;
+};
+
+static inline int sampler_geometry(int64_t ndat, SamplerGeom *g) {
+  g->ntiles = (ndat + SM_T - 1) / SM_T;
+  g->s = 0;
+  while (((g->ntiles + ((int64_t)1 << g->s) - 1) >> g->s) > SM_NB1_MAX) g->s++;
+  if (g->s > 6) return -1;
+  g->nb1 = (g->ntiles + ((int64_t)1 << g->s) - 1) >> g->s;
+  g->BS = (int64_t)SM_T << g->s;
+  g->last_bin_size = ndat - (g->nb1 - 1) * g->BS;
+  g->last_tile_size = ndat - (g->ntiles - 1) * SM_T;
+  g->k1 = 0;
+  while (((int64_t)1 << g->k1) < g->nb1) g->k1++;
+  return 0;
+}
+
+struct Philox4 {
+  uint32_t w[4];
+};
+
+__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                 uint32_t k0, uint32_t k1) {
+  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0;
+    c1 = lo1;
+    c2 = n2;
+    c3 = lo0;
+    k0 += W0;
+    k1 += W1;
+  }
+  Philox4 o;
+  o.w[0] = c0;
+  o.w[1] = c1;
+  o.w[2] = c2;
+  o.w[3] = c3;
+  return o;
+}
+
+__device__ __forceinline__ uint32_t slot16(const Philox4 &o, int e) {
+  return (o.w[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+}
+
+// Stage 3 for one (replicate r, tile t) executed by one wave: every accepted
+// draw calls hit(off) with off in [0, tile_size).  `n` = counts[r][t].
+template <class Hit>
+__device__ __forceinline__ void sampler_fine_tile(uint32_t k0, uint32_t k1, uint32_t r, uint32_t t,
+                                                  uint32_t n, uint32_t tile_size, int lane, Hit hit) {
+  uint32_t quota = n / 64u + ((uint32_t)lane < (n % 64u) ? 1u : 0u);
+  uint32_t j = 0;
+  const uint32_t c1 = t * 64u + (uint32_t)lane;
+  if (tile_size == (uint32_t)SM_T) {
+    // full tile: every slot is accepted -> branch-free body
+    while (quota >= 8u) {
+      const Philox4 o = philox4x32_10(j++, c1, r, 3u, k0, k1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) hit(slot16(o, e) & (uint32_t)(SM_T - 1));
+      quota -= 8u;
+    }
+    if (quota) {
+      const Philox4 o = philox4x32_10(j++, c1, r, 3u, k0, k1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if ((uint32_t)e < quota) hit(slot16(o, e) & (uint32_t)(SM_T - 1));
+    }
+  } else {
+    while (quota) {
+      const Philox4 o = philox4x32_10(j++, c1, r, 3u, k0, k1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t off = slot16(o, e) & (uint32_t)(SM_T - 1);
+        if (quota && off < tile_size) {
+          hit(off);
+          --quota;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace txm

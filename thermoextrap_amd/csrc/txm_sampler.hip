@@ -1,0 +1,254 @@
+// txm_sampler.hip -- sampler kernels: indices -> freq histogram (parity mode,
+// cmomy's indices_to_freq) and the counter-based exact multinomial sampler
+// (scale mode) that replaces `rng.choice(ndat, (nrep, ndat))` + histogram
+// (cmomy factory_sampler as reached from data.py:1782-1789) without ever
+// materialising the (nrep, ndat) index/freq tables.
+//
+// Stage 1: per replicate, nsamp draws of a coarse bin id into LDS bins (u32),
+//          16 workgroups of 1024 threads per replicate, flushed with one global
+//          atomic per non-empty bin.
+// Stage 2: one wave per (replicate, coarse bin) splits its count over the 2^s
+//          tiles of the bin.
+// Stage 3: lives in txm_sampler.h and is executed inside the bootstrap kernel
+//          (txm_resample.hip), tile by tile, straight into LDS.
+#include "txm_sampler.h"
+
+namespace txm {
+
+__device__ int g_index_error;
+
+__global__ void clear_index_error_kernel() { g_index_error = 0; }
+
+__global__ __launch_bounds__(256) void indices_to_freq_kernel(const int64_t *__restrict__ idx,
+                                                              int64_t nrep, int64_t nsamp,
+                                                              int64_t ndat,
+                                                              int64_t *__restrict__ freq) {
+  const int64_t r = blockIdx.y;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nsamp;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = idx[r * nsamp + k];
+    if (j < 0 || j >= ndat) {
+      g_index_error = 1;
+    } else {
+      atomicAdd(reinterpret_cast<unsigned long long *>(freq + r * ndat + j), 1ULL);
+    }
+  }
+  (void)nrep;
+}
+
+// ---- stage 1 ---------------------------------------------------------------
+// grid (SM_V1 / 1024, nrep), block 1024, dynamic LDS = nb1 * 4 bytes.
+__global__ __launch_bounds__(1024) void sampler_stage1_kernel(uint32_t k0, uint32_t k1key,
+                                                              int64_t nsamp, SamplerGeom g,
+                                                              uint32_t *__restrict__ n1) {
+  extern __shared__ uint32_t bins[];
+  const uint32_t r = blockIdx.y;
+  const uint32_t v = blockIdx.x * 1024u + threadIdx.x;
+  const uint32_t nb1 = (uint32_t)g.nb1;
+  for (uint32_t b = threadIdx.x; b < nb1; b += 1024u) bins[b] = 0u;
+  __syncthreads();
+  uint64_t quota = (uint64_t)(nsamp / SM_V1) + ((int64_t)v < (nsamp % SM_V1) ? 1u : 0u);
+  const uint32_t mask = (1u << g.k1) - 1u;
+  const bool last_partial = g.last_bin_size < g.BS;
+  const uint32_t bsmask = (uint32_t)(g.BS - 1);
+  const uint32_t last_size = (uint32_t)g.last_bin_size;
+  uint32_t j = 0, m = 0;
+  while (quota) {
+    const Philox4 o = philox4x32_10(j++, v, r, 1u, k0, k1key);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t c = slot16(o, e) & mask;
+      bool ok = quota && (c < nb1);
+      if (ok && last_partial && c == nb1 - 1u) {
+        const Philox4 o2 = philox4x32_10(m++, v, r, 4u, k0, k1key);
+        ok = (o2.w[0] & bsmask) < last_size;
+      }
+      if (ok) {
+        atomicAdd(&bins[c], 1u);
+        --quota;
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < nb1; b += 1024u) {
+    const uint32_t cnt = bins[b];
+    if (cnt) atomicAdd(&n1[(size_t)r * nb1 + b], cnt);
+  }
+}
+
+__global__ void sampler_fill_single_bin_kernel(uint32_t *__restrict__ counts, int64_t nrep,
+                                               uint32_t nsamp) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < nrep) counts[r] = nsamp;
+}
+
+// ---- stage 2 ---------------------------------------------------------------
+// one wave per (r, b); block 256 = 4 waves.
+__global__ __launch_bounds__(256) void sampler_stage2_kernel(uint32_t k0, uint32_t k1key,
+                                                             int64_t nrep, SamplerGeom g,
+                                                             const uint32_t *__restrict__ n1,
+                                                             uint32_t *__restrict__ counts) {
+  __shared__ uint32_t sub[4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t task = (int64_t)blockIdx.x * 4 + wave;
+  const bool active = task < nrep * g.nb1;
+  const uint32_t r = active ? (uint32_t)(task / g.nb1) : 0u;
+  const uint32_t b = active ? (uint32_t)(task % g.nb1) : 0u;
+  sub[wave][lane] = 0u;
+  __syncthreads();
+  if (active) {
+    const uint32_t n = n1[(size_t)r * g.nb1 + b];
+    const uint32_t size_b = (b == (uint32_t)g.nb1 - 1u) ? (uint32_t)g.last_bin_size : (uint32_t)g.BS;
+    const uint32_t bsmask = (uint32_t)(g.BS - 1);
+    uint32_t quota = n / 64u + ((uint32_t)lane < (n % 64u) ? 1u : 0u);
+    uint32_t j = 0;
+    const uint32_t c1 = b * 64u + (uint32_t)lane;
+    while (quota) {
+      const Philox4 o = philox4x32_10(j++, c1, r, 2u, k0, k1key);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t off = slot16(o, e) & bsmask;
+        if (quota && off < size_b) {
+          atomicAdd(&sub[wave][off >> SM_LT], 1u);
+          --quota;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (active && lane < (1 << g.s)) {
+    const int64_t t = ((int64_t)b << g.s) + lane;
+    if (t < g.ntiles) counts[(size_t)r * g.ntiles + t] = sub[wave][lane];
+  }
+}
+
+// ---- materialise freq (testing / small sizes) -------------------------------
+// one wave per (r, t); block 256 = 4 waves, each with a private 1024-bin tile.
+__global__ __launch_bounds__(256) void sampler_freq_kernel(uint32_t k0, uint32_t k1key,
+                                                           int64_t nrep, int64_t ndat,
+                                                           SamplerGeom g,
+                                                           const uint32_t *__restrict__ counts,
+                                                           int64_t *__restrict__ freq) {
+  __shared__ uint32_t tile[4][SM_T];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t task = (int64_t)blockIdx.x * 4 + wave;
+  const bool active = task < nrep * g.ntiles;
+  const uint32_t r = active ? (uint32_t)(task / g.ntiles) : 0u;
+  const uint32_t t = active ? (uint32_t)(task % g.ntiles) : 0u;
+  for (int i = lane; i < SM_T; i += 64) tile[wave][i] = 0u;
+  __syncthreads();
+  const uint32_t tsize = (t == (uint32_t)g.ntiles - 1u) ? (uint32_t)g.last_tile_size : (uint32_t)SM_T;
+  if (active) {
+    const uint32_t n = counts[(size_t)r * g.ntiles + t];
+    uint32_t *tl = tile[wave];
+    sampler_fine_tile(k0, k1key, r, t, n, tsize, lane, [&](uint32_t off) { atomicAdd(&tl[off], 1u); });
+  }
+  __syncthreads();
+  if (active) {
+    for (uint32_t i = lane; i < tsize; i += 64)
+      freq[(size_t)r * ndat + (size_t)t * SM_T + i] = (int64_t)tile[wave][i];
+  }
+}
+
+}  // namespace txm
+
+using namespace txm;
+
+extern "C" int txm_indices_to_freq(const int64_t *indices, int64_t nrep, int64_t nsamp,
+                                   int64_t ndat, int64_t *freq, txm_stream stream) {
+  TXM_REQUIRE(indices && freq, "indices_to_freq: null pointer");
+  TXM_REQUIRE(nrep >= 1 && nsamp >= 1 && ndat >= 1 && nrep <= 65535, "indices_to_freq: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  TXM_HIP(hipMemsetAsync(freq, 0, sizeof(int64_t) * (size_t)nrep * ndat, st));
+  hipLaunchKernelGGL(clear_index_error_kernel, dim3(1), dim3(1), 0, st);
+  TXM_LAUNCH_CHECK();
+  int gx = (int)cdiv(nsamp, 256 * 4);
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(indices_to_freq_kernel, dim3(gx, (unsigned)nrep), dim3(256), 0, st, indices,
+                     nrep, nsamp, ndat, freq);
+  TXM_LAUNCH_CHECK();
+  int flag = 0;
+  TXM_HIP(hipMemcpyFromSymbolAsync(&flag, HIP_SYMBOL(g_index_error), sizeof(int), 0,
+                                   hipMemcpyDeviceToHost, st));
+  TXM_HIP(hipStreamSynchronize(st));
+  if (flag) {
+    set_error("indices_to_freq: index outside [0, %lld)", (long long)ndat);
+    return TXM_ERR_INVALID;
+  }
+  return TXM_OK;
+}
+
+extern "C" int64_t txm_sampler_ntiles(int64_t ndat) { return ndat < 1 ? 0 : (ndat + SM_T - 1) / SM_T; }
+
+static int check_spec(const txm_sampler_spec *sp, SamplerGeom *g, int64_t *nsamp) {
+  TXM_REQUIRE(sp, "sampler: null spec");
+  TXM_REQUIRE(sp->nrep >= 1 && sp->nrep <= 65535, "sampler: nrep=%lld outside [1, 65535]",
+              (long long)sp->nrep);
+  TXM_REQUIRE(sp->ndat >= 1, "sampler: ndat < 1");
+  *nsamp = sp->nsamp > 0 ? sp->nsamp : sp->ndat;
+  TXM_REQUIRE(*nsamp < ((int64_t)1 << 32), "sampler: nsamp >= 2^32 unsupported");
+  if (sampler_geometry(sp->ndat, g) != 0) {
+    set_error("sampler: ndat=%lld too large (max 2^30)", (long long)sp->ndat);
+    return TXM_ERR_UNSUPPORTED;
+  }
+  return TXM_OK;
+}
+
+extern "C" size_t txm_sampler_counts_ws_bytes(const txm_sampler_spec *sp) {
+  SamplerGeom g;
+  int64_t nsamp;
+  if (check_spec(sp, &g, &nsamp) != TXM_OK) return 0;
+  return (size_t)sp->nrep * (size_t)g.nb1 * sizeof(uint32_t) + 256;
+}
+
+extern "C" int txm_sampler_tile_counts(const txm_sampler_spec *sp, uint32_t *counts, void *ws,
+                                       size_t ws_bytes, txm_stream stream) {
+  SamplerGeom g;
+  int64_t nsamp;
+  int rc = check_spec(sp, &g, &nsamp);
+  if (rc != TXM_OK) return rc;
+  TXM_REQUIRE(counts, "sampler: null counts");
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t k0 = (uint32_t)sp->seed, k1 = (uint32_t)(sp->seed >> 32);
+  if (g.nb1 == 1) {
+    hipLaunchKernelGGL(sampler_fill_single_bin_kernel, dim3((unsigned)cdiv(sp->nrep, 256)),
+                       dim3(256), 0, st, counts, sp->nrep, (uint32_t)nsamp);
+    TXM_LAUNCH_CHECK();
+    return TXM_OK;
+  }
+  uint32_t *n1 = counts;
+  if (g.s > 0) {
+    if (!ws || ws_bytes < txm_sampler_counts_ws_bytes(sp)) {
+      set_error("sampler: workspace too small");
+      return TXM_ERR_WORKSPACE;
+    }
+    n1 = (uint32_t *)ws;
+  }
+  TXM_HIP(hipMemsetAsync(n1, 0, sizeof(uint32_t) * (size_t)sp->nrep * g.nb1, st));
+  hipLaunchKernelGGL(sampler_stage1_kernel, dim3(SM_V1 / 1024, (unsigned)sp->nrep), dim3(1024),
+                     (size_t)g.nb1 * sizeof(uint32_t), st, k0, k1, nsamp, g, n1);
+  TXM_LAUNCH_CHECK();
+  if (g.s > 0) {
+    const int64_t tasks = sp->nrep * g.nb1;
+    hipLaunchKernelGGL(sampler_stage2_kernel, dim3((unsigned)cdiv(tasks, 4)), dim3(256), 0, st, k0,
+                       k1, sp->nrep, g, n1, counts);
+    TXM_LAUNCH_CHECK();
+  }
+  return TXM_OK;
+}
+
+extern "C" int txm_sampler_freq(const txm_sampler_spec *sp, const uint32_t *counts, int64_t *freq,
+                                txm_stream stream) {
+  SamplerGeom g;
+  int64_t nsamp;
+  int rc = check_spec(sp, &g, &nsamp);
+  if (rc != TXM_OK) return rc;
+  TXM_REQUIRE(counts && freq, "sampler_freq: null pointer");
+  const int64_t tasks = sp->nrep * g.ntiles;
+  TXM_REQUIRE(cdiv(tasks, 4) < ((int64_t)1 << 31), "sampler_freq: too many tiles");
+  const uint32_t k0 = (uint32_t)sp->seed, k1 = (uint32_t)(sp->seed >> 32);
+  hipLaunchKernelGGL(sampler_freq_kernel, dim3((unsigned)cdiv(tasks, 4)), dim3(256), 0,
+                     (hipStream_t)stream, k0, k1, sp->nrep, sp->ndat, g, counts, freq);
+  TXM_LAUNCH_CHECK();
+  return TXM_OK;
+}

@@ -1,0 +1,282 @@
+"""Device-level calls into libtxmom: torch CUDA tensors in, torch CUDA tensors out.
+
+Thin layer over the C ABI (include/txmom.h): allocates outputs and scratch with
+torch, passes raw pointers and the current torch stream, checks status codes.
+The labelled-array API that mirrors the reference sits on top (moments.py,
+data.py); nothing here knows about dims or names.
+"""
+
+from __future__ import annotations
+
+import ctypes as ct
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import SamplerSpec, check
+
+F64 = torch.float64
+_ws_cache: dict[tuple[int, str], torch.Tensor] = {}
+
+
+def _L():
+    if not _lib.gpu_ready():
+        _lib.require_gpu()
+    return _lib.load()
+
+
+def _stream():
+    return ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ct.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def workspace(nbytes: int, tag: str = "main") -> torch.Tensor:
+    """Grow-only scratch buffer per (device, tag)."""
+    key = (torch.cuda.current_device(), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _ws_cache.pop(key, None)
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device="cuda")
+        _ws_cache[key] = buf
+    return buf
+
+
+def to_device(a, dtype=F64) -> torch.Tensor:
+    if isinstance(a, torch.Tensor):
+        return a.to(device="cuda", dtype=dtype)
+    return torch.as_tensor(np.asarray(a), dtype=dtype).to("cuda")
+
+
+def _check_f64_cuda(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == F64):
+        raise TypeError(f"{name} must be a float64 CUDA tensor")
+
+
+# ---------------------------------------------------------------------------
+def reduce_vals(x: torch.Tensor, u: torch.Tensor, order: int, w: torch.Tensor | None = None) -> torch.Tensor:
+    """x: (N, C) with either stride(1) == 1 or stride(0) == 1 (a transposed view
+    of a (C, N) array), or (N,).  Returns (C, 2, K) (or (2, K))."""
+    L = _L()
+    _check_f64_cuda(x, "x")
+    _check_f64_cuda(u, "u")
+    squeeze = x.dim() == 1
+    x2 = x.unsqueeze(1) if squeeze else x
+    if x2.dim() != 2:
+        raise ValueError("x must be (N,) or (N, C)")
+    N, C = x2.shape
+    if u.shape != (N,):
+        raise ValueError(f"u must have shape ({N},), got {tuple(u.shape)}")
+    u = u.contiguous()
+    if w is not None:
+        _check_f64_cuda(w, "w")
+        if w.shape != (N,):
+            raise ValueError("w must have shape (N,)")
+        w = w.contiguous()
+    if C == 1:
+        x2 = x2.contiguous()
+        ls, lc = 1, 1  # a single contiguous series
+    elif x2.stride(1) == 1 and (N == 1 or x2.stride(0) >= C):
+        ls, lc = (x2.stride(0) if N > 1 else C), 1  # (rec, val) row-major, pitch ls
+    elif x2.stride(0) == 1 and (C == 1 or x2.stride(1) >= N):
+        ls, lc = 1, x2.stride(1)  # (val, rec): every column contiguous along samples
+    else:
+        x2 = x2.contiguous()
+        ls, lc = C, 1
+    out = torch.empty((C, 2, order + 1), dtype=F64, device="cuda")
+    nws = L.txm_reduce_vals_ws_bytes(N, C, order)
+    ws = workspace(nws)
+    check(
+        L.txm_reduce_vals(_ptr(x2), ls, lc, _ptr(u), _ptr(w), N, C, order, _ptr(out), _ptr(ws), ws.numel(), _stream()),
+        "txm_reduce_vals",
+    )
+    return out[0] if squeeze else out
+
+
+def reduce_vals_1d(u: torch.Tensor, mom: int, w: torch.Tensor | None = None) -> torch.Tensor:
+    """u: (R, N) rows contiguous, or (N,).  Returns (R, mom+1) / (mom+1,)."""
+    L = _L()
+    _check_f64_cuda(u, "u")
+    squeeze = u.dim() == 1
+    u2 = u.unsqueeze(0) if squeeze else u
+    if u2.stride(1) != 1:
+        u2 = u2.contiguous()
+    R, N = u2.shape
+    if w is not None:
+        _check_f64_cuda(w, "w")
+        w = w.contiguous()
+    M = mom + 1
+    out = torch.empty((R, M), dtype=F64, device="cuda")
+    ws = workspace(L.txm_reduce_vals_1d_ws_bytes(N, R, M))
+    check(
+        L.txm_reduce_vals_1d(_ptr(u2), u2.stride(0) if R > 1 else N, 1, _ptr(w), N, R, M, _ptr(out), _ptr(ws),
+                             ws.numel(), _stream()),
+        "txm_reduce_vals_1d",
+    )
+    return out[0] if squeeze else out
+
+
+def indices_to_freq(indices: torch.Tensor, ndat: int | None = None) -> torch.Tensor:
+    L = _L()
+    idx = indices.to(device="cuda", dtype=torch.int64).contiguous()
+    nrep, nsamp = idx.shape
+    ndat = nsamp if ndat is None else int(ndat)
+    freq = torch.empty((nrep, ndat), dtype=torch.int64, device="cuda")
+    check(L.txm_indices_to_freq(_ptr(idx), nrep, nsamp, ndat, _ptr(freq), _stream()), "txm_indices_to_freq")
+    return freq
+
+
+class DeviceSampler:
+    """Counter-based exact multinomial sampler (include/txmom.h txm_sampler_*).
+
+    Holds only the per-(replicate, tile) draw counts (uint32, nrep x ceil(ndat/1024));
+    the per-sample counts are regenerated inside the bootstrap kernel.
+    """
+
+    def __init__(self, seed: int, nrep: int, ndat: int, nsamp: int = 0):
+        L = _L()
+        self.spec = SamplerSpec(seed=0, nrep=int(nrep), ndat=int(ndat), nsamp=int(nsamp))
+        self.ntiles = int(L.txm_sampler_ntiles(ndat))
+        self.counts = torch.empty((nrep, self.ntiles), dtype=torch.int32, device="cuda")  # bit pattern of uint32
+        self._nws = L.txm_sampler_counts_ws_bytes(ct.byref(self.spec))
+        if self._nws == 0:
+            raise _lib.TxmError(f"sampler spec rejected: {_lib.last_error()}")
+        self.draw(seed)
+
+    def draw(self, seed: int) -> "DeviceSampler":
+        """(Re)draw the tile counts for a new seed, reusing the buffers."""
+        L = _L()
+        self.spec.seed = int(seed) & (2**64 - 1)
+        ws = workspace(self._nws, "sampler")
+        check(
+            L.txm_sampler_tile_counts(ct.byref(self.spec), _ptr(self.counts), _ptr(ws), ws.numel(), _stream()),
+            "txm_sampler_tile_counts",
+        )
+        return self
+
+    @property
+    def seed(self):
+        return self.spec.seed
+
+    @property
+    def nrep(self):
+        return self.spec.nrep
+
+    @property
+    def ndat(self):
+        return self.spec.ndat
+
+    def freq(self) -> torch.Tensor:
+        L = _L()
+        out = torch.empty((self.spec.nrep, self.spec.ndat), dtype=torch.int64, device="cuda")
+        check(L.txm_sampler_freq(ct.byref(self.spec), _ptr(self.counts), _ptr(out), _stream()), "txm_sampler_freq")
+        return out
+
+
+def resample_vals(
+    x: torch.Tensor,
+    u: torch.Tensor,
+    order: int,
+    *,
+    freq: torch.Tensor | None = None,
+    sampler: DeviceSampler | None = None,
+    w: torch.Tensor | None = None,
+    pivot: torch.Tensor | None = None,
+    out: torch.Tensor | None = None,
+) -> torch.Tensor:
+    """(nrep, C, 2, K) bootstrap states; x is (N, C) row-major (or (N,))."""
+    L = _L()
+    _check_f64_cuda(x, "x")
+    _check_f64_cuda(u, "u")
+    squeeze = x.dim() == 1
+    x2 = x.unsqueeze(1) if squeeze else x
+    if x2.stride(1) != 1 and x2.shape[1] > 1:
+        x2 = x2.contiguous()
+    N, C = x2.shape
+    ls = x2.stride(0) if N > 1 else C
+    if C == 1 and x2.stride(1) != 1:
+        x2 = x2.contiguous()
+        ls = 1
+    ls = max(ls, C)
+    u = u.contiguous()
+    if w is not None:
+        _check_f64_cuda(w, "w")
+        w = w.contiguous()
+    if (freq is None) == (sampler is None):
+        raise ValueError("give exactly one of freq= or sampler=")
+    if freq is not None:
+        freq = freq.to(device="cuda", dtype=torch.int64).contiguous()
+        if freq.dim() != 2 or freq.shape[1] != N:
+            raise ValueError(f"freq must be (nrep, {N}), got {tuple(freq.shape)}")
+        nrep = freq.shape[0]
+        spec_p, counts_p = None, None
+    else:
+        if sampler.ndat != N:
+            raise ValueError(f"sampler.ndat={sampler.ndat} must equal N={N}")
+        nrep = sampler.nrep
+        spec_p, counts_p = ct.byref(sampler.spec), _ptr(sampler.counts)
+    if pivot is not None:
+        _check_f64_cuda(pivot, "pivot")
+        pivot = pivot.contiguous()
+        if pivot.numel() != 1 + C:
+            raise ValueError("pivot must have 1 + C entries")
+    if out is None:
+        out = torch.empty((nrep, C, 2, order + 1), dtype=F64, device="cuda")
+    ws = workspace(L.txm_resample_vals_ws_bytes(N, C, nrep, order))
+    check(
+        L.txm_resample_vals(_ptr(x2), ls, 1, _ptr(u), _ptr(w), N, C, order, nrep, _ptr(freq), spec_p, counts_p,
+                            _ptr(pivot), _ptr(out), _ptr(ws), ws.numel(), _stream()),
+        "txm_resample_vals",
+    )
+    return out[:, 0] if squeeze else out
+
+
+def resample_data(data: torch.Tensor, freq: torch.Tensor | None, order: int) -> torch.Tensor:
+    """data (nrec, C, 2, K); freq (nrep, nrec) or None (plain reduce) -> (nrep, C, 2, K)."""
+    L = _L()
+    _check_f64_cuda(data, "data")
+    data = data.contiguous()
+    nrec, C = data.shape[:2]
+    if data.shape[2:] != (2, order + 1):
+        raise ValueError("data must be (nrec, C, 2, order+1)")
+    if freq is not None:
+        freq = freq.to(device="cuda", dtype=torch.int64).contiguous()
+        if freq.shape[1] != nrec:
+            raise ValueError("freq must be (nrep, nrec)")
+        nrep = freq.shape[0]
+    else:
+        nrep = 1
+    out = torch.empty((nrep, C, 2, order + 1), dtype=F64, device="cuda")
+    ws = workspace(L.txm_resample_data_ws_bytes(nrec, C, order))
+    check(
+        L.txm_resample_data(_ptr(data), _ptr(freq), nrec, C, nrep, order, _ptr(out), _ptr(ws), ws.numel(), _stream()),
+        "txm_resample_data",
+    )
+    return out
+
+
+def convert_cov(states: torch.Tensor, to_central: bool) -> torch.Tensor:
+    L = _L()
+    _check_f64_cuda(states, "states")
+    s = states.contiguous()
+    K = s.shape[-1]
+    if s.shape[-2] != 2:
+        raise ValueError("states must be (..., 2, K)")
+    out = torch.empty_like(s)
+    check(L.txm_convert_cov(_ptr(s), _ptr(out), s.numel() // (2 * K), K - 1, int(to_central), _stream()),
+          "txm_convert_cov")
+    return out
+
+
+def convert_1d(states: torch.Tensor, to_central: bool) -> torch.Tensor:
+    L = _L()
+    _check_f64_cuda(states, "states")
+    s = states.contiguous()
+    M = s.shape[-1]
+    out = torch.empty_like(s)
+    check(L.txm_convert_1d(_ptr(s), _ptr(out), s.numel() // M, M, int(to_central), _stream()), "txm_convert_1d")
+    return out
