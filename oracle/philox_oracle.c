@@ -24,12 +24,21 @@
  *     off = Philox(ctr=(m, v, r, 4)).w0 & (BS-1) with m = running count of such
  *     events on this lane, and reject unless off < size(last bin).  Accepted
  *     draws increment n1[r][c] until the quota is met.
- *   Stage 2 (per replicate r, coarse bin b; only when s > 0): 64 lanes, quota
- *     split of n1[r][b]; ctr = (j, b*64 + lane, r, 2); slot z: off = z & (BS-1),
- *     reject unless off < size(bin b); n2[r][b*2^s + (off >> 10)] += 1.
- *   Stage 3 (per replicate r, tile t): 64 lanes, quota split of n2[r][t];
- *     ctr = (j, t*64 + lane, r, 3); slot z: off = z & 1023, reject unless
- *     off < size(tile t); freq[r][t*1024 + off] += 1.
+ *   Stage 2 (per replicate r, coarse bin b; only when s > 0), n = n1[r][b]:
+ *     full bin (covers 2^s whole tiles): draw d in [0, n) uses field d % F of
+ *     Philox call c = d / F, F = 4 * floor(32 / s); field k of word w is bits
+ *     [k*s, (k+1)*s) (k < floor(32/s)), fields ordered word-major;
+ *     ctr = (c, b, r, 2).  The field value is the tile inside the bin.
+ *     last bin when partial: 64 lanes, quota split of n; ctr = (j, b*64 + lane,
+ *     r, 5); 16-bit slot z: off = z & (BS-1), reject unless off < size(bin b);
+ *     tile inside the bin = off >> 10.
+ *   Stage 3 (per replicate r, tile t), n = n2[r][t]:
+ *     full tile: draw d uses field d % 12 of call c = d / 12 (three 10-bit
+ *     fields per word: bits 0-9, 10-19, 20-29); ctr = (c, t, r, 3); the field
+ *     value is the sample inside the tile.
+ *     last tile when partial: 64 lanes, quota split of n; ctr = (j, t*64 + lane,
+ *     r, 6); 16-bit slot z: off = z & 1023, reject unless off < size(tile t).
+ *   freq[r][t*1024 + off] += 1 for every stage-3 draw.
  * Acceptance regions are exactly proportional to the number of samples a bin
  * covers, so every draw is uniform over [0, ndat) and the tables are exactly
  * multinomial.
@@ -127,20 +136,32 @@ int orc_sampler_tile_counts(uint64_t seed, int64_t nrep, int64_t ndat, int64_t n
     if (g.s == 0) {
       for (int64_t b = 0; b < g.nb1; ++b) n2[b] = n1[b];
     } else {
+      const int fpw = 32 / g.s, F = 4 * fpw; /* fields per word / per call */
+      const uint32_t fmask = ((uint32_t)1 << g.s) - 1;
       for (int64_t b = 0; b < g.nb1; ++b) {
         const int64_t n = n1[b];
         const int64_t size_b = (b == g.nb1 - 1) ? g.last_bin_size : g.BS;
-        for (int lane = 0; lane < 64; ++lane) {
-          int64_t quota = n / 64 + (lane < n % 64 ? 1 : 0);
-          uint32_t j = 0;
-          while (quota > 0) {
+        if (size_b == g.BS) {
+          for (int64_t c = 0; c * F < n; ++c) {
             uint32_t o[4];
-            philox4x32_10(j++, (uint32_t)(b * 64 + lane), (uint32_t)r, 2u, k0, k1, o);
-            for (int e = 0; e < 8 && quota > 0; ++e) {
-              const int64_t off = slot16(o, e) & (uint32_t)(g.BS - 1);
-              if (off >= size_b) continue;
-              n2[(b << g.s) + (off >> SM_LT)]++;
-              quota--;
+            philox4x32_10((uint32_t)c, (uint32_t)b, (uint32_t)r, 2u, k0, k1, o);
+            const int64_t nd = (n - c * F < F) ? n - c * F : F;
+            for (int64_t q = 0; q < nd; ++q)
+              n2[(b << g.s) + ((o[q / fpw] >> (g.s * (int)(q % fpw))) & fmask)]++;
+          }
+        } else {
+          for (int lane = 0; lane < 64; ++lane) {
+            int64_t quota = n / 64 + (lane < n % 64 ? 1 : 0);
+            uint32_t j = 0;
+            while (quota > 0) {
+              uint32_t o[4];
+              philox4x32_10(j++, (uint32_t)(b * 64 + lane), (uint32_t)r, 5u, k0, k1, o);
+              for (int e = 0; e < 8 && quota > 0; ++e) {
+                const int64_t off = slot16(o, e) & (uint32_t)(g.BS - 1);
+                if (off >= size_b) continue;
+                n2[(b << g.s) + (off >> SM_LT)]++;
+                quota--;
+              }
             }
           }
         }
@@ -162,17 +183,27 @@ int orc_sampler_freq(uint64_t seed, int64_t nrep, int64_t ndat, const uint32_t *
     for (int64_t t = 0; t < g.ntiles; ++t) {
       const int64_t n = counts[r * g.ntiles + t];
       const int64_t size_t_ = (t == g.ntiles - 1) ? g.last_tile_size : SM_T;
-      for (int lane = 0; lane < 64; ++lane) {
-        int64_t quota = n / 64 + (lane < n % 64 ? 1 : 0);
-        uint32_t j = 0;
-        while (quota > 0) {
+      if (size_t_ == SM_T) {
+        for (int64_t c = 0; c * 12 < n; ++c) {
           uint32_t o[4];
-          philox4x32_10(j++, (uint32_t)(t * 64 + lane), (uint32_t)r, 3u, k0, k1, o);
-          for (int e = 0; e < 8 && quota > 0; ++e) {
-            const int64_t off = slot16(o, e) & (SM_T - 1);
-            if (off >= size_t_) continue;
-            freq[r * ndat + t * SM_T + off]++;
-            quota--;
+          philox4x32_10((uint32_t)c, (uint32_t)t, (uint32_t)r, 3u, k0, k1, o);
+          const int64_t nd = (n - c * 12 < 12) ? n - c * 12 : 12;
+          for (int64_t q = 0; q < nd; ++q)
+            freq[r * ndat + t * SM_T + ((o[q / 3] >> (10 * (int)(q % 3))) & 1023u)]++;
+        }
+      } else {
+        for (int lane = 0; lane < 64; ++lane) {
+          int64_t quota = n / 64 + (lane < n % 64 ? 1 : 0);
+          uint32_t j = 0;
+          while (quota > 0) {
+            uint32_t o[4];
+            philox4x32_10(j++, (uint32_t)(t * 64 + lane), (uint32_t)r, 6u, k0, k1, o);
+            for (int e = 0; e < 8 && quota > 0; ++e) {
+              const int64_t off = slot16(o, e) & (SM_T - 1);
+              if (off >= size_t_) continue;
+              freq[r * ndat + t * SM_T + off]++;
+              quota--;
+            }
           }
         }
       }

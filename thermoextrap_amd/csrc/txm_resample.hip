@@ -22,6 +22,8 @@
 // f comes either from the Philox stage-3 stream (scale mode; the wave fills a
 // private [1024 samples][16 reps] u8 tile in LDS, never touching HBM) or from an
 // explicit int64 freq table (parity mode).
+#include <type_traits>
+
 #include "txm_sampler.h"
 #include "txm_pivot.h"
 
@@ -32,7 +34,21 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int RS_BLOCK = 256;          // 4 waves
 constexpr int RS_WAVES = RS_BLOCK / 64;
 constexpr int RS_REPS = 16;            // replicates per wave (MFMA M)
-constexpr int RS_TILE_BYTES = SM_T * RS_REPS;  // u8 [sample][rep]
+// f tile of one wave: u8 counts, layout [kk = sample quarter][rep][s = sample in quarter]
+// with a 264-byte row pitch: for the 8-byte reads of the contraction loop the bank
+// pair is 2*(rep + 16*kk) mod 64, i.e. conflict-free inside each 32-lane group.
+constexpr int RS_QUARTER = SM_T / 4;                  // 256 samples per lane-group per tile
+constexpr int RS_ROW_PITCH = RS_QUARTER + 8;          // bytes
+constexpr int RS_KK_PITCH = RS_REPS * RS_ROW_PITCH;   // 4224 bytes
+constexpr int RS_TILE_BYTES = 4 * RS_KK_PITCH;        // 16896 bytes per wave
+// steps per register-prefetch group: as many as the VGPR budget (2 waves/SIMD,
+// 256 VGPRs) allows next to the K*NBLK accumulator tiles.
+constexpr int rs_group(int K, int NBLK, bool weighted, bool explicit_) {
+  const int per_step = 2 + 2 * NBLK + (weighted ? 2 : 0) + (explicit_ ? 10 : 0);
+  for (int g = 8; g > 2; g >>= 1)
+    if (K * NBLK * 8 + 2 * g * per_step <= 160) return g;
+  return 2;
+}
 
 struct ResampleArgs {
   const double *x;
@@ -58,12 +74,27 @@ struct ResampleArgs {
 };
 
 // One wave: 16 replicates x (NBLK*16 columns) x one chunk of tiles.
-template <int K, int NBLK, bool WEIGHTED, bool EXPLICIT>
+//
+// MFMA operand roles for step s of a tile (lane = (row = lane & 15, kk = lane >> 4)):
+//   sample    i  = tile_base + kk * 256 + s          (each kk owns a contiguous quarter)
+//   A (rep = row, k = kk)   = f[rep][i] * w_i * du_i^j
+//   B (k = kk,  col = row)  = x[i][col] - px[col]
+// A lane therefore walks CONTIGUOUS samples: u/w/freq come as 16-byte loads of
+// 8 consecutive steps, f as one 8-byte LDS read per 8 steps, and the loads of
+// group g+1 are issued before the 8*K*NBLK MFMAs of group g (register double
+// buffer), so HBM/L2 latency hides under the matrix pipe.
+//
+// Tiles are always contracted over a full 1024-sample window.  The last
+// (partial) tile slides its window back to [N - 1024, N) and gives the samples
+// that belong to the previous tile a zero count, so the hot loop has no
+// bounds handling at all.  Only data sets shorter than one tile (SMALLN) use
+// clamped addresses, in a separate instantiation.
+template <int K, int NBLK, bool WEIGHTED, bool EXPLICIT, bool SMALLN>
 __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = lane & 15;   // A: replicate within block;  B: column within block
-  const int kk = lane >> 4;    // sample slot within the 4-sample step
+  const int kk = lane >> 4;    // which quarter of the tile this lane group walks
 
   // XCD-aware task map: workgroups that share a sample chunk sit on one XCD
   // (blocks b and b+8 share an XCD) and are dispatched back to back, so the
@@ -81,14 +112,15 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
   if (t_end > a.ntiles) t_end = a.ntiles;
 
   const double pu = a.pivot[0];
+  // Columns beyond C (padding of the last 16-column block) re-read column 0:
+  // their sums are finite garbage that the finalize kernel never looks at, which
+  // is cheaper than a mask multiply on the FP64 pipe the MFMAs need.
   double px[NBLK];
-  bool cok[NBLK];
   int64_t ccol[NBLK];
 #pragma unroll
   for (int bl = 0; bl < NBLK; ++bl) {
     const int64_t c = col0 + bl * 16 + row;
-    cok[bl] = c < a.C;
-    ccol[bl] = cok[bl] ? c : 0;
+    ccol[bl] = c < a.C ? c : 0;
     px[bl] = a.pivot[1 + ccol[bl]];
   }
 
@@ -101,65 +133,161 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
     for (int bl = 0; bl < NBLK; ++bl) acc[j][bl] = (v4f64){0.0, 0.0, 0.0, 0.0};
   }
 
-  unsigned char *tile = lds_raw + (size_t)wave * RS_TILE_BYTES;  // [sample][rep] u8
+  unsigned char *tile = lds_raw + (size_t)wave * RS_TILE_BYTES;
   const int64_t my_rep = rep0 + row;
   const bool rep_ok = my_rep < a.nrep;
+  const int64_t last = a.N - 1;
+
+  // register double buffer for one group of RS_GROUP steps
+  constexpr int RS_GROUP = SMALLN ? 2 : rs_group(K, NBLK, WEIGHTED, EXPLICIT);
+  struct Grp {
+    double u[RS_GROUP];
+    double w[RS_GROUP];
+    double x[RS_GROUP][NBLK];
+    uint32_t fb[2];           // scale mode: RS_GROUP u8 counts straight from LDS
+    int64_t fi[EXPLICIT ? RS_GROUP : 1];  // parity mode: raw int64 counts
+  };
 
   for (int64_t t = t_begin; t < t_end; ++t) {
     const int64_t i_tile = t * SM_T;
     const uint32_t tsize = (t == a.ntiles - 1) ? a.last_tile_size : (uint32_t)SM_T;
+    // window of 1024 samples that is contracted for this tile
+    int64_t wbase = i_tile;
+    if constexpr (!SMALLN)
+      if (wbase > a.N - SM_T) wbase = a.N - SM_T;
+    const uint32_t shift = (uint32_t)(i_tile - wbase);  // window slots owned by the previous tile
 
     if constexpr (!EXPLICIT) {
       // ---- stage 3 of the sampler: fill this wave's private f tile ---------
+      // (wave-private LDS: DS ops of one wave execute in order, so only the
+      // compiler needs fencing -- no s_barrier, waves of a workgroup drift
+      // apart and their VALU/LDS phases overlap other waves' MFMA phases)
       uint4 *z = reinterpret_cast<uint4 *>(tile);
-#pragma unroll
-      for (int s = 0; s < RS_TILE_BYTES / 16 / 64; ++s) z[s * 64 + lane] = make_uint4(0, 0, 0, 0);
-      __syncthreads();
+      for (int e = lane; e < RS_TILE_BYTES / 16; e += 64) z[e] = make_uint4(0, 0, 0, 0);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
       uint32_t *tw = reinterpret_cast<uint32_t *>(tile);
       for (int rr = 0; rr < RS_REPS; ++rr) {
         const int64_t r = rep0 + rr;
         if (r >= a.nrep) break;  // wave-uniform
         const uint32_t n = a.counts[(size_t)r * a.ntiles + t];
-        const uint32_t inc = 1u << (8 * (rr & 3));
-        const uint32_t wofs = (uint32_t)rr >> 2;
-        sampler_fine_tile(a.k0, a.k1, (uint32_t)r, (uint32_t)t, n, tsize, lane,
-                          [&](uint32_t off) { atomicAdd(&tw[off * (RS_REPS / 4) + wofs], inc); });
+        const uint32_t rbase = (uint32_t)rr * RS_ROW_PITCH;
+        sampler_fine_tile(a.k0, a.k1, (uint32_t)r, (uint32_t)t, n, tsize, lane, [&](uint32_t off0) {
+          const uint32_t off = off0 + shift;
+          const uint32_t addr = (off >> 8) * RS_KK_PITCH + rbase + (off & 255u);
+          atomicAdd(&tw[addr >> 2], 1u << (8u * (addr & 3u)));
+        });
       }
-      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
     }
 
-    // ---- contraction over the tile, 4 samples per step ----------------------
-    const int nsteps = (int)((tsize + 3u) >> 2);
-#pragma unroll 2
-    for (int s = 0; s < nsteps; ++s) {
-      const uint32_t li = (uint32_t)s * 4u + (uint32_t)kk;  // sample within tile
-      const bool iok = li < tsize;
-      const int64_t i = i_tile + (iok ? li : 0u);
-      double f;
-      if constexpr (EXPLICIT) {
-        f = (iok && rep_ok) ? (double)a.freq[(size_t)my_rep * a.N + i] : 0.0;
+    const unsigned char *frow = tile + kk * RS_KK_PITCH + row * RS_ROW_PITCH;
+    const int64_t ibase = wbase + (int64_t)kk * RS_QUARTER;
+    const uint32_t lbase = (uint32_t)kk * RS_QUARTER;  // window slot of this lane's step 0
+
+    auto compute_group = [&](const Grp &G) {
+#pragma unroll
+      for (int e = 0; e < RS_GROUP; ++e) {
+        double av;
+        if constexpr (EXPLICIT) av = (double)G.fi[e];
+        else av = (double)((G.fb[e >> 2] >> (8 * (e & 3))) & 0xffu);
+        if constexpr (WEIGHTED) av *= G.w[e];
+        const double du = G.u[e] - pu;
+        double xb[NBLK];
+#pragma unroll
+        for (int bl = 0; bl < NBLK; ++bl) xb[bl] = G.x[e][bl] - px[bl];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          usum[j] += av;
+#pragma unroll
+          for (int bl = 0; bl < NBLK; ++bl)
+            acc[j][bl] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, xb[bl], acc[j][bl], 0, 0, 0);
+          av *= du;
+        }
+      }
+    };
+
+    // Branch-free on purpose: a conditional around the prefetch loads makes the
+    // compiler's s_waitcnt insertion fall back to vmcnt(0) at the join, which
+    // serialises loads and MFMAs.
+    auto load_group = [&](int g, Grp &G) {
+      const int s0 = g * RS_GROUP;
+      if constexpr (!SMALLN) {
+        const double *up = a.u + ibase + s0;
+#pragma unroll
+        for (int e = 0; e < RS_GROUP; ++e) G.u[e] = up[e];
+        if constexpr (WEIGHTED) {
+          const double *wp = a.w + ibase + s0;
+#pragma unroll
+          for (int e = 0; e < RS_GROUP; ++e) G.w[e] = wp[e];
+        }
+#pragma unroll
+        for (int e = 0; e < RS_GROUP; ++e)
+#pragma unroll
+          for (int bl = 0; bl < NBLK; ++bl) G.x[e][bl] = a.x[(ibase + s0 + e) * a.ldx_s + ccol[bl]];
+        if constexpr (EXPLICIT) {
+          const int64_t *fp = a.freq + (size_t)(rep_ok ? my_rep : 0) * a.N + ibase + s0;
+#pragma unroll
+          for (int e = 0; e < RS_GROUP; ++e)
+            G.fi[e] = (rep_ok && lbase + (uint32_t)(s0 + e) >= shift) ? fp[e] : 0;
+        }
       } else {
-        f = iok ? (double)tile[li * RS_REPS + row] : 0.0;
+        // N < 1024: a single short tile; clamp addresses, zero the missing samples
+#pragma unroll
+        for (int e = 0; e < RS_GROUP; ++e) {
+          const int64_t ii = ibase + s0 + e;
+          const int64_t ic = ii <= last ? ii : last;
+          G.u[e] = a.u[ic];
+          if constexpr (WEIGHTED) G.w[e] = a.w[ic];
+#pragma unroll
+          for (int bl = 0; bl < NBLK; ++bl) G.x[e][bl] = a.x[ic * a.ldx_s + ccol[bl]];
+          if constexpr (EXPLICIT)
+            G.fi[e] = (rep_ok && ii <= last) ? a.freq[(size_t)(rep_ok ? my_rep : 0) * a.N + ic] : 0;
+        }
       }
-      if constexpr (WEIGHTED) f *= a.w[i];
-      const double du = a.u[i] - pu;
-      double xb[NBLK];
-#pragma unroll
-      for (int bl = 0; bl < NBLK; ++bl) {
-        const double xv = a.x[i * a.ldx_s + ccol[bl]];
-        xb[bl] = cok[bl] ? xv - px[bl] : 0.0;
+      if constexpr (!EXPLICIT) {
+        if constexpr (RS_GROUP == 8) {
+          const uint2 v = *reinterpret_cast<const uint2 *>(frow + s0);
+          G.fb[0] = v.x;
+          G.fb[1] = v.y;
+        } else if constexpr (RS_GROUP == 4) {
+          G.fb[0] = *reinterpret_cast<const uint32_t *>(frow + s0);
+        } else {
+          G.fb[0] = *reinterpret_cast<const uint16_t *>(frow + s0);
+        }
       }
-      double av = f;
-#pragma unroll
-      for (int j = 0; j < K; ++j) {
-        usum[j] += av;
-#pragma unroll
-        for (int bl = 0; bl < NBLK; ++bl)
-          acc[j][bl] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, xb[bl], acc[j][bl], 0, 0, 0);
-        av *= du;
+    };
+    // groups per lane quarter (even); SMALLN: only those that hold samples
+    int ngroups = RS_QUARTER / RS_GROUP;
+    if constexpr (SMALLN) {
+      const uint32_t q0 = tsize < (uint32_t)RS_QUARTER ? tsize : (uint32_t)RS_QUARTER;
+      ngroups = (int)((q0 + RS_GROUP - 1) / RS_GROUP);
+      ngroups = (ngroups + 1) & ~1;
+    }
+    {
+      Grp A, B;
+      load_group(0, A);
+      // sched_barrier: keep "issue the next group's loads, then run this group's
+      // MFMAs" in program order (the machine scheduler otherwise sinks the loads
+      // next to their uses to save registers and exposes their latency).
+      for (int g = 0; g < ngroups; g += 2) {
+        load_group(g + 1, B);  // g + 1 < ngroups (even count)
+        __builtin_amdgcn_sched_barrier(0);
+        compute_group(A);
+        __builtin_amdgcn_sched_barrier(0);
+        const int g2 = (g + 2 < ngroups) ? g + 2 : g + 1;  // tail: harmless re-load
+        load_group(g2, A);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_group(B);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if constexpr (!EXPLICIT) __syncthreads();
+
+    if constexpr (!EXPLICIT) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
   }
 
   // ---- write partial sums ---------------------------------------------------
@@ -273,8 +401,13 @@ static int run_resample(ResampleArgs a, const ResamplePlan &p, bool weighted, bo
                         double *out, hipStream_t st) {
   dim3 grid((unsigned)(p.n_chunks * p.n_rbg), (unsigned)p.colgroups), block(RS_BLOCK);
   const size_t lds = explicit_ ? 0 : (size_t)RS_WAVES * RS_TILE_BYTES;
-#define TXM_RS_LAUNCH(NB, WT, EX) \
-  hipLaunchKernelGGL((resample_kernel<K, NB, WT, EX>), grid, block, lds, st, a)
+#define TXM_RS_LAUNCH(NB, WT, EX)                                                          \
+  do {                                                                                    \
+    if (a.N < SM_T)                                                                       \
+      hipLaunchKernelGGL((resample_kernel<K, NB, WT, EX, true>), grid, block, lds, st, a);  \
+    else                                                                                  \
+      hipLaunchKernelGGL((resample_kernel<K, NB, WT, EX, false>), grid, block, lds, st, a); \
+  } while (0)
   if (p.nblk == 1) {
     if (weighted) { if (explicit_) TXM_RS_LAUNCH(1, true, true); else TXM_RS_LAUNCH(1, true, false); }
     else          { if (explicit_) TXM_RS_LAUNCH(1, false, true); else TXM_RS_LAUNCH(1, false, false); }

@@ -60,31 +60,33 @@ __device__ __forceinline__ uint32_t slot16(const Philox4 &o, int e) {
   return (o.w[e >> 1] >> (16 * (e & 1))) & 0xffffu;
 }
 
-// Stage 3 for one (replicate r, tile t) executed by one wave: every accepted
-// draw calls hit(off) with off in [0, tile_size).  `n` = counts[r][t].
+// Stage 3 for one (replicate r, tile t) executed by one wave: every draw calls
+// hit(off) with off in [0, tile_size).  `n` = counts[r][t].
+//   full tile   : draw d = field d % 12 of Philox call d / 12 (three 10-bit
+//                 fields per word), call c handled by lane c % 64 -- no random
+//                 bit is wasted and a tile costs ceil(n / 768) wave iterations.
+//   partial tile: per-lane quotas with 16-bit slots and rejection.
 template <class Hit>
 __device__ __forceinline__ void sampler_fine_tile(uint32_t k0, uint32_t k1, uint32_t r, uint32_t t,
                                                   uint32_t n, uint32_t tile_size, int lane, Hit hit) {
-  uint32_t quota = n / 64u + ((uint32_t)lane < (n % 64u) ? 1u : 0u);
-  uint32_t j = 0;
-  const uint32_t c1 = t * 64u + (uint32_t)lane;
   if (tile_size == (uint32_t)SM_T) {
-    // full tile: every slot is accepted -> branch-free body
-    while (quota >= 8u) {
-      const Philox4 o = philox4x32_10(j++, c1, r, 3u, k0, k1);
+    for (uint32_t c0 = 0; c0 * 12u < n; c0 += 64u) {  // wave-uniform trip count
+      const uint32_t c = c0 + (uint32_t)lane;
+      const uint32_t first = c * 12u;
+      if (first < n) {
+        const Philox4 o = philox4x32_10(c, t, r, 3u, k0, k1);
+        const uint32_t nd = n - first;  // >= 1; fields beyond nd are unused
 #pragma unroll
-      for (int e = 0; e < 8; ++e) hit(slot16(o, e) & (uint32_t)(SM_T - 1));
-      quota -= 8u;
-    }
-    if (quota) {
-      const Philox4 o = philox4x32_10(j++, c1, r, 3u, k0, k1);
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if ((uint32_t)e < quota) hit(slot16(o, e) & (uint32_t)(SM_T - 1));
+        for (int q = 0; q < 12; ++q)
+          if ((uint32_t)q < nd) hit((o.w[q / 3] >> (10 * (q % 3))) & 1023u);
+      }
     }
   } else {
+    uint32_t quota = n / 64u + ((uint32_t)lane < (n % 64u) ? 1u : 0u);
+    uint32_t j = 0;
+    const uint32_t c1 = t * 64u + (uint32_t)lane;
     while (quota) {
-      const Philox4 o = philox4x32_10(j++, c1, r, 3u, k0, k1);
+      const Philox4 o = philox4x32_10(j++, c1, r, 6u, k0, k1);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const uint32_t off = slot16(o, e) & (uint32_t)(SM_T - 1);

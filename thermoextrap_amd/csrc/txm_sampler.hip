@@ -83,42 +83,80 @@ __global__ void sampler_fill_single_bin_kernel(uint32_t *__restrict__ counts, in
 }
 
 // ---- stage 2 ---------------------------------------------------------------
-// one wave per (r, b); block 256 = 4 waves.
+// One wave per run of S2_BINS consecutive coarse bins of one replicate; the
+// wave's 64-entry LDS table is private, so no workgroup barrier is needed.
+// Full bins use s-bit fields (F = 4 * floor(32/s) draws per Philox call, call c
+// on lane c % 64); only the last, partial bin needs rejection.
+constexpr int S2_BINS = 8;
+
 __global__ __launch_bounds__(256) void sampler_stage2_kernel(uint32_t k0, uint32_t k1key,
                                                              int64_t nrep, SamplerGeom g,
                                                              const uint32_t *__restrict__ n1,
                                                              uint32_t *__restrict__ counts) {
-  __shared__ uint32_t sub[4][64];
+  __shared__ uint32_t sub_all[4][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint32_t *sub = sub_all[wave];
+  const int64_t runs_per_rep = (g.nb1 + S2_BINS - 1) / S2_BINS;
   const int64_t task = (int64_t)blockIdx.x * 4 + wave;
-  const bool active = task < nrep * g.nb1;
-  const uint32_t r = active ? (uint32_t)(task / g.nb1) : 0u;
-  const uint32_t b = active ? (uint32_t)(task % g.nb1) : 0u;
-  sub[wave][lane] = 0u;
-  __syncthreads();
-  if (active) {
+  if (task >= nrep * runs_per_rep) return;  // whole wave exits together
+  const uint32_t r = (uint32_t)(task / runs_per_rep);
+  const int64_t b_begin = (task % runs_per_rep) * S2_BINS;
+  const int64_t b_end = (b_begin + S2_BINS < g.nb1) ? b_begin + S2_BINS : g.nb1;
+  const int s = g.s;
+  const int fpw = 32 / s;
+  const uint32_t F = 4u * (uint32_t)fpw;
+  const uint32_t fmask = (1u << s) - 1u;
+  for (int64_t bb = b_begin; bb < b_end; ++bb) {
+    const uint32_t b = (uint32_t)bb;
+    sub[lane] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
     const uint32_t n = n1[(size_t)r * g.nb1 + b];
-    const uint32_t size_b = (b == (uint32_t)g.nb1 - 1u) ? (uint32_t)g.last_bin_size : (uint32_t)g.BS;
-    const uint32_t bsmask = (uint32_t)(g.BS - 1);
-    uint32_t quota = n / 64u + ((uint32_t)lane < (n % 64u) ? 1u : 0u);
-    uint32_t j = 0;
-    const uint32_t c1 = b * 64u + (uint32_t)lane;
-    while (quota) {
-      const Philox4 o = philox4x32_10(j++, c1, r, 2u, k0, k1key);
+    const bool full_bin = !(bb == g.nb1 - 1 && g.last_bin_size < g.BS);
+    if (full_bin) {
+      for (uint32_t c0 = 0; (uint64_t)c0 * F < n; c0 += 64u) {
+        const uint32_t c = c0 + (uint32_t)lane;
+        const uint64_t first = (uint64_t)c * F;
+        if (first < n) {
+          const Philox4 o = philox4x32_10(c, b, r, 2u, k0, k1key);
+          const uint32_t nd = (n - first < F) ? (uint32_t)(n - first) : F;
+          uint32_t q = 0;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const uint32_t off = slot16(o, e) & bsmask;
-        if (quota && off < size_b) {
-          atomicAdd(&sub[wave][off >> SM_LT], 1u);
-          --quota;
+          for (int wi = 0; wi < 4; ++wi) {  // static word index: keeps `o` in registers
+            uint32_t word = o.w[wi];
+            for (int k = 0; k < fpw; ++k, ++q) {
+              if (q < nd) atomicAdd(&sub[word & fmask], 1u);
+              word >>= s;
+            }
+          }
+        }
+      }
+    } else {
+      const uint32_t size_b = (uint32_t)g.last_bin_size;
+      const uint32_t bsmask = (uint32_t)(g.BS - 1);
+      uint32_t quota = n / 64u + ((uint32_t)lane < (n % 64u) ? 1u : 0u);
+      uint32_t j = 0;
+      const uint32_t c1 = b * 64u + (uint32_t)lane;
+      while (quota) {
+        const Philox4 o = philox4x32_10(j++, c1, r, 5u, k0, k1key);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t off = slot16(o, e) & bsmask;
+          if (quota && off < size_b) {
+            atomicAdd(&sub[off >> SM_LT], 1u);
+            --quota;
+          }
         }
       }
     }
-  }
-  __syncthreads();
-  if (active && lane < (1 << g.s)) {
-    const int64_t t = ((int64_t)b << g.s) + lane;
-    if (t < g.ntiles) counts[(size_t)r * g.ntiles + t] = sub[wave][lane];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < (1 << s)) {
+      const int64_t t = (bb << s) + lane;
+      if (t < g.ntiles) counts[(size_t)r * g.ntiles + t] = sub[lane];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -229,7 +267,7 @@ extern "C" int txm_sampler_tile_counts(const txm_sampler_spec *sp, uint32_t *cou
                      (size_t)g.nb1 * sizeof(uint32_t), st, k0, k1, nsamp, g, n1);
   TXM_LAUNCH_CHECK();
   if (g.s > 0) {
-    const int64_t tasks = sp->nrep * g.nb1;
+    const int64_t tasks = sp->nrep * cdiv(g.nb1, S2_BINS);
     hipLaunchKernelGGL(sampler_stage2_kernel, dim3((unsigned)cdiv(tasks, 4)), dim3(256), 0, st, k0,
                        k1, sp->nrep, g, n1, counts);
     TXM_LAUNCH_CHECK();
