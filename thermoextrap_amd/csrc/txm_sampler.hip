@@ -89,28 +89,134 @@ __global__ void sampler_fill_single_bin_kernel(uint32_t *__restrict__ counts, in
 // on lane c % 64); only the last, partial bin needs rejection.
 constexpr int S2_BINS = 8;
 
-__global__ __launch_bounds__(256) void sampler_stage2_kernel(uint32_t k0, uint32_t k1key,
-                                                             int64_t nrep, SamplerGeom g,
-                                                             const uint32_t *__restrict__ n1,
-                                                             uint32_t *__restrict__ counts) {
-  __shared__ uint32_t sub_all[4][64];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  uint32_t *sub = sub_all[wave];
+// Fast path for s <= 3 (ndat <= 1.3e8): per-value counts by bit-slicing and
+// popcount, entirely in registers -- a Philox call (128 bits) is consumed with
+// ~6 ALU ops per value and word instead of one LDS read-modify-write per field.
+template <int S>
+__global__ __launch_bounds__(256) void sampler_stage2_popc_kernel(
+    uint32_t k0, uint32_t k1key, int64_t nrep, SamplerGeom g, const uint32_t *__restrict__ n1,
+    uint32_t *__restrict__ counts) {
+  constexpr int NS = 1 << S;
+  constexpr int FPW = 32 / S;
+  constexpr uint32_t F = 4u * FPW;
+  // LSB of every field of a word
+  uint32_t lsb = 0;
+#pragma unroll
+  for (int k = 0; k < FPW; ++k) lsb |= 1u << (k * S);
+  const int lane = threadIdx.x & 63;
   const int64_t runs_per_rep = (g.nb1 + S2_BINS - 1) / S2_BINS;
-  const int64_t task = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (task >= nrep * runs_per_rep) return;
+  const uint32_t r = (uint32_t)(task / runs_per_rep);
+  const int64_t b_begin = (task % runs_per_rep) * S2_BINS;
+  const int64_t b_end = (b_begin + S2_BINS < g.nb1) ? b_begin + S2_BINS : g.nb1;
+  // all counts of the run are loaded up front (one latency, not one per bin)
+  uint32_t nb[S2_BINS];
+#pragma unroll
+  for (int i = 0; i < S2_BINS; ++i)
+    nb[i] = (b_begin + i < b_end) ? n1[(size_t)r * g.nb1 + b_begin + i] : 0u;
+#pragma unroll
+  for (int i = 0; i < S2_BINS; ++i) {
+    const int64_t bb = b_begin + i;
+    if (bb >= b_end) break;
+    const uint32_t b = (uint32_t)bb;
+    const uint32_t n = nb[i];
+    uint32_t cnt[NS];
+#pragma unroll
+    for (int v = 0; v < NS; ++v) cnt[v] = 0u;
+    const bool full_bin = !(bb == g.nb1 - 1 && g.last_bin_size < g.BS);
+    if (full_bin) {
+      for (uint32_t c0 = 0; (uint64_t)c0 * F < n; c0 += 64u) {
+        const uint32_t c = c0 + (uint32_t)lane;
+        const uint64_t first = (uint64_t)c * F;
+        if (first < n) {
+          const Philox4 o = philox4x32_10(c, b, r, 2u, k0, k1key);
+          const uint32_t nd = (n - first < F) ? (uint32_t)(n - first) : F;
+#pragma unroll
+          for (int wi = 0; wi < 4; ++wi) {
+            // fields of this word that are real draws
+            const int nv = (int)nd - wi * FPW;
+            uint32_t valid = lsb;
+            if (nv <= 0) valid = 0u;
+            else if (nv < FPW) valid = lsb & ((1u << (nv * S)) - 1u);
+            const uint32_t word = o.w[wi];
+#pragma unroll
+            for (int v = 0; v < NS; ++v) {
+              uint32_t pat = 0;  // value v replicated into every field
+#pragma unroll
+              for (int k = 0; k < FPW; ++k) pat |= (uint32_t)v << (k * S);
+              const uint32_t m = ~(word ^ pat);
+              uint32_t t = m;
+#pragma unroll
+              for (int bit = 1; bit < S; ++bit) t &= m >> bit;
+              cnt[v] += __popc(t & valid);
+            }
+          }
+        }
+      }
+    } else {
+      const uint32_t size_b = (uint32_t)g.last_bin_size;
+      const uint32_t bsmask = (uint32_t)(g.BS - 1);
+      uint32_t quota = n / 64u + ((uint32_t)lane < (n % 64u) ? 1u : 0u);
+      uint32_t j = 0;
+      const uint32_t c1 = b * 64u + (uint32_t)lane;
+      while (quota) {
+        const Philox4 o = philox4x32_10(j++, c1, r, 5u, k0, k1key);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t off = slot16(o, e) & bsmask;
+          if (quota && off < size_b) {
+            const uint32_t sub = off >> SM_LT;
+#pragma unroll
+            for (int v = 0; v < NS; ++v) cnt[v] += (sub == (uint32_t)v) ? 1u : 0u;
+            --quota;
+          }
+        }
+      }
+    }
+    // wave reduction, then lane v stores tile v of the bin
+    uint32_t mine = 0;
+#pragma unroll
+    for (int v = 0; v < NS; ++v) {
+      uint32_t x = cnt[v];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+      if (lane == v) mine = x;
+    }
+    if (lane < NS) {
+      const int64_t t = (bb << S) + lane;
+      if (t < g.ntiles) counts[(size_t)r * g.ntiles + t] = mine;
+    }
+  }
+}
+
+
+constexpr int S2_WAVES = 2;  // waves per workgroup
+
+// Every lane keeps PRIVATE counters in LDS (row pitch 2^s + 1 words, so lanes
+// sit on different banks): a shared 2^s-entry table would make all 64 lanes of
+// a ds_add hit the same few addresses and serialise.
+__global__ __launch_bounds__(64 * S2_WAVES) void sampler_stage2_kernel(
+    uint32_t k0, uint32_t k1key, int64_t nrep, SamplerGeom g, const uint32_t *__restrict__ n1,
+    uint32_t *__restrict__ counts) {
+  extern __shared__ uint32_t sub_all[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int s = g.s;
+  const int nsub = 1 << s, pitch = nsub + 1;
+  uint32_t *sub = sub_all + (size_t)wave * 64 * pitch;
+  uint32_t *mine = sub + lane * pitch;
+  const int64_t runs_per_rep = (g.nb1 + S2_BINS - 1) / S2_BINS;
+  const int64_t task = (int64_t)blockIdx.x * S2_WAVES + wave;
   if (task >= nrep * runs_per_rep) return;  // whole wave exits together
   const uint32_t r = (uint32_t)(task / runs_per_rep);
   const int64_t b_begin = (task % runs_per_rep) * S2_BINS;
   const int64_t b_end = (b_begin + S2_BINS < g.nb1) ? b_begin + S2_BINS : g.nb1;
-  const int s = g.s;
   const int fpw = 32 / s;
   const uint32_t F = 4u * (uint32_t)fpw;
   const uint32_t fmask = (1u << s) - 1u;
   for (int64_t bb = b_begin; bb < b_end; ++bb) {
     const uint32_t b = (uint32_t)bb;
-    sub[lane] = 0u;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    for (int v = 0; v < nsub; ++v) mine[v] = 0u;
     const uint32_t n = n1[(size_t)r * g.nb1 + b];
     const bool full_bin = !(bb == g.nb1 - 1 && g.last_bin_size < g.BS);
     if (full_bin) {
@@ -125,7 +231,7 @@ __global__ __launch_bounds__(256) void sampler_stage2_kernel(uint32_t k0, uint32
           for (int wi = 0; wi < 4; ++wi) {  // static word index: keeps `o` in registers
             uint32_t word = o.w[wi];
             for (int k = 0; k < fpw; ++k, ++q) {
-              if (q < nd) atomicAdd(&sub[word & fmask], 1u);
+              if (q < nd) mine[word & fmask] += 1u;
               word >>= s;
             }
           }
@@ -143,17 +249,20 @@ __global__ __launch_bounds__(256) void sampler_stage2_kernel(uint32_t k0, uint32
         for (int e = 0; e < 8; ++e) {
           const uint32_t off = slot16(o, e) & bsmask;
           if (quota && off < size_b) {
-            atomicAdd(&sub[off >> SM_LT], 1u);
+            mine[off >> SM_LT] += 1u;
             --quota;
           }
         }
       }
     }
+    // wave-private region: DS ops of one wave execute in order; fence the compiler
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    if (lane < (1 << s)) {
+    if (lane < nsub) {
+      uint32_t tot = 0;
+      for (int l = 0; l < 64; ++l) tot += sub[l * pitch + lane];
       const int64_t t = (bb << s) + lane;
-      if (t < g.ntiles) counts[(size_t)r * g.ntiles + t] = sub[lane];
+      if (t < g.ntiles) counts[(size_t)r * g.ntiles + t] = tot;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -268,8 +377,19 @@ extern "C" int txm_sampler_tile_counts(const txm_sampler_spec *sp, uint32_t *cou
   TXM_LAUNCH_CHECK();
   if (g.s > 0) {
     const int64_t tasks = sp->nrep * cdiv(g.nb1, S2_BINS);
-    hipLaunchKernelGGL(sampler_stage2_kernel, dim3((unsigned)cdiv(tasks, 4)), dim3(256), 0, st, k0,
-                       k1, sp->nrep, g, n1, counts);
+    if (g.s <= 3) {
+      dim3 grid((unsigned)cdiv(tasks, 4)), block(256);
+      if (g.s == 1)
+        hipLaunchKernelGGL((sampler_stage2_popc_kernel<1>), grid, block, 0, st, k0, k1, sp->nrep, g, n1, counts);
+      else if (g.s == 2)
+        hipLaunchKernelGGL((sampler_stage2_popc_kernel<2>), grid, block, 0, st, k0, k1, sp->nrep, g, n1, counts);
+      else
+        hipLaunchKernelGGL((sampler_stage2_popc_kernel<3>), grid, block, 0, st, k0, k1, sp->nrep, g, n1, counts);
+    } else {
+      const size_t lds = (size_t)S2_WAVES * 64 * ((1 << g.s) + 1) * sizeof(uint32_t);
+      hipLaunchKernelGGL(sampler_stage2_kernel, dim3((unsigned)cdiv(tasks, S2_WAVES)),
+                         dim3(64 * S2_WAVES), lds, st, k0, k1, sp->nrep, g, n1, counts);
+    }
     TXM_LAUNCH_CHECK();
   }
   return TXM_OK;
