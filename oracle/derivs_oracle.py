@@ -1,0 +1,156 @@
+"""
+oracle/derivs_oracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT.
+
+Independent numerical restatement of the derivative formulas the reference
+generates symbolically (src/thermoextrap/beta.py:32-266 -> models.py:317-383).
+No symbolic algebra here: the same quantities are obtained from the identity
+the reference's *legacy* oracle is built on (legacy/utilities.py:61-111,
+180-245):
+
+    <a>(beta) = f / z,   f = sum_i a_i e^{-beta u_i},   z = sum_i e^{-beta u_i}
+    f^(k) / z = (-1)^k <a u^k>             z^(k) / z = (-1)^k <u^k>
+    with a = a(beta):   f^(n) / z = sum_k C(n,k) (-1)^k <a^(n-k) u^k>
+
+and the general Leibniz rule for a quotient,
+    g = f / z   =>   g^(n) = f^(n)/z - sum_{k<n} C(n,k) g^(k) z^(n-k)/z ,
+evaluated with truncated Taylor "jets" so that products, powers and -log of
+averages (central moments, post_func, minus_log) follow by jet arithmetic.
+
+Pinned against tests/golden/fixture_legacy.npz (outputs of the reference's own
+legacy code) in tests/test_derivs_oracle.py.
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+
+# ---------------------------------------------------------------------------
+# jets: arrays whose leading axis holds derivatives d^k/dbeta^k, k = 0..n
+# ---------------------------------------------------------------------------
+def jet_mul(a, b):
+    n = a.shape[0]
+    out = np.zeros(np.broadcast_shapes(a.shape, b.shape), dtype=np.result_type(a, b))
+    for k in range(n):
+        for j in range(k + 1):
+            out[k] = out[k] + math.comb(k, j) * a[j] * b[k - j]
+    return out
+
+
+def jet_pow(a, p: int):
+    out = np.zeros_like(a)
+    out[0] = 1.0
+    for _ in range(p):
+        out = jet_mul(out, a)
+    return out
+
+
+def jet_minus_log(a):
+    """derivatives of -log(a) from those of a:  y' = -a'/a  =>  a y' = -a'."""
+    n = a.shape[0]
+    y = np.zeros_like(a)
+    y[0] = -np.log(a[0])
+    # (a * y')^(k-1) = -a^(k):  sum_j C(k-1,j) a^(j) y^(k-j) = -a^(k)
+    for k in range(1, n):
+        acc = -a[k]
+        for j in range(1, k):
+            acc = acc - math.comb(k - 1, j) * a[j] * y[k - j]
+        y[k] = acc / a[0]
+    return y
+
+
+def average_jet(raw_au, raw_u, order):
+    """Jet of <a>(beta) for a beta-independent sample function a.
+
+    raw_au[k] = <a u^k> (k <= order; trailing dims free), raw_u[k] = <u^k> (scalars or
+    broadcastable)."""
+    g = [None] * (order + 1)
+    for n in range(order + 1):
+        acc = (-1) ** n * np.asarray(raw_au[n])
+        for k in range(n):
+            acc = acc - math.comb(n, k) * g[k] * (-1) ** (n - k) * raw_u[n - k]
+        g[n] = acc
+    return np.stack([np.broadcast_to(v, np.shape(g[-1])) for v in g])
+
+
+def average_jet_xalpha(raw_xu_dk, raw_u, order):
+    """Jet of <x(beta)>: raw_xu_dk[d][k] = <x^(d) u^k>."""
+    g = [None] * (order + 1)
+    for n in range(order + 1):
+        fn = 0.0
+        for k in range(n + 1):
+            fn = fn + math.comb(n, k) * (-1) ** k * np.asarray(raw_xu_dk[n - k][k])
+        acc = fn
+        for k in range(n):
+            acc = acc - math.comb(n, k) * g[k] * (-1) ** (n - k) * raw_u[n - k]
+        g[n] = acc
+    return np.stack(g)
+
+
+# ---------------------------------------------------------------------------
+# the named averages of beta.factory_derivatives
+# ---------------------------------------------------------------------------
+def raw_moments(x, u, kmax, w=None):
+    """<u^k>, <x u^k> for k <= kmax by direct summation in extended precision."""
+    x = np.asarray(x, dtype=np.longdouble)
+    u = np.asarray(u, dtype=np.longdouble)
+    w = np.ones_like(u) if w is None else np.asarray(w, dtype=np.longdouble)
+    W = w.sum()
+    ru = np.array([(w * u**k).sum() / W for k in range(kmax + 1)], dtype=np.longdouble)
+    xs = x.reshape(x.shape[0], -1)
+    rxu = np.stack([((w * u**k)[:, None] * xs).sum(axis=0) / W for k in range(kmax + 1)])
+    # kept in extended precision: at order 6 the raw-moment recursion cancels ~13 digits
+    # when u ~ 175 +- 5 (the ideal-gas notebook data); callers cast the final jets to float.
+    return ru, rxu.reshape((kmax + 1,) + x.shape[1:])
+
+
+def derivs_x_ave(x, u, order, w=None, post_func=None, minus_log=False):
+    """d^n <x> / dbeta^n, n <= order; x: (N,) or (N, C).  Output (order+1, C)."""
+    ru, rxu = raw_moments(x, u, order, w)
+    j = average_jet(rxu, ru, order)
+    if post_func == "minus_log" or minus_log:
+        j = jet_minus_log(j)
+    elif isinstance(post_func, str) and post_func.startswith("pow_"):
+        j = jet_pow(j, int(post_func.split("_")[-1]))
+    return np.asarray(j, dtype=float)
+
+
+def derivs_x_ave_xalpha(xd, u, order, w=None, minus_log=False):
+    """xd: (N, D, C) with xd[:, d] = d^d x / dbeta^d samples."""
+    u = np.asarray(u, dtype=float)
+    D = xd.shape[1]
+    if D < order + 1:
+        raise ValueError("need derivatives of x up to `order`")
+    ru, _ = raw_moments(xd[:, 0], u, order, w)
+    raw = [raw_moments(xd[:, d], u, order, w)[1] for d in range(order + 1)]
+    j = average_jet_xalpha(raw, ru, order)
+    return np.asarray(jet_minus_log(j) if minus_log else j, dtype=float)
+
+
+def derivs_un_ave(u, n, order, w=None):
+    """d^k <u^n> / dbeta^k."""
+    ru, _ = raw_moments(u, u, order + n, w)
+    return np.asarray(average_jet([ru[n + k] for k in range(order + 1)], ru, order), dtype=float)
+
+
+def derivs_dun_ave(u, n, order, w=None):
+    """d^k <(u-<u>)^n> / dbeta^k via jets of the raw moments."""
+    ujets = [derivs_un_ave(u, m, order, w) if m > 0 else np.r_[1.0, np.zeros(order)] for m in range(n + 1)]
+    mean = ujets[1]
+    out = np.zeros(order + 1)
+    for m in range(n + 1):
+        out = out + math.comb(n, m) * jet_mul(ujets[m], jet_pow(-mean, n - m))
+    return out
+
+
+def predict(derivs, alpha0, alphas, order=None):
+    """Taylor series sum_k derivs[k] (alpha-alpha0)^k / k!  -> (n_alpha, ...)."""
+    derivs = np.asarray(derivs)
+    order = derivs.shape[0] - 1 if order is None else order
+    d = np.asarray(alphas, dtype=float) - alpha0
+    out = 0.0
+    for k in range(order + 1):
+        out = out + np.multiply.outer(d**k, derivs[k]) / math.factorial(k)
+    return out

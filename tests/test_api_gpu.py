@@ -1,0 +1,415 @@
+"""GPU tests of the drop-in API, written to read like the reference's own tests
+(tests/test_data.py, tests/test_beta.py, tests/test_u_data.py, tests/conftest.py of
+usnistgov/thermoextrap) with `thermoextrap` -> `thermoextrap_amd` and the
+legacy-oracle numbers taken from tests/golden/fixture_legacy.npz.
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def xtrap(txm):
+    import thermoextrap_amd as xtrap
+
+    return xtrap
+
+
+class FixtureData:
+    """tests/conftest.py:15-112 of the reference, same seed and shapes."""
+
+    def __init__(self, xtrap, legacy, order=5):
+        from thermoextrap_amd.data import xrwrap_uv, xrwrap_xv
+
+        self.xtrap = xtrap
+        self.order = order
+        self.legacy = legacy
+        self.u = xrwrap_uv(legacy["u"])
+        self.x = xrwrap_xv(legacy["x"])
+        self.ub = xrwrap_uv(legacy["ub"])
+        self.xb = xrwrap_xv(legacy["xb"])
+        self.beta0 = 0.5
+        self.betas = [0.3, 0.4]
+        self._c = {}
+
+    def _get(self, key, fn):
+        if key not in self._c:
+            self._c[key] = fn()
+        return self._c[key]
+
+    @property
+    def rdata(self):
+        return self._get("rdata", lambda: self.xtrap.factory_data_values(uv=self.u, xv=self.x, order=self.order, central=False))
+
+    @property
+    def cdata(self):
+        return self._get("cdata", lambda: self.xtrap.factory_data_values(uv=self.u, xv=self.x, order=self.order, central=True))
+
+    @property
+    def xdata(self):
+        return self._get("xdata", lambda: self.xtrap.DataCentralMoments.from_vals(xv=self.x, uv=self.u, order=self.order, central=True, axis=0))
+
+    @property
+    def xdata_val(self):
+        return self._get("xdata_val", lambda: self.xtrap.DataCentralMomentsVals.from_vals(xv=self.x, uv=self.u, order=self.order, central=True))
+
+    @property
+    def xrdata(self):
+        return self._get("xrdata", lambda: self.xtrap.DataCentralMoments.from_vals(xv=self.x, uv=self.u, order=self.order, central=False, axis=0))
+
+    @property
+    def xrdata_val(self):
+        return self._get("xrdata_val", lambda: self.xtrap.DataCentralMomentsVals.from_vals(xv=self.x, uv=self.u, order=self.order, central=False))
+
+    @staticmethod
+    def xr_test(a, b, rtol=1e-7, atol=0.0):
+        from thermoextrap_amd.xrlite import assert_allclose
+
+        assert_allclose(a, b, rtol=rtol, atol=atol)
+
+    def xr_test_raw(self, b, a=None):
+        a = self.rdata if a is None else a
+        self.xr_test(a.u, b.u.sel(val=0) if "val" in b.u.dims else b.u)
+        self.xr_test(a.xu, b.xu)
+        for i in range(self.order):
+            bu = b.u_selector[i]
+            self.xr_test(a.u_selector[i], bu.sel(val=0) if "val" in bu.dims else bu)
+            self.xr_test(a.xu_selector[i], b.xu_selector[i])
+
+    def xr_test_central(self, b, a=None):
+        a = self.cdata if a is None else a
+        self.xr_test(a.du, b.du.sel(val=0) if "val" in b.du.dims else b.du, atol=1e-14)
+        self.xr_test(a.dxdu, b.dxdu, atol=1e-14)
+        self.xr_test(a.xave, b.xave)
+        self.xr_test(a.xave_selector, b.xave_selector)
+        for i in range(self.order):
+            bd = b.du_selector[i]
+            self.xr_test(a.du_selector[i], bd.sel(val=0) if "val" in bd.dims else bd, atol=1e-14)
+            self.xr_test(a.dxdu_selector[i], b.dxdu_selector[i], atol=1e-14)
+
+
+@pytest.fixture(scope="module")
+def fixture(xtrap, legacy):
+    return FixtureData(xtrap, legacy)
+
+
+# ---------------------------------------------------------------------------
+# tests/test_data.py
+# ---------------------------------------------------------------------------
+def test_rdata(fixture):
+    """new interface vs the legacy raw moments (reference test_data.py:7-38)."""
+    r = fixture.rdata
+    np.testing.assert_allclose(r.u.transpose(r.umom_dim, ...).values, fixture.legacy["raw_u"], rtol=1e-12)
+    np.testing.assert_allclose(r.xu.transpose(r.umom_dim, ...).values, fixture.legacy["raw_xu"], rtol=1e-12)
+
+
+def test_xdata(fixture):
+    fixture.xr_test_raw(fixture.xdata)
+    fixture.xr_test_central(fixture.xdata)
+
+
+def test_xdata_val(fixture):
+    fixture.xr_test_raw(fixture.xdata_val)
+    fixture.xr_test_central(fixture.xdata_val)
+
+
+def test_xdata_from_ave_raw(fixture, xtrap):
+    a = fixture.rdata
+    b = xtrap.DataCentralMoments.from_ave_raw(u=a.u, xu=a.xu, weight=len(a.uv))
+    fixture.xr_test_raw(b)
+
+
+def test_xdata_from_ave_central(fixture, xtrap):
+    a = fixture.cdata
+    b = xtrap.DataCentralMoments.from_ave_central(
+        du=a.du.values, dxdu=a.dxdu.values, xave=a.xave.values, uave=fixture.rdata.u.values[1],
+        weight=len(a.uv), axis=-1, dims=["val"],
+    )
+    fixture.xr_test_central(b)
+    b = xtrap.DataCentralMoments.from_ave_central(du=a.du, dxdu=a.dxdu, xave=a.xave, uave=fixture.rdata.u[1],
+                                                  weight=len(a.uv))
+    fixture.xr_test_central(b)
+
+
+def test_resample(fixture, xtrap):
+    """gather-resample (DataValues) == freq-resample (DataCentralMomentsVals) for a
+    shared sampler (reference test_data.py:94-112)."""
+    nrep = 10
+    ndat = fixture.x.shape[0]
+    rng = xtrap.moments.default_rng(123)
+    idx = rng.choice(ndat, (nrep, ndat), replace=True)
+    sampler = xtrap.moments.factory_sampler(indices=idx)
+    b = fixture.xdata_val.resample(sampler=sampler)
+    a = fixture.rdata.resample(sampler=sampler)
+    fixture.xr_test_raw(a=a, b=b)
+    a = fixture.cdata.resample(sampler=sampler)
+    fixture.xr_test_central(a=a, b=b)
+    # and the gathered views exist and have the reference's dims
+    assert a.uv.dims == ("rep", "rec") and a.xv.dims == ("rep", "rec", "val")
+    np.testing.assert_array_equal(a.uv.values, fixture.u.values[idx])
+
+
+def test_type_and_shape_errors(fixture, xtrap):
+    with pytest.raises(TypeError):
+        xtrap.DataCentralMomentsVals.from_vals(xv=fixture.x.values, uv=fixture.u.values, order=2)
+    with pytest.raises(ValueError):
+        xtrap.DataCentralMomentsVals(uv=fixture.u, xv=fixture.x, order=None)
+    with pytest.raises(ValueError):
+        xtrap.factory_data_values(2, fixture.u, fixture.x, xalpha=True)
+    with pytest.raises(ValueError):
+        fixture.rdata.resample(sampler={"indices": np.zeros((3, 7), dtype=int)})
+    with pytest.raises(ValueError):
+        xtrap.DataSelector(fixture.cdata.du, dims=["nope"])
+
+
+# ---------------------------------------------------------------------------
+# tests/test_beta.py
+# ---------------------------------------------------------------------------
+def test_beta_derivs_vs_legacy(fixture, xtrap):
+    """reference test_beta.py:17-26 (slow there: sympy; here the numbers are golden)."""
+    a = fixture.legacy["derivs"]
+    s = xtrap.beta.factory_derivatives(xalpha=False, central=False)
+    np.testing.assert_allclose(a, s.derivs(fixture.rdata, norm=False).values, rtol=1e-8)
+    s = xtrap.beta.factory_derivatives(xalpha=False, central=True)
+    np.testing.assert_allclose(a, s.derivs(fixture.cdata, norm=False).values, rtol=1e-8)
+
+
+def test_beta_derivs(fixture, xtrap):
+    s = xtrap.beta.factory_derivatives(xalpha=False, central=False)
+    b = s.derivs(fixture.rdata, norm=False)
+    assert b.dims == ("order", "val")
+    fixture.xr_test(b, s.derivs(fixture.xrdata, norm=False))
+    fixture.xr_test(b, s.derivs(fixture.xrdata_val, norm=False))
+    s = xtrap.beta.factory_derivatives(xalpha=False, central=True)
+    b = s.derivs(fixture.cdata, norm=False)
+    fixture.xr_test(b, s.derivs(fixture.xdata, norm=False))
+    fixture.xr_test(b, s.derivs(fixture.xdata_val, norm=False))
+
+
+def test_extrapmodel_vs_legacy(fixture, xtrap):
+    xem = xtrap.beta.factory_extrapmodel(beta=fixture.beta0, data=fixture.rdata)
+    p = xem.predict(fixture.betas, order=3)
+    assert p.dims == ("beta", "val")
+    np.testing.assert_allclose(fixture.legacy["predict_order3"], p.values, rtol=1e-8)
+    np.testing.assert_allclose(fixture.legacy["predict_order5"], xem.predict(fixture.betas).values, rtol=1e-8)
+
+
+def test_extrapmodel(fixture, xtrap):
+    xem0 = xtrap.beta.factory_extrapmodel(beta=fixture.beta0, data=fixture.rdata)
+    for data in [fixture.cdata, fixture.xdata, fixture.xrdata, fixture.xdata_val, fixture.xrdata_val]:
+        xem1 = xtrap.beta.factory_extrapmodel(beta=fixture.beta0, data=data)
+        fixture.xr_test(xem0.predict(fixture.betas, order=3), xem1.predict(fixture.betas, order=3))
+
+
+def test_extrapmodel_resample(fixture, xtrap):
+    ndat, nrep = len(fixture.u), 10
+    sampler = xtrap.moments.factory_sampler(ndat=ndat, nrep=nrep, rng=np.random.default_rng(5))
+    xem0 = xtrap.beta.factory_extrapmodel(beta=fixture.beta0, data=fixture.rdata)
+    a = xem0.resample(sampler=sampler).predict(fixture.betas, order=3)
+    assert set(a.dims) == {"beta", "rep", "val"}
+    for data in [fixture.cdata, fixture.xdata_val, fixture.xrdata_val]:
+        xem1 = xtrap.beta.factory_extrapmodel(beta=fixture.beta0, data=data)
+        fixture.xr_test(a, xem1.resample(sampler=sampler).predict(fixture.betas, order=3))
+    # block data class: resampling its 1-record state is not the same operation; check the API only
+    with pytest.raises(ValueError):
+        fixture.xdata.resample(sampler=sampler)
+
+
+def test_extrapmodel_minuslog(fixture, xtrap):
+    """reference test_beta.py:519-563."""
+    a = fixture.legacy["derivs_minus_log"]
+    xem = xtrap.beta.factory_extrapmodel(fixture.beta0, fixture.rdata, post_func="minus_log")
+    np.testing.assert_allclose(a, xem.derivatives.derivs(xem.data, norm=False, minus_log=False).values, rtol=1e-8)
+    xem2 = xtrap.beta.factory_extrapmodel(fixture.beta0, fixture.rdata, post_func=None)
+    np.testing.assert_allclose(a, xem2.derivatives.derivs(xem2.data, norm=False, minus_log=True).values, rtol=1e-8)
+    fixture.xr_test(xem.predict([0.2, 0.3]), xem2.predict([0.2, 0.3], minus_log=True))
+    for data in [fixture.cdata, fixture.xdata, fixture.xdata_val]:
+        xem1 = xtrap.beta.factory_extrapmodel(fixture.beta0, data, post_func="minus_log")
+        fixture.xr_test(xem.predict([0.2, 0.3], order=3), xem1.predict([0.2, 0.3], order=3))
+
+
+def test_extrapmodel_alphadep(fixture, xtrap):
+    """x depends on beta: xv[rec, deriv, val] (reference test_beta.py:654-720)."""
+    from thermoextrap_amd.xrlite import DataArray
+
+    order = fixture.order
+    x = DataArray(fixture.legacy["x_dep"], dims=["rec", "deriv", "val"])
+    u = fixture.u
+    xem0 = xtrap.beta.factory_extrapmodel(
+        fixture.beta0, xtrap.factory_data_values(uv=u, xv=x, order=order, central=False, deriv_dim="deriv"))
+    np.testing.assert_allclose(fixture.legacy["derivs_dep"], xem0.derivs(norm=False).values, rtol=1e-8)
+    xem1 = xtrap.beta.factory_extrapmodel(
+        fixture.beta0, data=xtrap.DataCentralMomentsVals.from_vals(uv=u, xv=x, order=order, central=False, deriv_dim="deriv"))
+    fixture.xr_test(xem0.predict([0.2, 0.7]), xem1.predict([0.2, 0.7]))
+    xem2 = xtrap.beta.factory_extrapmodel(
+        fixture.beta0, data=xtrap.DataCentralMomentsVals.from_vals(uv=u, xv=x, order=order, central=True, deriv_dim="deriv"))
+    fixture.xr_test(xem0.predict([0.2, 0.7], order=3), xem2.predict([0.2, 0.7], order=3))
+    # resampling keeps the deriv dim in place
+    r = xem2.resample({"nrep": 7, "rng": np.random.default_rng(0)})
+    assert r.data.values.dims == ("rep", "deriv", "val", "xmom", "umom")
+    assert r.derivs(order=3).dims == ("order", "rep", "val")
+
+
+def test_factory_extrapmodel_consistency_errors(fixture, xtrap):
+    with pytest.raises(ValueError):
+        xtrap.beta.factory_extrapmodel(0.5, fixture.rdata, central=True)
+    with pytest.raises(ValueError):
+        xtrap.beta.factory_extrapmodel(0.5, fixture.rdata, xalpha=True)
+    with pytest.raises(ValueError):
+        xtrap.beta.factory_extrapmodel(0.5, fixture.rdata, order=9)
+    with pytest.raises(ValueError):
+        xtrap.beta.factory_extrapmodel(0.5, fixture.rdata, name="u_ave")
+
+
+# ---------------------------------------------------------------------------
+# tests/test_u_data.py: x is u
+# ---------------------------------------------------------------------------
+def test_x_is_u(fixture, xtrap):
+    order = fixture.order
+    u = fixture.u
+    a = xtrap.DataCentralMoments.from_vals(uv=u, xv=u, order=order, central=True, axis=0)  # explicit x = u
+    b = xtrap.DataCentralMoments.from_vals(uv=u, xv=None, order=order, central=True, axis=0, x_is_u=True)
+    np.testing.assert_allclose(a.values.values, b.values.values, rtol=1e-10, atol=1e-15)
+    for central in (True, False):
+        d = xtrap.DataCentralMoments.from_vals(uv=u, xv=None, order=order, central=central, axis=0, x_is_u=True)
+        assert d.du.sizes["umom"] == order + 2 if central else d.u.sizes["umom"] == order + 2
+        em_u = xtrap.beta.factory_extrapmodel(0.5, d, name="u_ave")
+        dx = xtrap.DataCentralMoments.from_vals(uv=u, xv=u, order=order, central=central, axis=0)
+        em_x = xtrap.beta.factory_extrapmodel(0.5, dx, name="x_ave")
+        np.testing.assert_allclose(em_u.derivs().values, em_x.derivs().values, rtol=1e-8, atol=1e-12)
+    # other named averages evaluate (vs the jet oracle)
+    from oracle import derivs_oracle as dorc
+
+    d = xtrap.DataCentralMoments.from_vals(uv=u, xv=None, order=order, central=True, axis=0, x_is_u=True)
+    em = xtrap.beta.factory_extrapmodel(0.5, d, name="dun_ave", n=2, order=3)
+    np.testing.assert_allclose(em.derivs().values, dorc.derivs_dun_ave(u.values, 2, 3), rtol=1e-8)
+    d = xtrap.DataCentralMoments.from_vals(uv=u, xv=None, order=order, central=False, axis=0, x_is_u=True)
+    em = xtrap.beta.factory_extrapmodel(0.5, d, name="un_ave", n=2, order=3)
+    np.testing.assert_allclose(em.derivs().values, dorc.derivs_un_ave(u.values, 2, 3), rtol=1e-8)
+
+
+# ---------------------------------------------------------------------------
+# seeded notebook outputs of the reference (tests/golden/kat_notebooks.json)
+# ---------------------------------------------------------------------------
+def test_notebook_case1(xtrap, kat, idealgas_data, post_data_rng):
+    """Temperature_Extrap_Case1.ipynb cells 7-17: from_vals -> factory_extrapmodel ->
+    predict / derivs / resample({'nrep': 100}) on the seed-0 ideal-gas data."""
+    from thermoextrap_amd.xrlite import DataArray
+
+    x, u = idealgas_data
+    xdata, udata = DataArray(x, "rec"), DataArray(u, "rec")
+    data = xtrap.DataCentralMomentsVals.from_vals(order=6, rec_dim="rec", xv=xdata, uv=udata, central=True)
+    xem = xtrap.beta.factory_extrapmodel(5.6, data)
+    k = kat["case1"]
+    np.testing.assert_allclose(xem.derivs(norm=False).values, k["derivs_N1e5"], atol=6e-5)
+    betas = np.arange(0.1, 10.0, 0.5)
+    np.testing.assert_allclose(xem.predict(betas[:4], order=2).values, k["predict_betas4_order2"], atol=6e-5)
+    assert abs(float(xem.predict(betas[0]).values) - k["predict_beta0p1_order6"]) < 6e-3
+    # cell 9 drew one number from the global rng, then cell 12 resampled with nrep = 100
+    rng = post_data_rng()
+    assert abs(rng.random() - k["rng_random_after_data"]) < 5e-4
+    xtrap.moments._GLOBAL_RNG = rng
+    boot = xem.resample({"nrep": 100})
+    pred = boot.predict(betas[:4], order=2)
+    np.testing.assert_allclose(pred.mean("rep").values, k["boot100_predict_mean"], atol=6e-5)
+    np.testing.assert_allclose(pred.std("rep").values, k["boot100_predict_std"], atol=6e-5)
+
+
+def test_notebook_data_organization(xtrap, kat, idealgas_data, post_data_rng):
+    """Data_Organization.ipynb cells 10-52 through the class API."""
+    from conftest import rel_close
+    from thermoextrap_amd.xrlite import DataArray
+
+    x, u = idealgas_data
+    k = kat["data_org"]
+    xdata, udata = DataArray(x, "rec"), DataArray(u, "rec")
+    data = xtrap.DataCentralMomentsVals.from_vals(order=2, rec_dim="rec", xv=xdata, uv=udata, central=True)
+    assert data.values.dims == ("xmom", "umom")
+    assert rel_close(data.values.values.ravel(), k["values"], 5)
+    assert rel_close(data.u.values, k["u"], 5) and rel_close(data.xu.values, k["xu"], 5)
+    xtrap.moments._GLOBAL_RNG = post_data_rng()
+    rs = data.resample(sampler={"nrep": 3}).values
+    assert rs.dims == ("rep", "xmom", "umom")
+    assert rel_close(rs.values.ravel(), k["resample_nrep3"], 5)
+    # cells 38-41: blocks
+    xx = DataArray(x.reshape(100, -1), ["rec", "block"])
+    uu = DataArray(u.reshape(100, -1), ["rec", "block"])
+    data_fv = xtrap.DataCentralMoments.from_vals(xv=xx, uv=uu, dim="block", order=2, central=True)
+    assert data_fv.values.dims == ("rec", "xmom", "umom")
+    assert rel_close(data_fv.values.values[:4].ravel(), k["block_values_first6"][:24], 5)
+    rb = data_fv.resample(sampler={"nrep": 3}).values
+    assert rel_close(rb.values.ravel(), k["block_resample_nrep3"], 5)
+    # cell 43: from_ave_raw reproduces the block states
+    mom_u = DataArray(np.arange(3), "umom")
+    uave = (uu**mom_u).mean("block")
+    xuave = (xx * uu**mom_u).mean("block")
+    data_fa = xtrap.DataCentralMoments.from_ave_raw(u=uave, xu=xuave, central=True, weight=xx.sizes["block"])
+    np.testing.assert_allclose(data_fv.values.values, data_fa.values.transpose("rec", "xmom", "umom").values, rtol=1e-7, atol=1e-10)
+    # cells 46-48: vector observable
+    xv = DataArray(np.vstack([x, x**2]).T, ["rec", "vals"])
+    data_vec = xtrap.DataCentralMomentsVals.from_vals(order=2, rec_dim="rec", xv=xv, uv=udata, central=True)
+    assert data_vec.values.dims == ("vals", "xmom", "umom")
+    assert rel_close(data_vec.values.values.ravel(), k["vec_values"], 5)
+    rv = data_vec.resample(sampler={"nrep": 3}).values
+    assert rv.dims == ("rep", "vals", "xmom", "umom")
+    assert rel_close(rv.values.ravel(), k["vec_resample_nrep3"], 5)
+    # cells 50-52: vector blocks, reduce + resample
+    xb = DataArray(xv.values.reshape(100, -1, 2), ["rec", "block", "vals"])
+    x_xsq_uave = (xb * uu**mom_u).mean("block")
+    dfv = xtrap.DataCentralMoments.from_ave_raw(u=uave, xu=x_xsq_uave, central=True, weight=1000)
+    assert rel_close(dfv.reduce("rec").values.transpose("vals", "xmom", "umom").values.ravel(), k["vec_block_reduce"], 5)
+    rvb = dfv.resample(sampler={"nrep": 3}).values.transpose("rep", "vals", "xmom", "umom")
+    assert rel_close(rvb.values.ravel(), k["vec_block_resample_nrep3"], 5)
+
+
+def test_extrapmodel_ig(xtrap):
+    """Ideal gas vs closed forms within bootstrap error (reference test_beta.py:77-128)."""
+    from thermoextrap_amd.xrlite import DataArray
+
+    ref_beta, max_order = 5.0, 3
+    test_betas = np.array([4.9, 5.1])
+    rng = np.random.default_rng(42)
+    xdata, udata = xtrap.idealgas.generate_data((100_000, 1), ref_beta, 1.0, rng=rng)
+    dat = xtrap.DataCentralMomentsVals.from_vals(order=max_order, xv=DataArray(xdata, "rec"), uv=DataArray(udata, "rec"), central=True)
+    ex = xtrap.beta.factory_extrapmodel(ref_beta, dat, xalpha=False)
+    ex_res = ex.resample(sampler={"nrep": 100, "rng": rng})
+    for o in range(max_order + 1):
+        true_extrap, true_derivs = xtrap.idealgas.x_beta_extrap(o, ref_beta, test_betas, 1.0)
+        test_derivs = ex.derivs(order=o, norm=False).values
+        test_extrap = ex.predict(test_betas, order=o).values
+        derr = 2.0 * ex_res.derivs(order=o, norm=False).std("rep").values[-1]
+        eerr = 2.0 * np.max(ex_res.predict(test_betas, order=o).std("rep").values)
+        np.testing.assert_allclose(true_derivs[-1], test_derivs[-1], rtol=0.0, atol=derr * 5)
+        np.testing.assert_allclose(true_extrap, test_extrap, rtol=0.0, atol=eerr * 2)
+
+
+def test_device_sampler_through_api(xtrap):
+    """{'nrep': n, 'device': True}: the scale-mode sampler behind the same call."""
+    from thermoextrap_amd.xrlite import DataArray
+
+    rng = np.random.default_rng(1)
+    x, u = xtrap.idealgas.generate_data((20000, 1), 5.0, rng=rng)
+    dat = xtrap.DataCentralMomentsVals.from_vals(order=3, xv=DataArray(x, "rec"), uv=DataArray(u, "rec"), central=True)
+    ex = xtrap.beta.factory_extrapmodel(5.0, dat)
+    a = ex.resample({"nrep": 200, "device": True, "seed": 7})
+    b = ex.resample({"nrep": 200, "rng": np.random.default_rng(3)})
+    sa, sb = a.derivs(order=2).std("rep").values, b.derivs(order=2).std("rep").values
+    np.testing.assert_allclose(sa, sb, rtol=0.25)  # two independent bootstraps of the same data
+    # deterministic in the seed
+    a2 = ex.resample({"nrep": 200, "device": True, "seed": 7})
+    np.testing.assert_array_equal(a.data.values.values, a2.data.values.values)
+
+
+def test_state_collection_resample(fixture, xtrap):
+    xem0 = xtrap.beta.factory_extrapmodel(beta=0.05, data=fixture.rdata)
+    xem1 = xtrap.beta.factory_extrapmodel(
+        beta=0.5, data=xtrap.factory_data_values(uv=fixture.ub, xv=fixture.xb, order=fixture.order, central=False))
+    sc = xtrap.StateCollection([xem0, xem1])
+    r = sc.resample({"nrep": 5, "rng": np.random.default_rng(0)})
+    assert len(r) == 2 and r[0].data is not r[1].data
+    d = r.map_concat("derivs", order=2)
+    assert d.dims == ("beta", "order", "rep", "val") and d.shape == (2, 3, 5, 5)
+    with pytest.raises(ValueError):
+        sc.resample([{"nrep": 3}])

@@ -1,0 +1,225 @@
+"""CPU tests of the derivative layer (no GPU):
+
+* the jet oracle (oracle/derivs_oracle.py) is pinned to the outputs of the
+  reference's own legacy code (tests/golden/fixture_legacy.npz) and to the
+  seeded notebook numbers (tests/golden/kat_notebooks.json);
+* the host logic of the product -- the polynomial recursion of
+  thermoextrap_amd.symbolic and its table compiler -- is checked against that
+  oracle with a tiny pure-Python table interpreter that lives HERE (test code),
+  and against the symbolic identities the reference asserts in
+  tests/test_u_equations.py:55-88.
+"""
+
+import math
+
+import numpy as np
+import pytest
+
+from oracle import derivs_oracle as dorc
+from thermoextrap_amd import beta
+from thermoextrap_amd import symbolic as S
+
+
+# ---------------------------------------------------------------------------
+# oracle vs the reference's legacy outputs
+# ---------------------------------------------------------------------------
+def test_oracle_derivs_match_legacy(legacy):
+    x, u, order = legacy["x"], legacy["u"], int(legacy["order"])
+    got = dorc.derivs_x_ave(x, u, order)
+    np.testing.assert_allclose(got, legacy["derivs"], rtol=1e-9)
+    np.testing.assert_allclose(dorc.derivs_x_ave(legacy["xb"], legacy["ub"], order), legacy["derivs_b"], rtol=1e-9)
+
+
+def test_oracle_predict_matches_legacy(legacy):
+    d = dorc.derivs_x_ave(legacy["x"], legacy["u"], 5)
+    np.testing.assert_allclose(dorc.predict(d, 0.5, legacy["predict_betas"], order=3), legacy["predict_order3"], rtol=1e-9)
+    np.testing.assert_allclose(dorc.predict(d, 0.5, legacy["predict_betas"], order=5), legacy["predict_order5"], rtol=1e-9)
+
+
+def test_oracle_minus_log_matches_legacy(legacy):
+    got = dorc.derivs_x_ave(legacy["x"], legacy["u"], 5, minus_log=True)
+    np.testing.assert_allclose(got, legacy["derivs_minus_log"], rtol=1e-8)
+
+
+def test_oracle_xalpha_matches_legacy(legacy):
+    got = dorc.derivs_x_ave_xalpha(legacy["x_dep"], legacy["u"], 5)
+    np.testing.assert_allclose(got, legacy["derivs_dep"], rtol=1e-9)
+
+
+def test_oracle_matches_notebook_derivs(kat, idealgas_data):
+    # Temperature_Extrap_Case1.ipynb cell 17 (N = 1e5, order 6), printed to 4 decimals
+    x, u = idealgas_data
+    got = dorc.derivs_x_ave(x, u, 6).reshape(7)
+    np.testing.assert_allclose(got, kat["case1"]["derivs_N1e5"], atol=6e-5)
+    # cell 10: predict(betas[:4], order=2), beta_ref = 5.6
+    p = dorc.predict(got, 5.6, [0.1, 0.6, 1.1, 1.6], order=2)
+    np.testing.assert_allclose(p, kat["case1"]["predict_betas4_order2"], atol=6e-5)
+    assert abs(dorc.predict(got, 5.6, [0.1], order=6)[0] - kat["case1"]["predict_beta0p1_order6"]) < 6e-3
+
+
+# ---------------------------------------------------------------------------
+# a reference interpreter for compiled tables (test code only)
+# ---------------------------------------------------------------------------
+def run_table(table, atom_value):
+    """Evaluate a thermoextrap_amd.symbolic.compile_table() result with python floats/arrays."""
+    outs = []
+    for f in range(len(table["func_flags"])):
+        acc = 0.0
+        for t in range(table["func_term0"][f], table["func_term0"][f + 1]):
+            prod = table["coef"][t]
+            for k in range(table["term_fac0"][t], table["term_fac0"][t + 1]):
+                prod = prod * atom_value(table["atoms"][table["fac_atom"][k]]) ** table["fac_pow"][k]
+            acc = acc + prod
+        if table["func_flags"][f] & 1:
+            acc = acc - np.log(atom_value(table["atoms"][table["log_atom"]]))
+        outs.append(acc)
+    return outs
+
+
+def moment_lookup(x, u, order, xd=None):
+    """atom -> numpy value from extended-precision sample moments."""
+    ru, rxu = dorc.raw_moments(x if xd is None else xd[:, 0], u, order + 1)
+    ub = ru[1]
+    du = [np.mean((u - ub) ** k) for k in range(order + 2)]
+    xs = x if xd is None else xd
+
+    def val(a):
+        kind = a[0]
+        if kind == "u":
+            return ru[a[1]]
+        if kind == "du":
+            return du[a[1]]
+        if kind == "umean":
+            return ub
+        col = (lambda d: xs) if xd is None else (lambda d: xs[:, d])
+        d = a[-1] if kind != "x1" else a[1]
+        xx = col(d or 0)
+        if kind == "xu":
+            return np.mean(xx * (u ** a[1])[:, None], axis=0)
+        if kind == "x1":
+            return xx.mean(axis=0)
+        if kind == "dxdu":
+            return np.mean((xx - xx.mean(axis=0)) * ((u - ub) ** a[1])[:, None], axis=0)
+        raise KeyError(a)
+
+    return val
+
+
+@pytest.mark.parametrize("central", [False, True])
+@pytest.mark.parametrize("post_func", [None, "minus_log", "pow_2"])
+def test_symbolic_tables_match_oracle(legacy, central, post_func):
+    """factory_derivatives tables evaluated by the test interpreter == jet oracle
+    == the reference's legacy numbers (tests/test_beta.py:17-26, 519-543)."""
+    x, u, order = legacy["x"], legacy["u"], int(legacy["order"])
+    d = beta.factory_derivatives("x_ave", central=central, post_func=post_func)
+    table = S.compile_table(d.series[i] for i in range(order + 1))
+    got = np.array(run_table(table, moment_lookup(x, u, order)))
+    want = dorc.derivs_x_ave(x, u, order, post_func=post_func)
+    np.testing.assert_allclose(got, want, rtol=2e-8, atol=1e-10)
+    if post_func is None:
+        np.testing.assert_allclose(got, legacy["derivs"], rtol=2e-8)
+    if post_func == "minus_log":
+        np.testing.assert_allclose(got, legacy["derivs_minus_log"], rtol=2e-8)
+
+
+@pytest.mark.parametrize("central", [False, True])
+def test_symbolic_xalpha_tables_match_legacy(legacy, central):
+    xd, u, order = legacy["x_dep"], legacy["u"], int(legacy["order"])
+    d = beta.factory_derivatives("x_ave", central=central, xalpha=True)
+    table = S.compile_table(d.series[i] for i in range(order + 1))
+    got = np.array(run_table(table, moment_lookup(None, u, order, xd=xd)))
+    np.testing.assert_allclose(got, legacy["derivs_dep"], rtol=5e-8, atol=1e-10)
+
+
+def test_minus_log_chain_table_equals_direct(legacy):
+    """derivs(minus_log=True) (chain-rule table on derivative values, reference
+    models.py:261-288) == post_func='minus_log' (differentiating -log<x> directly)."""
+    from thermoextrap_amd.models import _minus_log_series
+
+    order = 5
+    X = legacy["derivs"]
+    ml = _minus_log_series()
+    table = S.compile_table(ml[i] for i in range(order + 1))
+    got = np.array(run_table(table, lambda a: X[a[1]]))
+    np.testing.assert_allclose(got, legacy["derivs_minus_log"], rtol=1e-9)
+
+
+# ---------------------------------------------------------------------------
+# symbolic identities (reference tests/test_u_equations.py:55-88)
+# ---------------------------------------------------------------------------
+def _x_to_u(p: S.Poly, central: bool) -> S.Poly:
+    """substitute x == u in a Poly: dxdu(n) -> du(n+1), x1 -> <u>; xu(n) -> u(n+1)."""
+
+    def m(a):
+        if a[0] == "dxdu":
+            return S.du(a[1] + 1)
+        if a[0] == "x1":
+            return S.umean()
+        if a[0] == "xu":
+            return S.u_raw(a[1] + 1)
+        return None
+
+    return p.subs(m)
+
+
+@pytest.mark.parametrize("central", [True, False])
+def test_x_ave_equals_u_ave_when_x_is_u(central):
+    xs = beta.SymDerivBeta.x_ave(central=central)
+    us = beta.SymDerivBeta.u_ave(central=central)
+    for i in range(7):
+        assert _x_to_u(xs[i], central) == us[i], i
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_dxdun_equals_dun_shifted(n):
+    a = beta.SymDerivBeta.dxdun_ave(n=n)
+    b = beta.SymDerivBeta.dun_ave(n=n + 1)
+    for i in range(6):
+        assert _x_to_u(a[i], True) == b[i]
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3])
+def test_xun_equals_un_shifted(n):
+    a = beta.SymDerivBeta.xun_ave(n=n)
+    b = beta.SymDerivBeta.un_ave(n=n + 1)
+    for i in range(6):
+        assert _x_to_u(a[i], False) == b[i]
+
+
+def test_named_averages_against_jets(legacy):
+    u = legacy["u"]
+    order = 4
+    val = moment_lookup(legacy["x"], u, order + 4)
+    for n in (2, 3):
+        d = beta.factory_derivatives("dun_ave", n=n, central=True)
+        got = run_table(S.compile_table(d.series[i] for i in range(order + 1)), val)
+        np.testing.assert_allclose(got, dorc.derivs_dun_ave(u, n, order), rtol=1e-7, atol=1e-12)
+        d = beta.factory_derivatives("un_ave", n=n, central=False)
+        got = run_table(S.compile_table(d.series[i] for i in range(order + 1)), val)
+        np.testing.assert_allclose(got, dorc.derivs_un_ave(u, n, order), rtol=1e-8)
+
+
+def test_expr_view_is_sympy_and_matches_hand_derivation():
+    import sympy as sp
+
+    d = beta.factory_derivatives("x_ave", central=True)
+    du, dxdu = sp.IndexedBase("du"), sp.IndexedBase("dxdu")
+    # SURVEY App. B (hand-derived from reference beta.py:52-54,110-116,174-176)
+    assert sp.simplify(d.exprs[3] - (-dxdu[3] + 3 * dxdu[1] * du[2])) == 0
+    assert sp.simplify(d.exprs[4] - (dxdu[4] - 6 * dxdu[2] * du[2] - 4 * dxdu[1] * du[3])) == 0
+
+
+def test_factory_argument_errors():
+    with pytest.raises(ValueError):
+        beta.SymDerivBeta.dun_ave(n=1)
+    with pytest.raises(ValueError):
+        beta.SymDerivBeta.dun_ave(n=2, central=False)
+    with pytest.raises(ValueError):
+        beta.SymDerivBeta.un_ave(n=0)
+    with pytest.raises(TypeError):
+        beta.SymDerivBeta.dxdun_ave(n=1, xalpha=True, d=None)
+    with pytest.raises(ValueError):
+        beta.SymDerivBeta.from_name("nope")
+    with pytest.raises(ValueError):
+        S.apply_post_func(S.x1(), "bogus")
+    assert math.isclose(float(S.DerivSeries(S.x1())[1].terms[((("dxdu", 1, None), 1),)]), -1.0)

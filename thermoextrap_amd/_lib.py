@@ -90,6 +90,11 @@ def load(path: Path | None = None):
             f"{p} is missing: the HIP extension has not been built. "
             "Run `python -m thermoextrap_amd._build` (hipcc, gfx950). There is no CPU fallback."
         )
+    # torch must load its HIP runtime first: loading libtxmom (linked against
+    # /opt/rocm's libamdhip64) before torch leaves two runtimes in the process and
+    # the second one sees no device.
+    import torch  # noqa: F401
+
     lib = ct.CDLL(str(p))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here == ABI drift: fail loudly
