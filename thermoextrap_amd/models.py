@@ -126,9 +126,9 @@ class Derivatives(_Params):
         self._tables: dict = {}
 
     def _table_for(self, src, order, extra_resolve=None) -> _DeviceTable:
-        key = (order, src.central, src.x_is_u, src.nrep, src.ndrv, src.nval, src.K,
-               id(extra_resolve) if extra_resolve else None)
-        if key not in self._tables:
+        key = (order, src.central, src.x_is_u, src.nrep, src.ndrv, src.nval, src.K)
+        # tables that reference callback-owned buffers are rebuilt per call (tiny)
+        if extra_resolve is not None or key not in self._tables:
             table = S.compile_table(self.series[i] for i in range(order + 1))
             specs = []
             for a in table["atoms"]:
@@ -142,7 +142,10 @@ class Derivatives(_Params):
                     d, n = (a[1] or 0), 0
                 off, s_rep, s_val = src.resolve(kind, n, d)
                 specs.append((0, off, s_rep, s_val))
-            self._tables[key] = _DeviceTable(table, specs)
+            built = _DeviceTable(table, specs)
+            if extra_resolve is not None:
+                return built
+            self._tables[key] = built
         return self._tables[key]
 
     def derivs(self, data=None, order=None, args=None, minus_log=False, order_dim="order", concat_kws=None,
