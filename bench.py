@@ -2,10 +2,12 @@
 """bench.py -- samples/s of the order-4 central-comoment bootstrap
 (BASELINE.json metric) on MI355X.
 
-One "step" = one `DataCentralMomentsVals.resample({"nrep": nrep})` of a state
-point whose samples are already resident in HBM: draw the sampler (device
-multinomial: stage-1/2 kernels), run the fused bootstrap kernel
-(txm_resample_vals: Philox stage 3 + FP64-MFMA contraction + finalize).
+One "step" = `ExtrapModel.resample({"nrep": nrep}).derivs()` through the drop-in
+API on a state point whose samples are already resident in HBM: draw the
+sampler (device multinomial: stage-1/2 kernels), run the fused bootstrap kernel
+(txm_resample_vals: Philox stage 3 + FP64-MFMA contraction + finalize),
+evaluate the derivative table on the replicate states (txm_eval_poly) and copy
+the (order+1, nrep, N_obs) derivatives to the host.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -44,6 +46,7 @@ def parse():
     p.add_argument("--nrep", type=int, default=1000)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU baseline duration")
+    p.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0: min(cores, 16), the 1-GPU box share)")
     return p.parse_args()
 
 
@@ -126,18 +129,33 @@ def main():
     K = order + 1
     x, u = make_data(N, C, seed=1000 + rank, torch=torch)
 
-    # state point as DataCentralMomentsVals.from_vals would hold it: values + reduced state
-    state = engine.reduce_vals(x, u, order)
+    # ---- the state point through the public drop-in API -----------------------------
+    # DataCentralMomentsVals.from_vals reduces the samples once (txm_reduce_vals);
+    # ExtrapModel.resample({"nrep": n}) draws the sampler and bootstraps
+    # (txm_sampler_tile_counts + txm_resample_vals); .derivs() evaluates the
+    # derivative table on the replicate states (txm_eval_poly) and copies the
+    # (order+1, nrep, N_obs) result to the host.
+    import thermoextrap_amd as xtrap
+    from thermoextrap_amd.moments import DeviceDataArray
+
+    xv = DeviceDataArray(x, ("rec", "val"))
+    uv = DeviceDataArray(u, ("rec",))
+    data = xtrap.DataCentralMomentsVals.from_vals(xv=xv, uv=uv, order=order, central=True)
+    xem = xtrap.beta.factory_extrapmodel(5.6, data)
+    state = data.dxduave.device_values  # (C, 2, K)
     pivot = torch.cat([state[0, 0, 1:2], state[:, 1, 0]]).contiguous()  # {<u>, <x_c>}
     sampler = engine.DeviceSampler(seed=0, nrep=nrep, ndat=N)
     out = torch.empty((nrep, C, 2, K), dtype=torch.float64, device="cuda")
-    gathered = [torch.empty_like(out) for _ in range(world)] if world > 1 else None
+    results = {}
 
     def step(i):
-        sampler.draw(seed=12345 + 1000 * i + rank)
-        engine.resample_vals(x, u, order, sampler=sampler, pivot=pivot, out=out)
+        boot = xem.resample(sampler={"nrep": nrep, "device": True, "seed": 12345 + 1000 * i + rank})
+        derivs = boot.derivs(norm=False)  # host labelled array (order+1, rep, val)
+        results["derivs"] = derivs
         if world > 1:
-            dist.all_gather(gathered, out)  # final gather of the replicate slabs over xGMI
+            slab = boot.data.dxduave.device_values
+            gathered = [torch.empty_like(slab) for _ in range(world)]
+            dist.all_gather(gathered, slab)  # final gather of the replicate slabs over xGMI
 
     def barrier():
         if world > 1:
@@ -176,6 +194,24 @@ def main():
     t_samp = timed(lambda: sampler.draw(seed=777), 3)
     t_red = timed(lambda: engine.reduce_vals(x, u, order), 10)
 
+    def pmc_traffic(kernel_prefix):
+        """HBM bytes per launch from the committed PMC summary (separate rocprofv3 --pmc
+        passes of this same command, tools/collect_profiles.py); None if the profiled
+        workload differs from this run's."""
+        import glob
+
+        for f in sorted(glob.glob(str(ROOT / "profiles" / "*_traffic.json")), reverse=True):
+            try:
+                d = json.loads(Path(f).read_text())
+            except Exception:  # noqa: BLE001
+                continue
+            if (N, C, order, nrep) != (100_000_000, 32, 4, 1000):
+                return None
+            for k, v in d.get("kernels", {}).items():
+                if k.startswith(kernel_prefix):
+                    return v.get("hbm_bytes_per_launch")
+        return None
+
     alg_bytes = 8.0 * N * (C + 1)                    # SURVEY 8(d): samples read once
     alg_flops = 2.0 * N * nrep * K * (C + 1)         # SURVEY 8(d): dense contraction F.M
     roofline = {
@@ -185,8 +221,10 @@ def main():
         "peak": FP64_PEAK_TFLOPS,
         "unit": "TFLOP/s",
         "frac": alg_flops / (t_boot * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-        "traffic": None,
+        "traffic": pmc_traffic("txm::resample_kernel"),
         "ms": t_boot,
+        "algorithmic_flops": alg_flops,
+        "algorithmic_bytes": alg_bytes,
         "hbm_achieved_GBs": alg_bytes / (t_boot * 1e-3) / 1e9,
         "hbm_frac": alg_bytes / (t_boot * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "note": "algorithmic flops = 2*N*nrep*K*(N_obs+1); fp64 peak 78.6 TF (vector = matrix); "
@@ -199,7 +237,8 @@ def main():
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": alg_bytes / (t_red * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "traffic": None,
+        "traffic": pmc_traffic("txm::reduce_rowmajor_kernel"),
+        "algorithmic_bytes": alg_bytes,
         "ms": t_red,
         "samples_per_s": N / (t_red * 1e-3),
     }
@@ -230,7 +269,8 @@ def main():
             "roofline_reduce": roofline_reduce,
         }
         if world == 1 and not args.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(C, order, nrep, args.cpu_seconds, os.cpu_count() or 1)
+            nthr = args.cpu_threads or min(os.cpu_count() or 1, 16)
+            rec["cpu_baseline"] = cpu_baseline(C, order, nrep, args.cpu_seconds, nthr)
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.destroy_process_group()
