@@ -1,0 +1,75 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU sharding helpers: the N>1 path of
+bench.py / thermoextrap_amd.distributed is exercised with synthetic slabs, since the
+compute itself needs a GPU."""
+
+import os
+import subprocess
+import sys
+import textwrap
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+WORKER = textwrap.dedent(
+    """
+    import os, sys
+    sys.path.insert(0, os.environ["TXM_ROOT"])
+    import torch, torch.distributed as dist
+    from thermoextrap_amd import distributed as D
+    dist.init_process_group("gloo")
+    rank, w = D.world()
+    assert w == 2
+    # replicate-sharded bootstrap: nrep = 7 -> shares (4, 3); slab content encodes (rank, seed, local index)
+    seeds = D.replicate_seeds(123, w)
+    assert len(set(seeds)) == w
+    def compute(n, seed):
+        assert seed == seeds[rank]
+        out = torch.zeros((n, 3, 2, 5), dtype=torch.float64)
+        out += rank * 100
+        out[:, 0, 0, 0] += torch.arange(n, dtype=torch.float64)
+        return out
+    full = D.sharded_bootstrap(compute, nrep=7, seed=123)
+    assert full.shape == (7, 3, 2, 5)
+    want = torch.tensor([0, 1, 2, 3, 100, 101, 102], dtype=torch.float64)
+    assert torch.equal(full[:, 0, 0, 0], want), full[:, 0, 0, 0]
+    assert torch.equal(full[:4, 1], torch.zeros(4, 2, 5, dtype=torch.float64))
+    assert torch.equal(full[4:, 1], torch.full((3, 2, 5), 100.0, dtype=torch.float64))
+    # state sharding: 5 states over 2 ranks, results come back in order on every rank
+    states = list(range(5))
+    outs = D.sharded_states(states, lambda s: torch.full((2, 2), float(s * s)))
+    assert [float(o[0, 0]) for o in outs] == [0.0, 1.0, 4.0, 9.0, 16.0]
+    # uneven slabs without counts
+    g = D.all_gather_slabs(torch.full((rank + 1, 2), float(rank)))
+    assert g.shape == (3, 2) and g[:, 0].tolist() == [0.0, 1.0, 1.0]
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+    """
+)
+
+
+def test_shard_range_partition():
+    from thermoextrap_amd import distributed as D
+
+    for n in (0, 1, 7, 16, 1000):
+        for w in (1, 2, 3, 8):
+            parts = [D.shard_range(n, r, w) for r in range(w)]
+            assert [i for p in parts for i in p] == list(range(n))
+            sizes = [len(p) for p in parts]
+            assert max(sizes) - min(sizes) <= 1
+            assert D.shard_counts(n, w) == sizes
+    with pytest.raises(ValueError):
+        D.shard_range(4, 2, 2)
+
+
+def test_two_rank_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, TXM_ROOT=str(ROOT), MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout

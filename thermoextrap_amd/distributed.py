@@ -1,0 +1,94 @@
+"""Multi-GPU sharding of the hot path (one process per GPU, torch.distributed;
+backend "nccl" is RCCL over xGMI on MI355X, "gloo" in CPU tests).
+
+The path shards with **no data-path collective** (SURVEY 8(e)): state points and
+bootstrap replicates are independent.  Every rank works on its contiguous share
+and one all-gather of the small result slabs ([nrep, C, 2, K] states or
+[order+1, nrep, C] derivatives; <= a few MB) ends the step -- each GPU sends its
+slab on all xGMI links at once; never a ring all-reduce of bulk data.
+"""
+
+from __future__ import annotations
+
+from collections.abc import Callable, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def world() -> tuple[int, int]:
+    """(rank, world_size); (0, 1) when torch.distributed is not initialised."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_range(n: int, rank: int | None = None, world_size: int | None = None) -> range:
+    """Contiguous share of ``range(n)``: the first ``n % world`` ranks get one extra item."""
+    r, w = world()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    if not 0 <= rank < world_size:
+        raise ValueError(f"rank {rank} outside [0, {world_size})")
+    base, extra = divmod(n, world_size)
+    lo = rank * base + min(rank, extra)
+    return range(lo, lo + base + (1 if rank < extra else 0))
+
+
+def shard_counts(n: int, world_size: int) -> list[int]:
+    return [len(shard_range(n, r, world_size)) for r in range(world_size)]
+
+
+def all_gather_slabs(local: torch.Tensor, counts: Sequence[int] | None = None, group=None) -> torch.Tensor:
+    """Concatenate every rank's slab along dim 0 (slabs may differ in dim-0 length)."""
+    rank, w = world()
+    if w == 1:
+        return local
+    if counts is None:
+        n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+        ns = [torch.zeros_like(n) for _ in range(w)]
+        dist.all_gather(ns, n, group=group)
+        counts = [int(t.item()) for t in ns]
+    nmax = max(counts)
+    pad = local
+    if local.shape[0] < nmax:  # equal-size buffers keep the collective a plain all-gather
+        pad = torch.zeros((nmax, *local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(w)]
+    dist.all_gather(bufs, pad.contiguous(), group=group)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
+def replicate_seeds(seed: int, world_size: int) -> list[int]:
+    """Independent sampler seeds per rank (replicate-sharded bootstrap): the
+    device stream is keyed by (seed, replicate, tile), so distinct seeds give
+    independent replicate slabs."""
+    return [(int(seed) * 0x9E3779B97F4A7C15 + r * 0xD1B54A32D192ED03) & (2**63 - 1) for r in range(world_size)]
+
+
+def sharded_bootstrap(compute: Callable[[int, int], torch.Tensor], nrep: int, seed: int, group=None) -> torch.Tensor:
+    """Replicate-sharded bootstrap of ONE state point whose samples every rank holds:
+    rank r computes ``compute(nrep_r, seed_r)`` -> slab ``[nrep_r, ...]`` and all ranks
+    receive the ``[nrep, ...]`` concatenation."""
+    rank, w = world()
+    counts = shard_counts(nrep, w)
+    slab = compute(counts[rank], replicate_seeds(seed, w)[rank])
+    if slab.shape[0] != counts[rank]:
+        raise ValueError("compute returned the wrong number of replicates")
+    return all_gather_slabs(slab, counts, group)
+
+
+def sharded_states(states: Sequence, func: Callable, group=None) -> list:
+    """State-point sharding (reference models.py:635-641 runs this loop serially):
+    rank r evaluates ``func(state)`` -> tensor for its share of ``states``; every
+    rank gets the full list back, in order.  All results must share one shape."""
+    rank, w = world()
+    mine = shard_range(len(states), rank, w)
+    outs = [func(states[i]) for i in mine]
+    if w == 1:
+        return outs
+    counts = shard_counts(len(states), w)
+    if not outs:
+        raise ValueError("more ranks than states: give every rank at least one state")
+    full = all_gather_slabs(torch.stack(outs), counts, group)
+    return list(full.unbind(0))
