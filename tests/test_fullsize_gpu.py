@@ -1,0 +1,124 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties (the CPU
+oracle cannot run these sizes):
+
+  C2          N = 1e7, N_obs = 8,  order 4, nrep = 200
+  north star  N = 1e8, N_obs = 32, order 4, nrep = 1000 (bootstrap), order 6 (reduce)
+
+Properties: exact replicate weights; merge(reduce(halves)) == reduce(all); affine
+covariance of the states; column independence; fused device sampler == explicit
+frequency table materialised from the same stream (whose bit-exactness vs the CPU
+restatement is tested at small N); replicate means scatter like sigma/sqrt(N).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng(txm):
+    from thermoextrap_amd import engine
+
+    return engine
+
+
+def synth(N, C, seed):
+    from bench import make_data
+
+    return make_data(N, C, seed, torch)
+
+
+def scale_of(x_std, u_std, K):
+    sc = torch.empty((x_std.numel(), 2, K), dtype=torch.float64, device="cuda")
+    for b in range(K):
+        sc[:, 0, b] = u_std**b
+        sc[:, 1, b] = x_std * u_std**b
+    return sc
+
+
+def close(a, b, sc, tol):
+    err = ((a - b).abs() / (b.abs() + sc)).max().item()
+    assert err <= tol, err
+
+
+@pytest.mark.parametrize("N,C,order", [(10_000_000, 8, 4), (100_000_000, 32, 6)])
+def test_reduce_fullsize_properties(eng, N, C, order):
+    x, u = synth(N, C, 7)
+    K = order + 1
+    st = eng.reduce_vals(x, u, order)
+    assert torch.isfinite(st).all()
+    assert (st[:, 0, 0] == float(N)).all()                       # sum of unit weights is exact
+    sc = scale_of(x.std(dim=0), u.std(), K)
+    # (1) split / merge: reduce(all) == merge(reduce(first), reduce(second)) through resample_data
+    h = N // 2 + 12345
+    parts = torch.stack([eng.reduce_vals(x[:h], u[:h], order), eng.reduce_vals(x[h:], u[h:], order)])
+    merged = eng.resample_data(parts, None, order)[0]
+    close(merged, st, sc, 2e-12)
+    # (2) affine covariance: x -> a x + b, u -> c u + d
+    a, b_, c, d = 3.0, -7.0, 0.5, 11.0
+    st2 = eng.reduce_vals(x[:, :4] * a + b_, u * c + d, order)
+    want = st[:4].clone()
+    for i in range(2):
+        for j in range(K):
+            if (i, j) == (0, 0):
+                continue
+            want[:, i, j] = st[:4, i, j] * a**i * c**j
+    want[:, 1, 0] = a * st[:4, 1, 0] + b_
+    want[:, 0, 1] = c * st[:4, 0, 1] + d
+    sc2 = scale_of(x[:, :4].std(dim=0) * a, u.std() * c, K)
+    close(st2, want, sc2, 5e-12)
+    # (3) column independence and layout independence
+    sub = eng.reduce_vals(x[:, 3:5].contiguous(), u, order)
+    close(sub, st[3:5], sc[3:5], 1e-13)
+    if N <= 10_000_000:
+        close(eng.reduce_vals(x.t().contiguous().t(), u, order), st, sc, 1e-12)   # (val, rec) layout
+    # (4) first moments against torch's own reduction
+    np.testing.assert_allclose(st[:, 1, 0].cpu().numpy(), x.mean(dim=0).cpu().numpy(), rtol=1e-12)
+    np.testing.assert_allclose(st[0, 0, 1].item(), u.mean().item(), rtol=1e-13)
+    np.testing.assert_allclose(st[0, 0, 2].item(), u.var(unbiased=False).item(), rtol=1e-10)
+
+
+@pytest.mark.parametrize("N,C,order,nrep", [(10_000_000, 8, 4, 200), (100_000_000, 32, 4, 1000)])
+def test_bootstrap_fullsize_properties(eng, N, C, order, nrep):
+    x, u = synth(N, C, 11)
+    K = order + 1
+    st = eng.reduce_vals(x, u, order)
+    sc = scale_of(x.std(dim=0), u.std(), K)[None]
+    s = eng.DeviceSampler(20261003, nrep, N)
+    counts = s.counts.view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    assert (counts.sum(dim=1) == N).all()                        # every replicate draws exactly N samples
+    rep = eng.resample_vals(x, u, order, sampler=s)
+    assert rep.shape == (nrep, C, 2, K) and torch.isfinite(rep).all()
+    assert (rep[:, :, 0, 0] == float(N)).all()                   # replicate weight = N exactly
+    # u-row identical for every observable column
+    assert (rep[:, :, 0, :] == rep[:, :1, 0, :]).all()
+    # replicate means scatter around the sample mean like sigma / sqrt(N)
+    z = (rep[:, :, 1, 0] - st[None, :, 1, 0]) / (x.std(dim=0)[None] / np.sqrt(N))
+    assert abs(z.mean().item()) < 5 / np.sqrt(nrep * C) * 3 and 0.85 < z.std().item() < 1.15
+    # replicate variances are unbiased-ish: mean over replicates close to the sample variance
+    v = rep[:, 0, 0, 2].mean().item() / st[0, 0, 2].item()
+    assert abs(v - 1.0) < 5e-3 * np.sqrt(1e5 / N) + 1e-6 * 50
+    # fused sampler == explicit frequency table from the same stream, on a few replicates
+    few = 2
+    s2 = eng.DeviceSampler(424242, few, N)
+    fused = eng.resample_vals(x, u, order, sampler=s2)
+    freq = s2.freq()
+    assert (freq.sum(dim=1) == N).all() and (freq >= 0).all()
+    explicit = eng.resample_vals(x, u, order, freq=freq)
+    close(fused, explicit, sc, 2e-13)
+    # pivot independence and column independence
+    piv = torch.cat([st[0, 0, 1:2] + 3.0 * u.std(), st[:, 1, 0] - 2.0 * x.std(dim=0)]).contiguous()
+    close(eng.resample_vals(x, u, order, sampler=s2, pivot=piv), fused, sc, 1e-9)
+    sub = eng.resample_vals(x[:, 2:4].contiguous(), u, order, sampler=s2)
+    close(sub, fused[:, 2:4], sc[:, 2:4], 1e-13)
+    # weights: w = 2 doubles every weight and changes nothing else
+    w2 = torch.full((N,), 2.0, dtype=torch.float64, device="cuda")
+    wrep = eng.resample_vals(x[:, :C], u, order, sampler=s2, w=w2)
+    assert (wrep[:, :, 0, 0] == 2.0 * N).all()
+    wrep[:, :, 0, 0] = float(N)
+    close(wrep, fused, sc, 1e-13)
+    # determinism: same seed, same bits
+    again = eng.resample_vals(x, u, order, sampler=eng.DeviceSampler(424242, few, N))
+    assert torch.equal(again, fused)
