@@ -84,7 +84,9 @@ def load(path: Path | None = None):
     global _lib
     if _lib is not None:
         return _lib
-    p = Path(path) if path else LIB
+    import os
+
+    p = Path(path) if path else Path(os.environ.get("TXM_LIBRARY", LIB))  # TXM_LIBRARY: A/B builds of the kernels
     if not p.exists():
         raise TxmError(
             f"{p} is missing: the HIP extension has not been built. "

@@ -34,19 +34,24 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int RS_BLOCK = 256;          // 4 waves
 constexpr int RS_WAVES = RS_BLOCK / 64;
 constexpr int RS_REPS = 16;            // replicates per wave (MFMA M)
-// f tile of one wave: u8 counts, layout [kk = sample quarter][rep][s = sample in quarter]
-// with a 264-byte row pitch: for the 8-byte reads of the contraction loop the bank
-// pair is 2*(rep + 16*kk) mod 64, i.e. conflict-free inside each 32-lane group.
+// f tile of one wave: u8 counts, layout [sample slot 0..1023][rep 0..15] (16 KiB).
+// A draw of slot `off` for replicate rr is one ds_add_u32 of (1 << 8*(rr&3)) at byte
+// off*16 + (rr & ~3): one shift-add of VALU work per draw.  The contraction reads
+// one byte per step (ds_read_u8, immediate offset): no VALU unpacking.
+// On gfx950 the FP64 MFMA shares the VALU datapath (tools/mfma_f64_peak4.hip:
+// every VALU instruction costs 4.5-8 cycles of matrix-pipe time), so the design
+// rule of this kernel is: as few VALU instructions per MFMA as possible.
 constexpr int RS_QUARTER = SM_T / 4;                  // 256 samples per lane-group per tile
-constexpr int RS_ROW_PITCH = RS_QUARTER + 8;          // bytes
-constexpr int RS_KK_PITCH = RS_REPS * RS_ROW_PITCH;   // 4224 bytes
-constexpr int RS_TILE_BYTES = 4 * RS_KK_PITCH;        // 16896 bytes per wave
+constexpr int RS_TILE_BYTES = SM_T * RS_REPS;         // 16384 bytes per wave
 // steps per register-prefetch group: as many as the VGPR budget (2 waves/SIMD,
 // 256 VGPRs) allows next to the K*NBLK accumulator tiles.
 constexpr int rs_group(int K, int NBLK, bool weighted, bool explicit_) {
   const int per_step = 2 + 2 * NBLK + (weighted ? 2 : 0) + (explicit_ ? 10 : 0);
   for (int g = 8; g > 2; g >>= 1)
-    if (K * NBLK * 8 + 2 * g * per_step <= 160) return g;
+#ifndef TXM_EXP_BUDGET
+#define TXM_EXP_BUDGET 160
+#endif
+    if (K * NBLK * 8 + 2 * g * per_step <= TXM_EXP_BUDGET) return g;
   return 2;
 }
 
@@ -83,6 +88,61 @@ struct ResampleArgs {
 // 8 consecutive steps, f as one 8-byte LDS read per 8 steps, and the loads of
 // group g+1 are issued before the 8*K*NBLK MFMAs of group g (register double
 // buffer), so HBM/L2 latency hides under the matrix pipe.
+// Stage 3 of the sampler for a FULL tile and the 16 replicates of one wave, with the
+// minimum of VALU work (the stream itself is the one oracle/philox_oracle.c defines:
+// draw d of (r, t) = 10-bit field d % 12 of Philox call d / 12 -- which lane runs a
+// call is free).  Replicates are taken in pairs: calls 0..63 of each go to one wave
+// iteration each, and their remaining calls 64..95 (n - 768 draws, ~1/3 of a wave)
+// share a third iteration, 32 lanes per replicate.  Fields past the replicate's
+// draw count add 0 instead of being branched around.
+template <bool ALL_VALID>
+__device__ __forceinline__ void tile_calls(uint32_t *tw, uint32_t k0, uint32_t k1, uint32_t r, uint32_t t,
+                                           uint32_t c, uint32_t n, uint32_t inc, uint32_t wsel) {
+  const uint32_t first = c * 12u;
+  if (first >= n) return;
+  const Philox4 o = philox4x32_10(c, t, r, 3u, k0, k1);
+  const uint32_t nd = n - first;
+#pragma unroll
+  for (int wi = 0; wi < 4; ++wi) {
+    const uint32_t word = o.w[wi];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const uint32_t f = (word >> (10 * k)) & 1023u;
+      const uint32_t add = ALL_VALID ? inc : (((uint32_t)(wi * 3 + k) < nd) ? inc : 0u);
+      atomicAdd(&tw[f * (RS_REPS / 4) + wsel], add);
+    }
+  }
+}
+
+__device__ __forceinline__ void fill_tile_full(const ResampleArgs &a, uint32_t *tw, int64_t rep0, int64_t t,
+                                               int lane) {
+#pragma unroll 1
+  for (int p = 0; p < RS_REPS / 2; ++p) {
+    const int64_t ra = rep0 + 2 * p, rb = ra + 1;
+    if (ra >= a.nrep) break;  // wave-uniform
+    const uint32_t na = a.counts[(size_t)ra * a.ntiles + t];
+    const uint32_t nb = rb < a.nrep ? a.counts[(size_t)rb * a.ntiles + t] : 0u;
+    const uint32_t wsel = (uint32_t)p >> 1;                  // (2p) >> 2 == (2p+1) >> 2
+    const uint32_t inc_a = 1u << (8u * ((2u * p) & 3u)), inc_b = inc_a << 8;
+    // iterations 1 and 2: calls 0..63 of each replicate; when n >= 768 (wave-uniform,
+    // practically always) every field is a real draw and no select is needed
+    if (na >= 768u) tile_calls<true>(tw, a.k0, a.k1, (uint32_t)ra, (uint32_t)t, (uint32_t)lane, na, inc_a, wsel);
+    else tile_calls<false>(tw, a.k0, a.k1, (uint32_t)ra, (uint32_t)t, (uint32_t)lane, na, inc_a, wsel);
+    if (nb >= 768u) tile_calls<true>(tw, a.k0, a.k1, (uint32_t)rb, (uint32_t)t, (uint32_t)lane, nb, inc_b, wsel);
+    else tile_calls<false>(tw, a.k0, a.k1, (uint32_t)rb, (uint32_t)t, (uint32_t)lane, nb, inc_b, wsel);
+    // iteration 3: calls 64..95 of both, 32 lanes each
+    const bool hb = lane >= 32;
+    tile_calls<false>(tw, a.k0, a.k1, (uint32_t)(hb ? rb : ra), (uint32_t)t, 64u + ((uint32_t)lane & 31u),
+                      hb ? nb : na, hb ? inc_b : inc_a, wsel);
+    // calls >= 96 (n > 1152, a > 4 sigma event): plain loop
+    const uint32_t nmax = na > nb ? na : nb;
+    for (uint32_t c0 = 96u; c0 * 12u < nmax; c0 += 64u) {
+      tile_calls<false>(tw, a.k0, a.k1, (uint32_t)ra, (uint32_t)t, c0 + (uint32_t)lane, na, inc_a, wsel);
+      tile_calls<false>(tw, a.k0, a.k1, (uint32_t)rb, (uint32_t)t, c0 + (uint32_t)lane, nb, inc_b, wsel);
+    }
+  }
+}
+
 //
 // Tiles are always contracted over a full 1024-sample window.  The last
 // (partial) tile slides its window back to [N - 1024, N) and gives the samples
@@ -92,7 +152,9 @@ struct ResampleArgs {
 template <int K, int NBLK, bool WEIGHTED, bool EXPLICIT, bool SMALLN>
 __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // readfirstlane: tell the compiler the wave index is wave-uniform, so everything
+  // derived from it (replicate base, LDS tile base, loop bounds) lives in SGPRs
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int row = lane & 15;   // A: replicate within block;  B: column within block
   const int kk = lane >> 4;    // which quarter of the tile this lane group walks
 
@@ -144,7 +206,7 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
     double u[RS_GROUP];
     double w[RS_GROUP];
     double x[RS_GROUP][NBLK];
-    uint32_t fb[2];           // scale mode: RS_GROUP u8 counts straight from LDS
+    uint32_t fb[RS_GROUP];    // scale mode: u8 counts straight from LDS, one per step
     int64_t fi[EXPLICIT ? RS_GROUP : 1];  // parity mode: raw int64 counts
   };
 
@@ -163,47 +225,86 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
       // compiler needs fencing -- no s_barrier, waves of a workgroup drift
       // apart and their VALU/LDS phases overlap other waves' MFMA phases)
       uint4 *z = reinterpret_cast<uint4 *>(tile);
-      for (int e = lane; e < RS_TILE_BYTES / 16; e += 64) z[e] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < RS_TILE_BYTES / 16 / 64; ++e) z[e * 64 + lane] = make_uint4(0, 0, 0, 0);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
       uint32_t *tw = reinterpret_cast<uint32_t *>(tile);
-      for (int rr = 0; rr < RS_REPS; ++rr) {
-        const int64_t r = rep0 + rr;
-        if (r >= a.nrep) break;  // wave-uniform
-        const uint32_t n = a.counts[(size_t)r * a.ntiles + t];
-        const uint32_t rbase = (uint32_t)rr * RS_ROW_PITCH;
-        sampler_fine_tile(a.k0, a.k1, (uint32_t)r, (uint32_t)t, n, tsize, lane, [&](uint32_t off0) {
-          const uint32_t off = off0 + shift;
-          const uint32_t addr = (off >> 8) * RS_KK_PITCH + rbase + (off & 255u);
-          atomicAdd(&tw[addr >> 2], 1u << (8u * (addr & 3u)));
-        });
+      if (tsize == (uint32_t)SM_T) {
+        fill_tile_full(a, tw, rep0, t, lane);
+      } else {
+        for (int rr = 0; rr < RS_REPS; ++rr) {
+          const int64_t r = rep0 + rr;
+          if (r >= a.nrep) break;  // wave-uniform
+          const uint32_t n = a.counts[(size_t)r * a.ntiles + t];
+          sampler_fine_tile(a.k0, a.k1, (uint32_t)r, (uint32_t)t, n, tsize, lane, [&](uint32_t off0) {
+            const uint32_t off = off0 + shift;
+            atomicAdd(&tw[off * (RS_REPS / 4) + ((uint32_t)rr >> 2)], 1u << (8u * ((uint32_t)rr & 3u)));
+          });
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
     }
 
-    const unsigned char *frow = tile + kk * RS_KK_PITCH + row * RS_ROW_PITCH;
+    const unsigned char *frow = tile + (kk * RS_QUARTER) * RS_REPS + row;  // + s * 16 per step
     const int64_t ibase = wbase + (int64_t)kk * RS_QUARTER;
     const uint32_t lbase = (uint32_t)kk * RS_QUARTER;  // window slot of this lane's step 0
+    // unsigned 32-bit BYTE offsets: base (SGPR pair) + zext(VGPR) is the saddr form of global_load
+    const uint32_t lane_uoff = (uint32_t)(kk * RS_QUARTER) * 8u;
+    uint32_t lane_xoff[NBLK];
+#pragma unroll
+    for (int bl = 0; bl < NBLK; ++bl) lane_xoff[bl] = (uint32_t)((kk * RS_QUARTER * a.ldx_s + ccol[bl]) * 8);
+    auto ld = [](const void *base, uint32_t byteoff) {
+      return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byteoff);
+    };
 
+    // One-step operand lookahead: the A operands (f * w * du^j) and B operands
+    // (x - px) of step e+1 are computed into a second register set BEFORE the
+    // K*NBLK MFMAs of step e are issued, so the MFMAs of a step go out back to back
+    // and no VALU write targets a register an in-flight MFMA still reads.
+    struct Ops {
+      double a[K];
+      double b[NBLK];
+    };
+    auto prep_step = [&](const Grp &G, int e, Ops &o) {
+      double av;
+      if constexpr (EXPLICIT) av = (double)G.fi[e];
+      else av = (double)G.fb[e];
+      if constexpr (WEIGHTED) av *= G.w[e];
+      const double du = G.u[e] - pu;
+#pragma unroll
+      for (int bl = 0; bl < NBLK; ++bl) o.b[bl] = G.x[e][bl] - px[bl];
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        o.a[j] = av;
+        // S0[0] = sum of counts: accumulated only when weights make it non-trivial
+        // (unweighted it is the replicate's draw count, summed from `counts` below)
+        if (j > 0 || WEIGHTED || EXPLICIT) usum[j] += av;
+        av *= du;
+      }
+    };
+    auto mfma_step = [&](const Ops &o) {
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int bl = 0; bl < NBLK; ++bl)
+          acc[j][bl] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a[j], o.b[bl], acc[j][bl], 0, 0, 0);
+    };
     auto compute_group = [&](const Grp &G) {
+      Ops P, Q;
+      prep_step(G, 0, P);
 #pragma unroll
-      for (int e = 0; e < RS_GROUP; ++e) {
-        double av;
-        if constexpr (EXPLICIT) av = (double)G.fi[e];
-        else av = (double)((G.fb[e >> 2] >> (8 * (e & 3))) & 0xffu);
-        if constexpr (WEIGHTED) av *= G.w[e];
-        const double du = G.u[e] - pu;
-        double xb[NBLK];
-#pragma unroll
-        for (int bl = 0; bl < NBLK; ++bl) xb[bl] = G.x[e][bl] - px[bl];
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-          usum[j] += av;
-#pragma unroll
-          for (int bl = 0; bl < NBLK; ++bl)
-            acc[j][bl] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, xb[bl], acc[j][bl], 0, 0, 0);
-          av *= du;
+      for (int e = 0; e < RS_GROUP; e += 2) {
+        if (e + 1 < RS_GROUP) prep_step(G, e + 1, Q);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(P);
+        __builtin_amdgcn_sched_barrier(0);
+        if (e + 1 < RS_GROUP) {
+          if (e + 2 < RS_GROUP) prep_step(G, e + 2, P);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_step(Q);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     };
@@ -214,18 +315,22 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
     auto load_group = [&](int g, Grp &G) {
       const int s0 = g * RS_GROUP;
       if constexpr (!SMALLN) {
-        const double *up = a.u + ibase + s0;
+        // wave-uniform row base (SGPRs, scalar ALU) + a loop-invariant 32-bit lane
+        // offset: the loads need no per-step vector address arithmetic
+        const double *ur = a.u + (wbase + s0);
 #pragma unroll
-        for (int e = 0; e < RS_GROUP; ++e) G.u[e] = up[e];
+        for (int e = 0; e < RS_GROUP; ++e) G.u[e] = ld(ur + e, lane_uoff);
         if constexpr (WEIGHTED) {
-          const double *wp = a.w + ibase + s0;
+          const double *wr = a.w + (wbase + s0);
 #pragma unroll
-          for (int e = 0; e < RS_GROUP; ++e) G.w[e] = wp[e];
+          for (int e = 0; e < RS_GROUP; ++e) G.w[e] = ld(wr + e, lane_uoff);
         }
 #pragma unroll
-        for (int e = 0; e < RS_GROUP; ++e)
+        for (int e = 0; e < RS_GROUP; ++e) {
+          const double *xr = a.x + (wbase + s0 + e) * a.ldx_s;
 #pragma unroll
-          for (int bl = 0; bl < NBLK; ++bl) G.x[e][bl] = a.x[(ibase + s0 + e) * a.ldx_s + ccol[bl]];
+          for (int bl = 0; bl < NBLK; ++bl) G.x[e][bl] = ld(xr, lane_xoff[bl]);
+        }
         if constexpr (EXPLICIT) {
           const int64_t *fp = a.freq + (size_t)(rep_ok ? my_rep : 0) * a.N + ibase + s0;
 #pragma unroll
@@ -247,15 +352,8 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
         }
       }
       if constexpr (!EXPLICIT) {
-        if constexpr (RS_GROUP == 8) {
-          const uint2 v = *reinterpret_cast<const uint2 *>(frow + s0);
-          G.fb[0] = v.x;
-          G.fb[1] = v.y;
-        } else if constexpr (RS_GROUP == 4) {
-          G.fb[0] = *reinterpret_cast<const uint32_t *>(frow + s0);
-        } else {
-          G.fb[0] = *reinterpret_cast<const uint16_t *>(frow + s0);
-        }
+#pragma unroll
+        for (int e = 0; e < RS_GROUP; ++e) G.fb[e] = frow[(s0 + e) * RS_REPS];
       }
     };
     // groups per lane quarter (even); SMALLN: only those that hold samples
@@ -304,6 +402,13 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
         px_out[((size_t)rrow * a.C_pad + c) * K + j] = acc[j][bl][rg];
       }
   if (colgrp == 0) {
+    if constexpr (!WEIGHTED && !EXPLICIT) {
+      // lanes kk == 0 sum their replicate's tile counts of this chunk (exact integers)
+      double cnt = 0.0;
+      if (kk == 0 && rep_ok)
+        for (int64_t t = t_begin; t < t_end; ++t) cnt += (double)a.counts[(size_t)my_rep * a.ntiles + t];
+      usum[0] = cnt;  // other lane groups contribute 0
+    }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       double v = usum[j];
