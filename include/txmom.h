@@ -209,6 +209,14 @@ typedef struct txm_poly_table {
 int txm_eval_poly(const txm_poly_table *table_host, const double *const *srcs, int32_t n_srcs,
                   int64_t nrep, int64_t nval, double *out, txm_stream stream);
 
+/* ---- (f-2) covariance of the derivatives over bootstrap replicates --------- */
+/* vals [n_ord][nrep][nval] -> cov [nval][n_ord][n_ord] with ddof = 1 (numpy.cov),
+ * the per-output covariance that gpr_active.input_GP_from_state feeds to the GP
+ *   replaces np.cov(resamp_derivs.values[..., k]) for every output k
+ *   reference: src/thermoextrap/gpr_active/active_utils.py:134-140.  n_ord <= 16. */
+int txm_cov_over_rep(const double *vals, int32_t n_ord, int64_t nrep, int64_t nval, double *cov,
+                     txm_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

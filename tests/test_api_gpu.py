@@ -489,3 +489,39 @@ def test_lnpi_golden(xtrap, lnpi_samples, central):
     for s in samples:
         b = out.sel(beta=s["beta"], order=s["order"])
         np.testing.assert_allclose(s["lnpi_data"].values, b.values, rtol=1e-7, atol=1e-9)
+
+
+# ---------------------------------------------------------------------------
+# gpr_active.input_GP_from_state contract
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("log_scale", [False, True])
+def test_input_gp_from_state(fixture, xtrap, log_scale):
+    """(x, y, cov) as reference gpr_active/active_utils.py:58-142 builds them: y = derivs,
+    cov[k] = np.cov over replicates of the derivative orders of output k (Faa di Bruno
+    transform for log_scale), here from the device covariance kernel."""
+    import sympy as sp
+
+    order = 3
+    data = xtrap.DataCentralMomentsVals.from_vals(xv=fixture.x, uv=fixture.u, order=order, central=True)
+    state = xtrap.beta.factory_extrapmodel(0.5, data)
+    idx = np.random.default_rng(3).choice(100, (50, 100))
+    x_data, y_data, cov = xtrap.gpr_input.input_GP_from_state(state, n_rep=50, log_scale=log_scale,
+                                                             sampler={"indices": idx})
+    assert x_data.shape == (order + 1, 2) and y_data.shape == (order + 1, 5) and cov.shape == (5, order + 1, order + 1)
+    derivs = state.derivs(norm=False).values
+    res = state.resample(sampler={"indices": idx}).derivs(norm=False).values  # (order, rep, val)
+    if log_scale:
+        ld = np.zeros_like(derivs)
+        ld[0] = derivs[0]
+        lres = np.zeros_like(res)
+        lres[0] = res[0]
+        for n in range(1, order + 1):
+            for k in range(1, n + 1):
+                bf = float(sp.bell(n, k, state.alpha0 * (np.log(10.0) ** np.arange(1, n - k + 2))))
+                ld[n] += derivs[k] * bf
+                lres[n] += res[k] * bf
+        derivs, res = ld, lres
+        np.testing.assert_allclose(x_data[:, 0], np.log10(0.5))
+    np.testing.assert_allclose(y_data, derivs, rtol=1e-12)
+    want = np.array([np.cov(res[..., k]) for k in range(res.shape[-1])])
+    np.testing.assert_allclose(cov, want, rtol=1e-9, atol=1e-18)

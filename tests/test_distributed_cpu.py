@@ -45,7 +45,7 @@ WORKER = textwrap.dedent(
     assert g.shape == (3, 2) and g[:, 0].tolist() == [0.0, 1.0, 1.0]
     dist.barrier()
     dist.destroy_process_group()
-    print("rank", rank, "ok")
+    open(os.path.join(os.environ["TXM_OUT"], f"rank{rank}.ok"), "w").write("ok")
     """
 )
 
@@ -67,9 +67,9 @@ def test_shard_range_partition():
 def test_two_rank_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, TXM_ROOT=str(ROOT), MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, TXM_ROOT=str(ROOT), TXM_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
            "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()

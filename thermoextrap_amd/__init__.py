@@ -21,7 +21,7 @@ _LAZY = {
     "Derivatives": "models", "ExtrapModel": "models", "StateCollection": "models",
     "DataArray": "xrlite",
 }
-_MODULES = {"distributed", "beta", "data", "models", "moments", "idealgas", "symbolic", "engine", "xrlite", "volume", "volume_idealgas", "lnpi"}
+_MODULES = {"distributed", "gpr_input", "beta", "data", "models", "moments", "idealgas", "symbolic", "engine", "xrlite", "volume", "volume_idealgas", "lnpi"}
 
 
 def __getattr__(name):

@@ -89,9 +89,11 @@ __global__ void sampler_fill_single_bin_kernel(uint32_t *__restrict__ counts, in
 // on lane c % 64); only the last, partial bin needs rejection.
 constexpr int S2_BINS = 8;
 
-// Fast path for s <= 3 (ndat <= 1.3e8): per-value counts by bit-slicing and
-// popcount, entirely in registers -- a Philox call (128 bits) is consumed with
-// ~6 ALU ops per value and word instead of one LDS read-modify-write per field.
+// Fast path for s <= 3 (ndat <= 1.3e8).  Per-tile counts come from popcounts of
+// bit-plane products: with B_b = bit b of every field, P(m) = popc(AND_{b in m} B_b)
+// for the 2^S - 1 non-empty bit subsets m, and the number of fields equal to v is
+// the Moebius sum  c(v) = sum_{m >= v} (-1)^{|m|-|v|} P(m)  (P(0) = #fields).
+// 16 ALU ops per 32-bit word for S = 3 instead of one match-and-count per value.
 template <int S>
 __global__ __launch_bounds__(256) void sampler_stage2_popc_kernel(
     uint32_t k0, uint32_t k1key, int64_t nrep, SamplerGeom g, const uint32_t *__restrict__ n1,
@@ -99,8 +101,7 @@ __global__ __launch_bounds__(256) void sampler_stage2_popc_kernel(
   constexpr int NS = 1 << S;
   constexpr int FPW = 32 / S;
   constexpr uint32_t F = 4u * FPW;
-  // LSB of every field of a word
-  uint32_t lsb = 0;
+  uint32_t lsb = 0;  // LSB of every field of a word
 #pragma unroll
   for (int k = 0; k < FPW; ++k) lsb |= 1u << (k * S);
   const int lane = threadIdx.x & 63;
@@ -121,9 +122,10 @@ __global__ __launch_bounds__(256) void sampler_stage2_popc_kernel(
     if (bb >= b_end) break;
     const uint32_t b = (uint32_t)bb;
     const uint32_t n = nb[i];
-    uint32_t cnt[NS];
+    uint32_t pc[NS];   // pc[m] = P(m); pc[0] = number of fields seen by this lane
+    uint32_t cnt[NS];  // exact per-value counts of the (rare) rejection path
 #pragma unroll
-    for (int v = 0; v < NS; ++v) cnt[v] = 0u;
+    for (int v = 0; v < NS; ++v) pc[v] = cnt[v] = 0u;
     const bool full_bin = !(bb == g.nb1 - 1 && g.last_bin_size < g.BS);
     if (full_bin) {
       for (uint32_t c0 = 0; (uint64_t)c0 * F < n; c0 += 64u) {
@@ -134,22 +136,22 @@ __global__ __launch_bounds__(256) void sampler_stage2_popc_kernel(
           const uint32_t nd = (n - first < F) ? (uint32_t)(n - first) : F;
 #pragma unroll
           for (int wi = 0; wi < 4; ++wi) {
-            // fields of this word that are real draws
-            const int nv = (int)nd - wi * FPW;
+            const int nv = (int)nd - wi * FPW;  // fields of this word that are real draws
             uint32_t valid = lsb;
             if (nv <= 0) valid = 0u;
             else if (nv < FPW) valid = lsb & ((1u << (nv * S)) - 1u);
             const uint32_t word = o.w[wi];
+            uint32_t B[S];
 #pragma unroll
-            for (int v = 0; v < NS; ++v) {
-              uint32_t pat = 0;  // value v replicated into every field
+            for (int bit = 0; bit < S; ++bit) B[bit] = (word >> bit) & valid;
+            pc[0] += __popc(valid);
 #pragma unroll
-              for (int k = 0; k < FPW; ++k) pat |= (uint32_t)v << (k * S);
-              const uint32_t m = ~(word ^ pat);
-              uint32_t t = m;
+            for (int m = 1; m < NS; ++m) {
+              uint32_t t = 0xffffffffu;
 #pragma unroll
-              for (int bit = 1; bit < S; ++bit) t &= m >> bit;
-              cnt[v] += __popc(t & valid);
+              for (int bit = 0; bit < S; ++bit)
+                if (m & (1 << bit)) t &= B[bit];
+              pc[m] += __popc(t);
             }
           }
         }
@@ -174,14 +176,31 @@ __global__ __launch_bounds__(256) void sampler_stage2_popc_kernel(
         }
       }
     }
-    // wave reduction, then lane v stores tile v of the bin
+    // wave reduction of the subset popcounts, Moebius inversion, lane v stores tile v
+#pragma unroll
+    for (int m = 0; m < NS; ++m) {
+      uint32_t x = pc[m];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+      pc[m] = x;
+      uint32_t y = cnt[m];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) y += __shfl_xor(y, off);
+      cnt[m] = y;
+    }
     uint32_t mine = 0;
 #pragma unroll
     for (int v = 0; v < NS; ++v) {
-      uint32_t x = cnt[v];
+      int32_t c = 0;
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-      if (lane == v) mine = x;
+      for (int m = 0; m < NS; ++m) {
+        if ((m & v) == v) {  // m is a superset of v
+          const int extra = __builtin_popcount(m ^ v);
+          c += (extra & 1) ? -(int32_t)pc[m] : (int32_t)pc[m];
+        }
+      }
+      const uint32_t tot = (uint32_t)c + cnt[v];
+      if (lane == v) mine = tot;
     }
     if (lane < NS) {
       const int64_t t = (bb << S) + lane;
@@ -189,7 +208,6 @@ __global__ __launch_bounds__(256) void sampler_stage2_popc_kernel(
     }
   }
 }
-
 
 constexpr int S2_WAVES = 2;  // waves per workgroup
 
@@ -334,6 +352,9 @@ static int check_spec(const txm_sampler_spec *sp, SamplerGeom *g, int64_t *nsamp
   TXM_REQUIRE(sp->ndat >= 1, "sampler: ndat < 1");
   *nsamp = sp->nsamp > 0 ? sp->nsamp : sp->ndat;
   TXM_REQUIRE(*nsamp < ((int64_t)1 << 32), "sampler: nsamp >= 2^32 unsupported");
+  // per-sample counts live in 8-bit LDS counters inside the bootstrap kernel: keep
+  // the mean count <= 16 so that an overflow (count >= 256) is beyond any reachable tail
+  TXM_REQUIRE(*nsamp <= 16 * sp->ndat, "sampler: nsamp > 16 * ndat unsupported (8-bit per-sample counters)");
   if (sampler_geometry(sp->ndat, g) != 0) {
     set_error("sampler: ndat=%lld too large (max 2^30)", (long long)sp->ndat);
     return TXM_ERR_UNSUPPORTED;

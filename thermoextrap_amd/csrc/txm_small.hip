@@ -218,9 +218,60 @@ __global__ __launch_bounds__(256) void eval_poly_kernel(PolyDev t, const double 
   }
 }
 
+// ---- covariance over replicates ---------------------------------------------
+// block per output value; two fixed-order passes (mean, then centred products).
+__global__ __launch_bounds__(256) void cov_over_rep_kernel(const double *__restrict__ vals, int n_ord,
+                                                           int64_t nrep, int64_t nval,
+                                                           double *__restrict__ cov) {
+  const int64_t v = blockIdx.x;
+  __shared__ double red[256];
+  __shared__ double mean[16];
+  for (int a = 0; a < n_ord; ++a) {
+    double acc = 0.0;
+    for (int64_t r = threadIdx.x; r < nrep; r += blockDim.x) acc += vals[((size_t)a * nrep + r) * nval + v];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) mean[a] = red[0] / (double)nrep;
+    __syncthreads();
+  }
+  for (int a = 0; a < n_ord; ++a)
+    for (int b = a; b < n_ord; ++b) {
+      double acc = 0.0;
+      for (int64_t r = threadIdx.x; r < nrep; r += blockDim.x)
+        acc += (vals[((size_t)a * nrep + r) * nval + v] - mean[a]) * (vals[((size_t)b * nrep + r) * nval + v] - mean[b]);
+      red[threadIdx.x] = acc;
+      __syncthreads();
+      for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) {
+        const double c = red[0] / (double)(nrep - 1);
+        cov[((size_t)v * n_ord + a) * n_ord + b] = c;
+        cov[((size_t)v * n_ord + b) * n_ord + a] = c;
+      }
+      __syncthreads();
+    }
+}
+
 }  // namespace txm
 
 using namespace txm;
+
+extern "C" int txm_cov_over_rep(const double *vals, int32_t n_ord, int64_t nrep, int64_t nval, double *cov,
+                                txm_stream stream) {
+  TXM_REQUIRE(vals && cov, "cov_over_rep: null pointer");
+  TXM_REQUIRE(n_ord >= 1 && n_ord <= 16 && nrep >= 2 && nval >= 1, "cov_over_rep: need 1 <= n_ord <= 16, nrep >= 2");
+  TXM_REQUIRE(nval < ((int64_t)1 << 31), "cov_over_rep: nval too large");
+  hipLaunchKernelGGL(cov_over_rep_kernel, dim3((unsigned)nval), dim3(256), 0, (hipStream_t)stream, vals,
+                     (int)n_ord, nrep, nval, cov);
+  TXM_LAUNCH_CHECK();
+  return TXM_OK;
+}
 
 extern "C" int txm_convert_cov(const double *in, double *out, int64_t n, int order, int to_central,
                                txm_stream stream) {

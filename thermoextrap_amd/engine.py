@@ -280,3 +280,14 @@ def convert_1d(states: torch.Tensor, to_central: bool) -> torch.Tensor:
     out = torch.empty_like(s)
     check(L.txm_convert_1d(_ptr(s), _ptr(out), s.numel() // M, M, int(to_central), _stream()), "txm_convert_1d")
     return out
+
+
+def cov_over_rep(vals: torch.Tensor) -> torch.Tensor:
+    """vals (n_ord, nrep, nval) -> (nval, n_ord, n_ord), ddof = 1 (numpy.cov over replicates)."""
+    L = _L()
+    _check_f64_cuda(vals, "vals")
+    v = vals.contiguous()
+    n_ord, nrep, nval = v.shape
+    out = torch.empty((nval, n_ord, n_ord), dtype=F64, device="cuda")
+    check(L.txm_cov_over_rep(_ptr(v), n_ord, nrep, nval, _ptr(out), _stream()), "txm_cov_over_rep")
+    return out

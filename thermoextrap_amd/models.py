@@ -149,7 +149,7 @@ class Derivatives(_Params):
         return self._tables[key]
 
     def derivs(self, data=None, order=None, args=None, minus_log=False, order_dim="order", concat_kws=None,
-               norm=False):
+               norm=False, _device=False):
         """Derivatives for orders ``range(order + 1)`` as one array with leading
         ``order_dim`` (or a list when ``order_dim is None``)."""
         if data is None:
@@ -185,6 +185,8 @@ class Derivatives(_Params):
             fac = torch.tensor([1.0 / math.factorial(i) for i in range(order + 1)], dtype=torch.float64,
                                device="cuda")
             vals = vals * fac[:, None, None]
+        if _device:
+            return vals, src
         host = vals.cpu().numpy().reshape(order + 1, *src.out_shape)
         if order_dim is None:
             outs = []
