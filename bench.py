@@ -78,7 +78,7 @@ def cpu_baseline(C, order, nrep_full, seconds, ncores):
     from oracle import oracle as orc
 
     rng = np.random.default_rng(0)
-    nrep = 16
+    nrep = 32
     # calibrate on a small run, then size N for ~`seconds`
     def run(N):
         u = rng.normal(174.85, 5.31, N)
@@ -89,7 +89,7 @@ def cpu_baseline(C, order, nrep_full, seconds, ncores):
         return time.perf_counter() - t0
 
     t_small = run(20000)
-    N = int(min(2_000_000, max(20000, 20000 * seconds / max(t_small, 1e-3))))
+    N = int(min(8_000_000, max(20000, 20000 * seconds / max(t_small, 1e-3))))
     t = run(N)
     # samples/s at nrep_full replicates: work is linear in N * nrep
     value = N * (nrep / nrep_full) / t
