@@ -217,6 +217,19 @@ int txm_eval_poly(const txm_poly_table *table_host, const double *const *srcs, i
 int txm_cov_over_rep(const double *vals, int32_t n_ord, int64_t nrep, int64_t nval, double *cov,
                      txm_stream stream);
 
+/* ---- (f-4) PerturbModel.predict: exponential reweighting ------------------- */
+/* out[a][c] = sum_i x[i][c] e^{-dalpha[a] (u_i - uref[a])} / sum_i e^{-dalpha[a] (u_i - uref[a])}
+ * for n_alpha perturbations in ONE pass over the samples; uref[a] is the u extreme that
+ * makes the largest exponent 0 (min u for dalpha > 0, max u for dalpha < 0), computed by
+ * the library.   replaces PerturbModel.predict (reference models.py:1019-1039:
+ * exp(dalpha_uv - max) weights, xr.dot / mean).  x row-major (ldx_c == 1); freq (nullable,
+ * [nrep][N] int64) adds bootstrap weights -> out [nrep][n_alpha][C]; n_alpha <= 8.
+ * dalpha_host: host array.  ws: txm_perturb_ws_bytes. */
+size_t txm_perturb_ws_bytes(int64_t N, int64_t C, int32_t n_alpha, int64_t nrep);
+int txm_perturb(const double *x, int64_t ldx_s, const double *u, int64_t N, int64_t C,
+                const double *dalpha_host, int32_t n_alpha, const int64_t *freq, int64_t nrep,
+                double *out, void *ws, size_t ws_bytes, txm_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

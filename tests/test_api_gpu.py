@@ -525,3 +525,39 @@ def test_input_gp_from_state(fixture, xtrap, log_scale):
     np.testing.assert_allclose(y_data, derivs, rtol=1e-12)
     want = np.array([np.cov(res[..., k]) for k in range(res.shape[-1])])
     np.testing.assert_allclose(cov, want, rtol=1e-9, atol=1e-18)
+
+
+# ---------------------------------------------------------------------------
+# PerturbModel (reference models.py:1019-1039, tests/test_beta.py:154-162)
+# ---------------------------------------------------------------------------
+def _perturb_numpy(x, u, beta0, betas):
+    out = []
+    for b in np.atleast_1d(betas):
+        e = -(b - beta0) * u
+        w = np.exp(e - e.max())
+        out.append((w[:, None] * x.reshape(len(u), -1)).sum(0) / w.sum())
+    return np.array(out)
+
+
+def test_perturbmodel(fixture, xtrap, kat, idealgas_data):
+    from thermoextrap_amd.xrlite import DataArray
+
+    beta0, betas = 0.5, [0.3, 0.7]
+    xpm = xtrap.beta.factory_perturbmodel(beta0, uv=fixture.u, xv=fixture.x)
+    got = xpm.predict(betas)
+    assert got.dims == ("beta", "val")
+    np.testing.assert_allclose(got.values, _perturb_numpy(fixture.legacy["x"], fixture.legacy["u"], beta0, betas), rtol=1e-12)
+    # more alphas than one pass holds, and a scalar alpha
+    many = np.linspace(0.1, 0.9, 11)
+    np.testing.assert_allclose(xpm.predict(many).values, _perturb_numpy(fixture.legacy["x"], fixture.legacy["u"], beta0, many), rtol=1e-12)
+    assert xpm.predict(0.3).dims == ("val",)
+    # bootstrap
+    idx = np.random.default_rng(0).choice(100, (4, 100))
+    r = xpm.resample(sampler={"indices": idx}).predict(betas)
+    assert r.dims == ("beta", "rep", "val")
+    for k in range(4):
+        np.testing.assert_allclose(r.values[:, k], _perturb_numpy(fixture.legacy["x"][idx[k]], fixture.legacy["u"][idx[k]], beta0, betas), rtol=1e-11)
+    # the reference's notebook: Temperature_Extrap_Case1.ipynb cell 10, PerturbModel.predict(0.1) = 0.199
+    x, u = idealgas_data
+    pm = xtrap.beta.factory_perturbmodel(5.6, uv=DataArray(u, "rec"), xv=DataArray(x, "rec"))
+    assert abs(float(pm.predict(0.1).values) - kat["case1"]["perturb_beta0p1"]) < 6e-4

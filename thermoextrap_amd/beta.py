@@ -19,9 +19,9 @@ from __future__ import annotations
 from functools import lru_cache
 
 from . import symbolic as S
-from .models import Derivatives, ExtrapModel, SymDerivBase
+from .models import Derivatives, ExtrapModel, PerturbModel, SymDerivBase
 
-__all__ = ["SymDerivBeta", "factory_derivatives", "factory_extrapmodel"]
+__all__ = ["SymDerivBeta", "factory_derivatives", "factory_extrapmodel", "factory_perturbmodel"]
 
 
 class SymDerivBeta(SymDerivBase):
@@ -149,3 +149,11 @@ def factory_extrapmodel(beta, data, *, name="x_ave", n=None, d=None, xalpha=None
         derivatives = factory_derivatives(name=name, n=n, d=d, xalpha=xalpha, central=central, post_func=post_func,
                                           **(derivatives_kws or {}))
     return ExtrapModel(alpha0=beta, data=data, derivatives=derivatives, order=order, alpha_name=alpha_name)
+
+
+def factory_perturbmodel(beta, uv, xv, alpha_name="beta", **kws):
+    """PerturbModel for a beta expansion (reference beta.py:669-696)."""
+    from .data import DataValues
+
+    data = DataValues.from_vals(xv=xv, uv=uv, order=0, **kws)
+    return PerturbModel(alpha0=beta, data=data, alpha_name=alpha_name)

@@ -291,3 +291,39 @@ def cov_over_rep(vals: torch.Tensor) -> torch.Tensor:
     out = torch.empty((nval, n_ord, n_ord), dtype=F64, device="cuda")
     check(L.txm_cov_over_rep(_ptr(v), n_ord, nrep, nval, _ptr(out), _stream()), "txm_cov_over_rep")
     return out
+
+
+def perturb(x: torch.Tensor, u: torch.Tensor, dalphas, freq: torch.Tensor | None = None) -> torch.Tensor:
+    """Exponentially reweighted averages for each dalpha: (n_alpha, C), or
+    (nrep, n_alpha, C) with bootstrap counts ``freq`` (nrep, N).  x: (N, C) row-major or (N,)."""
+    L = _L()
+    _check_f64_cuda(x, "x")
+    _check_f64_cuda(u, "u")
+    squeeze = x.dim() == 1
+    x2 = x.unsqueeze(1) if squeeze else x
+    if x2.stride(1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < x2.shape[1]):
+        x2 = x2.contiguous()
+    N, C = x2.shape
+    u = u.contiguous()
+    da = np.atleast_1d(np.asarray(dalphas, dtype=np.float64))
+    nrep = 1
+    if freq is not None:
+        freq = freq.to(device="cuda", dtype=torch.int64).contiguous()
+        nrep = freq.shape[0]
+    outs = []
+    for a0 in range(0, len(da), 8):  # 8 perturbations per pass over the samples
+        chunk = np.ascontiguousarray(da[a0 : a0 + 8])
+        na = len(chunk)
+        out = torch.empty((nrep, na, C), dtype=F64, device="cuda")
+        ws = workspace(L.txm_perturb_ws_bytes(N, C, na, nrep))
+        check(
+            L.txm_perturb(_ptr(x2), max(x2.stride(0), C) if N > 1 else C, _ptr(u), N, C,
+                          chunk.ctypes.data_as(ct.POINTER(ct.c_double)), na, _ptr(freq), nrep, _ptr(out), _ptr(ws),
+                          ws.numel(), _stream()),
+            "txm_perturb",
+        )
+        outs.append(out)
+    res = torch.cat(outs, dim=1)
+    if freq is None:
+        res = res[0]
+    return res[..., 0] if squeeze else res

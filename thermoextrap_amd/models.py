@@ -26,7 +26,7 @@ from .data import AbstractData, _Params, xrwrap_alpha
 from .moments import IndexSampler
 from .xrlite import DataArray, concat, is_labelled
 
-__all__ = ["Derivatives", "ExtrapModel", "StateCollection", "SymDerivBase", "taylor_series_norm"]
+__all__ = ["Derivatives", "ExtrapModel", "PerturbModel", "StateCollection", "SymDerivBase", "taylor_series_norm"]
 
 
 class SymDerivBase(S.DerivSeries):
@@ -351,3 +351,66 @@ class StateCollection(_Params):
     @property
     def alpha0(self):
         return [m.alpha0 for m in self]
+
+
+class PerturbModel(_Params):
+    """Exponential reweighting to another alpha (reference models.py:1009-1047):
+
+        <x>(alpha) = sum_i x_i e^{-(alpha-alpha0) u_i} / sum_i e^{-(alpha-alpha0) u_i}
+
+    evaluated for all requested alphas in one pass over the samples
+    (txm_perturb).  ``data`` must be a values-holding object (``DataValues``)."""
+
+    _fields = ("alpha0", "data", "alpha_name")
+
+    def __init__(self, alpha0, data, alpha_name="alpha"):
+        if not isinstance(data, AbstractData):
+            raise TypeError("data must be a data object")
+        self.alpha0 = float(alpha0)
+        self.data = data
+        self.alpha_name = "alpha" if alpha_name is None else alpha_name
+
+    def predict(self, alpha, alpha_name=None):
+        from .moments import _dev_and_dims
+
+        if alpha_name is None:
+            alpha_name = self.alpha_name
+        alpha = xrwrap_alpha(alpha, name=alpha_name)
+        dalpha = np.atleast_1d(np.asarray(alpha.values, dtype=float) - self.alpha0)
+        data = self.data
+        rec = data.rec_dim
+        res = getattr(data, "_resampled", None)
+        if res is not None:
+            buv, bxv, sampler, rep_dim = res
+        else:
+            buv, bxv, sampler, rep_dim = data._uv if hasattr(data, "_uv") else data.uv, \
+                data._xv if hasattr(data, "_xv") else data.xv, None, None
+        ut, udims = _dev_and_dims(buv)
+        xt, xdims = _dev_and_dims(bxv)
+        if udims != (rec,):
+            raise NotImplementedError("uv must be 1-D along the record dim")
+        others = [d for d in xdims if d != rec]
+        x2 = xt.movedim(xdims.index(rec), 0)
+        cshape = list(x2.shape[1:])
+        x2 = x2.reshape(x2.shape[0], -1) if x2.dim() > 1 else x2
+        freq = sampler.freq_device() if sampler is not None else None
+        out = engine.perturb(x2, ut, dalpha, freq=freq)  # (na, C) | (nrep, na, C) | 1-D x: (na,) | (nrep, na)
+        vals = out.cpu().numpy()
+        if sampler is not None:
+            vals = np.moveaxis(vals, 0, 1)  # (na, nrep, ...)
+            vals = vals.reshape(len(dalpha), sampler.nrep, *cshape)
+            dims = [alpha_name, rep_dim, *others]
+        else:
+            vals = vals.reshape(len(dalpha), *cshape)
+            dims = [alpha_name, *others]
+        if alpha.ndim == 0:
+            vals, dims = vals[0], dims[1:]
+            return DataArray(vals, dims, coords={alpha_name: alpha.values})
+        return DataArray(vals, dims, coords={alpha_name: alpha.values})
+
+    def __call__(self, *args, **kwargs):
+        return self.predict(*args, **kwargs)
+
+    def resample(self, sampler, **kws):
+        return type(self)(alpha0=self.alpha0, data=self.data.resample(sampler=sampler, **kws),
+                          alpha_name=self.alpha_name)
