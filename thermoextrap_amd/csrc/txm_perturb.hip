@@ -80,6 +80,11 @@ __global__ __launch_bounds__(PB_BLOCK) void perturb_kernel(const double *__restr
     for (int v = 0; v < VEC; ++v) num[a][v] = 0.0;
   }
   const int64_t stride = (int64_t)gridDim.x * ROWS;
+  // lanes of this column chunk that own real columns (block-uniform): the exp-sharing
+  // path needs lanes 0..NA-1 of every row group to be active
+  const int64_t cols_left = C - (int64_t)blockIdx.y * (LPR * VEC);
+  const int64_t nvalid = (cols_left + VEC - 1) / VEC;
+  const bool share = (LPR >= NA) && (LPR <= 64) && (NA > 1) && (nvalid >= NA);
   if (col_ok) {
     for (int64_t i = (int64_t)blockIdx.x * ROWS + rib; i < N; i += stride) {
       double xv[VEC];
@@ -93,12 +98,37 @@ __global__ __launch_bounds__(PB_BLOCK) void perturb_kernel(const double *__restr
       const double ui = u[i];
       double fw = 1.0;
       if constexpr (FREQ) fw = (double)freq[rep * N + i];
+      if (share) {
+        // exp() is ~25 vector instructions per wave whatever the number of active lanes, and
+        // the LPR lanes of a row would all compute the same NA values.  Instead lane `lir`
+        // evaluates alpha number lir (one exp sequence covers all alphas of the row) and the
+        // row's lanes fetch the NA weights with cross-lane reads.
+        const int a_mine = lir < NA ? lir : 0;
+        double da_mine = pa.da[0], ur_mine = uref[0];
 #pragma unroll
-      for (int a = 0; a < NA; ++a) {
-        const double w = fw * exp(-pa.da[a] * (ui - uref[a]));
-        den[a] += w;
+        for (int a = 1; a < NA; ++a)
+          if (a_mine == a) {
+            da_mine = pa.da[a];
+            ur_mine = uref[a];
+          }
+        const double w_mine = fw * exp(-da_mine * (ui - ur_mine));
+        const int lane = tid & 63;
+        const int row_lane0 = lane & ~(LPR - 1);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) num[a][v] = fma(w, xv[v], num[a][v]);
+        for (int a = 0; a < NA; ++a) {
+          const double w = __shfl(w_mine, row_lane0 + a);
+          den[a] += w;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) num[a][v] = fma(w, xv[v], num[a][v]);
+        }
+      } else {
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+          const double w = fw * exp(-pa.da[a] * (ui - uref[a]));
+          den[a] += w;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) num[a][v] = fma(w, xv[v], num[a][v]);
+        }
       }
     }
   }
