@@ -154,3 +154,66 @@ def predict(derivs, alpha0, alphas, order=None):
     for k in range(order + 1):
         out = out + np.multiply.outer(d**k, derivs[k]) / math.factorial(k)
     return out
+
+
+def weighted_predict(derivs_pair, alpha0_pair, alphas, order=None, m=20):
+    """Minkowski-weighted blend of two Taylor series (reference legacy/interp.py:71-126,
+    models.py:726-728, 835-858): w_s = 1 - d_s^m / (d_0^m + d_1^m), out = sum w_s p_s / sum w_s."""
+    alphas = np.atleast_1d(np.asarray(alphas, dtype=float))
+    p = [predict(derivs_pair[s], alpha0_pair[s], alphas, order) for s in range(2)]
+    d = [np.abs(alphas - alpha0_pair[s]) ** m for s in range(2)]
+    w = [1.0 - d[s] / (d[0] + d[1]) for s in range(2)]
+    shape = (-1,) + (1,) * (p[0].ndim - 1)
+    return (p[0] * w[0].reshape(shape) + p[1] * w[1].reshape(shape)) / (w[0] + w[1]).reshape(shape)
+
+
+def interp_coefs(derivs_states, alpha0_states):
+    """Hermite interpolation polynomial through value + derivatives at each state
+    (reference legacy/interp.py:157-235, models.py:861-925): coefficients c_p with
+    sum_p c_p p!/(p-j)! a_s^(p-j) = derivs[s][j].  Solved EXACTLY in rational
+    arithmetic on the given doubles (the reference inverts the matrix in float64;
+    this is the checker, so it does not share that conditioning)."""
+    from fractions import Fraction
+
+    derivs_states = [np.asarray(d, dtype=float) for d in derivs_states]
+    nord = derivs_states[0].shape[0]
+    n = len(derivs_states) * nord
+    tail = derivs_states[0].shape[1:]
+    rhs = np.concatenate([d.reshape(nord, -1) for d in derivs_states], axis=0)
+    ncol = rhs.shape[1]
+    A = []
+    for a0 in alpha0_states:
+        fa = Fraction(float(a0))
+        for j in range(nord):
+            A.append([Fraction(math.perm(p, j)) * fa ** (p - j) if p >= j else Fraction(0) for p in range(n)])
+    B = [[Fraction(float(v)) for v in row] for row in rhs]
+    for c in range(n):                       # Gauss-Jordan, exact
+        piv = next(r for r in range(c, n) if A[r][c] != 0)
+        A[c], A[piv] = A[piv], A[c]
+        B[c], B[piv] = B[piv], B[c]
+        inv = 1 / A[c][c]
+        A[c] = [v * inv for v in A[c]]
+        B[c] = [v * inv for v in B[c]]
+        for r in range(n):
+            if r != c and A[r][c] != 0:
+                f = A[r][c]
+                A[r] = [x - f * y for x, y in zip(A[r], A[c])]
+                B[r] = [x - f * y for x, y in zip(B[r], B[c])]
+    out = np.array([[float(v) for v in row] for row in B]).reshape((n, *tail))
+    exact = [[v for v in row] for row in B]
+    return out, exact
+
+
+def interp_predict(derivs_states, alpha0_states, alphas):
+    """sum_p c_p alpha^p with the exact coefficients, rounded once at the end."""
+    from fractions import Fraction
+
+    _, exact = interp_coefs(derivs_states, alpha0_states)
+    tail = np.asarray(derivs_states[0]).shape[1:]
+    alphas = np.atleast_1d(np.asarray(alphas, dtype=float))
+    out = np.empty((len(alphas), len(exact[0])))
+    for i, a in enumerate(alphas):
+        fa = Fraction(float(a))
+        for c in range(len(exact[0])):
+            out[i, c] = float(sum(exact[p][c] * fa**p for p in range(len(exact))))
+    return out.reshape((len(alphas), *tail))

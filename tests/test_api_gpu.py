@@ -561,3 +561,155 @@ def test_perturbmodel(fixture, xtrap, kat, idealgas_data):
     x, u = idealgas_data
     pm = xtrap.beta.factory_perturbmodel(5.6, uv=DataArray(u, "rec"), xv=DataArray(x, "rec"))
     assert abs(float(pm.predict(0.1).values) - kat["case1"]["perturb_beta0p1"]) < 6e-4
+
+
+# ---------------------------------------------------------------------------
+# tests/test_beta.py:165-452 -- weighted / interpolation models
+# ---------------------------------------------------------------------------
+def _rand_states(fixture, xtrap, beta0, seed=17):
+    from thermoextrap_amd.data import xrwrap_uv, xrwrap_xv
+
+    rng = np.random.default_rng(seed)
+    out = []
+    for b in beta0:
+        xv = xrwrap_xv(rng.random(fixture.x.shape))
+        uv = xrwrap_uv(rng.random(fixture.u.shape))
+        out.append(xtrap.beta.factory_extrapmodel(
+            beta=b, data=xtrap.factory_data_values(xv=xv, uv=uv, central=False, order=fixture.order)))
+    return out
+
+
+def _variants(fixture, xtrap, xems_r):
+    xems_c = [xtrap.beta.factory_extrapmodel(beta=m.alpha0, data=xtrap.factory_data_values(
+        order=fixture.order, uv=m.data.uv, xv=m.data.xv, central=True)) for m in xems_r]
+    xems_x = [xtrap.beta.factory_extrapmodel(beta=m.alpha0, data=xtrap.DataCentralMomentsVals.from_vals(
+        order=fixture.order, uv=m.data.uv, xv=m.data.xv, central=True)) for m in xems_r]
+    return xems_c, xems_x
+
+
+def test_extrapmodel_weighted_vs_legacy(fixture, xtrap):
+    """test_beta.py:165-236: legacy ExtrapWeightedModel = Minkowski blend (oracle restatement of
+    legacy/interp.py:71-126) of the two legacy derivative sets in the golden file."""
+    from oracle import derivs_oracle as D
+
+    beta0, betas = [0.05, 0.5], [0.3, 0.4]
+    want = D.weighted_predict([fixture.legacy["derivs"], fixture.legacy["derivs_b"]], beta0, betas, order=3)
+    mk = xtrap.beta.factory_extrapmodel
+    datas_b = [
+        xtrap.factory_data_values(uv=fixture.ub, xv=fixture.xb, order=fixture.order, central=False),
+        xtrap.factory_data_values(uv=fixture.ub, xv=fixture.xb, order=fixture.order, central=True),
+        xtrap.DataCentralMoments.from_vals(uv=fixture.ub, xv=fixture.xb, order=fixture.order, central=True),
+    ]
+    first = None
+    for d0, d1 in zip([fixture.rdata, fixture.cdata, fixture.xdata], datas_b):
+        xemw = xtrap.ExtrapWeightedModel([mk(beta=beta0[0], data=d0), mk(beta=beta0[1], data=d1)])
+        got = xemw.predict(betas, order=3)
+        assert got.dims == ("beta", "val")
+        np.testing.assert_allclose(got.values, want, rtol=1e-8)
+        if first is None:
+            first = got
+        fixture.xr_test(first, got)
+    # scalar alpha, cumsum and the bounded check
+    one = xemw.predict(0.3, order=3)
+    np.testing.assert_allclose(one.values, want[0], rtol=1e-8)
+    cs = xemw.predict(betas, order=3, cumsum=True)
+    np.testing.assert_allclose(cs.isel(order=-1).values, want, rtol=1e-8)
+    np.testing.assert_allclose(cs.isel(order=1).values,
+                               D.weighted_predict([fixture.legacy["derivs"], fixture.legacy["derivs_b"]], beta0, betas, order=1),
+                               rtol=1e-8)
+    with pytest.raises(ValueError):
+        xemw.predict([0.3, 0.6], bounded=True)
+    xemw.predict([0.05, 0.5], bounded=True)
+
+
+def test_extrapmodel_weighted_multi(fixture, xtrap):
+    beta0, betas = [0.05, 0.2, 1.0], [0.3, 0.4, 0.6, 0.7]
+    xems_r = _rand_states(fixture, xtrap, beta0)
+    xems_c, xems_x = _variants(fixture, xtrap, xems_r)
+    xemw_a = xtrap.ExtrapWeightedModel([xems_r[0], xems_r[1]])
+    xemw_b = xtrap.ExtrapWeightedModel([xems_r[1], xems_r[2]])
+    xemw_r = xtrap.ExtrapWeightedModel(xems_r)
+    fixture.xr_test(xemw_a.predict([0.2, 0.4]), xemw_r.predict([0.2, 0.4], method="nearest"))
+    fixture.xr_test(xemw_b.predict([0.4, 0.8]), xemw_r.predict([0.4, 0.8], method="between"))
+    with pytest.raises(ValueError):
+        xemw_r.predict([0.4], method="closest")
+    xemw_c, xemw_x = xtrap.ExtrapWeightedModel(xems_c), xtrap.ExtrapWeightedModel(xems_x)
+    fixture.xr_test(xemw_r.predict(betas, order=3), xemw_c.predict(betas, order=3))
+    fixture.xr_test(xemw_r.predict(betas, order=3), xemw_x.predict(betas, order=3))
+    nrep = 20
+    ndat = fixture.u.shape[0]
+    sampler = [xtrap.moments.factory_sampler(ndat=ndat, nrep=nrep, rng=np.random.default_rng(5 + i)) for i in range(3)]
+    a = xemw_c.resample(sampler=sampler).predict(betas)
+    b = xemw_x.resample(sampler=sampler).predict(betas)
+    assert set(a.dims) == {"beta", "rep", "val"} and a.sizes["rep"] == nrep
+    fixture.xr_test(a, b)
+
+
+def test_interpmodel(fixture, xtrap):
+    """test_beta.py:312-399.  The checker solves the Hermite system exactly (oracle/derivs_oracle.py)
+    from derivatives computed by the oracle's own jet recursion on the same samples."""
+    from oracle import derivs_oracle as D
+
+    beta0, betas = [0.05, 0.5, 1.0], [0.3, 0.4, 0.6, 0.7]
+    xems_r = _rand_states(fixture, xtrap, beta0, seed=23)
+    xems_c, xems_x = _variants(fixture, xtrap, xems_r)
+    xemi_r, xemi_c, xemi_x = (xtrap.InterpModel(s) for s in (xems_r, xems_c, xems_x))
+    for order in (1, 3):
+        dsets = [D.derivs_x_ave(m.data.xv.values, m.data.uv.values, order) for m in xems_r]
+        want = D.interp_predict(dsets, beta0, betas)
+        got = xemi_c.predict(betas, order=order)
+        assert got.dims == ("beta", "val")
+        np.testing.assert_allclose(got.values, want, rtol=2e-7 if order == 3 else 1e-10)
+        wc, _ = D.interp_coefs(dsets, beta0)
+        c = xemi_c.coefs(order=order)
+        assert c.dims == ("porder", "val") and c.shape[0] == 3 * (order + 1)
+        np.testing.assert_allclose(c.values, wc, rtol=1e-5 if order == 3 else 1e-9, atol=1e-6 * np.abs(wc).max())
+    fixture.xr_test(xemi_r.predict(betas, order=3), xemi_c.predict(betas, order=3), rtol=1e-6)
+    fixture.xr_test(xemi_r.predict(betas, order=3), xemi_x.predict(betas, order=3), rtol=1e-6)
+    # the polynomial reproduces each state's own value and slope
+    p0 = xemi_c.predict(beta0, order=1)
+    for i, m in enumerate(xems_c):
+        np.testing.assert_allclose(p0.values[i], m.derivs(order=0).values[0], rtol=1e-9)
+    nrep, ndat = 20, fixture.u.shape[0]
+    samplers = [xtrap.moments.factory_sampler(ndat=ndat, nrep=nrep, rng=np.random.default_rng(9 + i)) for i in range(3)]
+    a = xemi_c.resample(sampler=samplers).predict(betas, order=2)
+    b = xemi_x.resample(sampler=samplers).predict(betas, order=2)
+    assert set(a.dims) == {"beta", "rep", "val"}
+    fixture.xr_test(a, b, rtol=1e-6)
+
+
+def test_interpmodelpiecewise(fixture, xtrap):
+    beta0 = [0.05, 0.2, 1.0]
+    xems_r = _rand_states(fixture, xtrap, beta0, seed=29)
+    a = xtrap.InterpModel([xems_r[0], xems_r[1]])
+    b = xtrap.InterpModel([xems_r[1], xems_r[2]])
+    pw = xtrap.InterpModelPiecewise(xems_r)
+    fixture.xr_test(a.predict([0.2, 0.4]), pw.predict([0.2, 0.4], method="nearest"))
+    fixture.xr_test(b.predict([0.4, 0.8]), pw.predict([0.4, 0.8], method="between"))
+    # outside the range the end pairs are used; scalar alpha keeps the alpha dim off
+    fixture.xr_test(a.predict(0.01), pw.predict(0.01))
+    fixture.xr_test(b.predict(1.5), pw.predict(1.5))
+    assert pw.predict(0.3).dims == ("val",)
+    assert pw.single_interpmodel(0, 1) is pw.single_interpmodel(0, 1)
+    with pytest.raises(ValueError):
+        pw.predict([0.01], bounded=True)
+    two = xtrap.InterpModelPiecewise(xems_r[:2])
+    fixture.xr_test(a.predict([0.1, 0.15]), two.predict([0.1, 0.15]))
+
+
+def test_interpmodel_polynomial(xtrap):
+    """test_beta.py:428-452: two points at -1, +1 with value/slope of x^(i+1) give back that monomial exactly."""
+    from thermoextrap_amd.xrlite import DataArray
+
+    xdat2 = DataArray(np.array([0.5, 1.5]), "rec")
+    for i in range(3):
+        xdat1 = xdat2 * ((-1.0) ** (i + 1))
+        udat1 = DataArray(np.array([-2.0, 2.0]), "rec") * (i + 1)
+        udat2 = DataArray(np.array([2.0, -2.0]), "rec") * (i + 1)
+        dat1 = xtrap.DataCentralMomentsVals.from_vals(order=1, xv=xdat1, uv=udat1, central=True)
+        dat2 = xtrap.DataCentralMomentsVals.from_vals(order=1, xv=xdat2, uv=udat2, central=True)
+        ex1 = xtrap.beta.factory_extrapmodel(-1.0, dat1, xalpha=False)
+        ex2 = xtrap.beta.factory_extrapmodel(1.0, dat2, xalpha=False)
+        want = np.zeros(4)
+        want[i + 1] = 1.0
+        np.testing.assert_array_equal(xtrap.InterpModel([ex1, ex2]).coefs().values, want)

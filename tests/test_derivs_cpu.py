@@ -223,3 +223,60 @@ def test_factory_argument_errors():
     with pytest.raises(ValueError):
         S.apply_post_func(S.x1(), "bogus")
     assert math.isclose(float(S.DerivSeries(S.x1())[1].terms[((("dxdu", 1, None), 1),)]), -1.0)
+
+
+# ---------------------------------------------------------------------------
+# multi-state models: checker restatements and the host-only selection logic
+# ---------------------------------------------------------------------------
+def test_oracle_weighted_and_interp_restatements():
+    from oracle import derivs_oracle as D
+
+    rng = np.random.default_rng(3)
+    ds = [rng.random((4, 5)) for _ in range(3)]
+    a0 = [0.05, 0.5, 1.0]
+    # at a reference state the Minkowski weight of the other state is 0
+    w = D.weighted_predict(ds[:2], a0[:2], a0[:2], order=3)
+    np.testing.assert_allclose(w[0], ds[0][0], rtol=1e-14)
+    np.testing.assert_allclose(w[1], ds[1][0], rtol=1e-14)
+    # midway both series count equally
+    mid = D.weighted_predict(ds[:2], a0[:2], [0.275], order=3)[0]
+    both = 0.5 * (D.predict(ds[0], a0[0], [0.275], 3)[0] + D.predict(ds[1], a0[1], [0.275], 3)[0])
+    np.testing.assert_allclose(mid, both, rtol=1e-13)
+    # the exact Hermite polynomial reproduces every value and derivative it was built from
+    c, _ = D.interp_coefs(ds, a0)
+    n = c.shape[0]
+    for s, a in enumerate(a0):
+        for j in range(4):
+            dj = sum(c[p] * math.perm(p, j) * a ** (p - j) for p in range(j, n))
+            np.testing.assert_allclose(dj, ds[s][j], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(D.interp_predict(ds, a0, a0), np.array([d[0] for d in ds]), rtol=1e-14)
+
+
+def test_piecewise_selection_matches_reference_rule():
+    """models.py:734-761 of the reference: np.digitize bracket with end clamping / two nearest."""
+    from thermoextrap_amd.models import InterpModel, PiecewiseMixin, StateCollection
+
+    class Stub:
+        order, alpha_name = 3, "beta"
+
+        def __init__(self, a):
+            self.alpha0 = a
+
+    class PW(StateCollection, PiecewiseMixin):
+        pass
+
+    pw = PW([Stub(0.05), Stub(0.2), Stub(1.0), Stub(2.5)])
+    for a in [-1.0, 0.05, 0.1, 0.2, 0.5, 1.0, 1.7, 2.5, 4.0]:
+        idx = np.digitize(a, pw.alpha0, right=False) - 1
+        idx = 0 if idx < 0 else (len(pw) - 2 if idx == len(pw) - 1 else idx)
+        assert pw._indices_between_alpha(a) == [idx, idx + 1]
+        assert pw._indices_nearest_alpha(a) == list(np.argsort(np.abs(np.array(pw.alpha0) - a))[:2])
+    with pytest.raises(ValueError):
+        pw._indices_alpha(0.3, "closest")
+    with pytest.raises(ValueError):
+        pw._check_alpha([0.1, 3.0], bounded=True)
+    pw._check_alpha([0.1, 3.0], bounded=False)
+    # Hermite matrix for states at -1, +1, order 1: inverse known in closed form
+    inv = InterpModel([Stub(-1.0), Stub(1.0)])._hermite_inverse(1)
+    want = np.array([[0.5, 0.25, 0.5, -0.25], [-0.75, -0.25, 0.75, -0.25], [0, -0.25, 0, 0.25], [0.25, 0.25, -0.25, 0.25]])
+    np.testing.assert_allclose(inv, want, atol=1e-15)

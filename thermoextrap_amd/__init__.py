@@ -19,6 +19,7 @@ _LAZY = {
     "DataValuesCentral": "data", "DataCallback": "data", "DataCallbackABC": "data", "DataSelector": "data",
     "factory_data_values": "data", "xrwrap_uv": "data", "xrwrap_xv": "data", "xrwrap_alpha": "data",
     "Derivatives": "models", "ExtrapModel": "models", "StateCollection": "models", "PerturbModel": "models",
+    "ExtrapWeightedModel": "models", "InterpModel": "models", "InterpModelPiecewise": "models",
     "DataArray": "xrlite",
 }
 _MODULES = {"distributed", "gpr_input", "beta", "data", "models", "moments", "idealgas", "symbolic", "engine", "xrlite", "volume", "volume_idealgas", "lnpi"}

@@ -26,7 +26,8 @@ from .data import AbstractData, _Params, xrwrap_alpha
 from .moments import IndexSampler
 from .xrlite import DataArray, concat, is_labelled
 
-__all__ = ["Derivatives", "ExtrapModel", "PerturbModel", "StateCollection", "SymDerivBase", "taylor_series_norm"]
+__all__ = ["Derivatives", "ExtrapModel", "ExtrapWeightedModel", "InterpModel", "InterpModelPiecewise", "PerturbModel",
+           "PiecewiseMixin", "StateCollection", "SymDerivBase", "taylor_series_norm", "xr_weights_minkowski"]
 
 
 class SymDerivBase(S.DerivSeries):
@@ -414,3 +415,156 @@ class PerturbModel(_Params):
     def resample(self, sampler, **kws):
         return type(self)(alpha0=self.alpha0, data=self.data.resample(sampler=sampler, **kws),
                           alpha_name=self.alpha_name)
+
+
+# ---------------------------------------------------------------------------
+# Multi-state models (reference models.py:710-1007).  Host algebra on top of
+# ExtrapModel.derivs / predict, which are where the device work happens.
+# ---------------------------------------------------------------------------
+def _alpha_seq(alpha):
+    try:
+        return list(iter(alpha))
+    except TypeError:
+        return [alpha]
+
+
+def xr_weights_minkowski(deltas, m=20, dim="state"):
+    """Minkowski-like weights ``1 - d^m / sum_dim d^m`` (reference models.py:726-728)."""
+    dm = deltas**m
+    return 1.0 - dm / dm.sum(dim)
+
+
+class PiecewiseMixin:
+    """Pick the two states that bracket (or are nearest to) an alpha
+    (reference models.py:731-761).  States must be in ascending ``alpha0`` order."""
+
+    def _check_alpha(self, alpha, bounded=False) -> None:
+        if not bounded:
+            return
+        lo, hi = self[0].alpha0, self[-1].alpha0
+        for a in _alpha_seq(alpha):
+            if a < lo or a > hi:
+                raise ValueError(f"{a} outside of bounds [{lo}, {hi}]")
+
+    def _indices_between_alpha(self, alpha):
+        i = int(np.searchsorted(np.asarray(self.alpha0), alpha, side="right")) - 1
+        i = min(max(i, 0), len(self) - 2)
+        return [i, i + 1]
+
+    def _indices_nearest_alpha(self, alpha):
+        dist = np.abs(np.asarray(self.alpha0) - alpha)
+        return [int(i) for i in np.argsort(dist)[:2]]
+
+    def _indices_alpha(self, alpha, method):
+        if method is None or method == "between":
+            return self._indices_between_alpha(alpha)
+        if method == "nearest":
+            return self._indices_nearest_alpha(alpha)
+        raise ValueError(f"unknown method {method}")
+
+    def _states_alpha(self, alpha, method):
+        return [self[i] for i in self._indices_alpha(alpha, method)]
+
+    def _per_alpha(self, alpha, alpha_name, one):
+        """Evaluate ``one(a)`` for each scalar alpha and join along ``alpha_name``."""
+        seq = [float(a) for a in _alpha_seq(alpha)]
+        outs = [one(a) for a in seq]
+        if np.ndim(alpha) == 0:
+            return outs[0]
+        return concat(outs, dim=DataArray(np.asarray(seq), alpha_name))
+
+
+class ExtrapWeightedModel(StateCollection, PiecewiseMixin):
+    """Two Taylor series, one from each side, blended with Minkowski weights on
+    the distance to each reference state (reference models.py:764-858)."""
+
+    def predict(self, alpha, order=None, order_dim="order", cumsum=False, minus_log=None, alpha_name=None,
+                method=None, bounded=False):
+        self._check_alpha(alpha, bounded)
+        if order is None:
+            order = self.order
+        if alpha_name is None:
+            alpha_name = self.alpha_name
+        if len(self) != 2:
+            if np.ndim(np.asarray(alpha)) > 0:
+                return self._per_alpha(alpha, alpha_name, lambda a: self.predict(
+                    a, order=order, order_dim=order_dim, cumsum=cumsum, minus_log=minus_log,
+                    alpha_name=alpha_name, method=method))
+            pair = self._states_alpha(alpha, method)
+        else:
+            pair = list(self.states)
+        alpha = xrwrap_alpha(alpha, name=alpha_name)
+        preds = [m.predict(alpha, order=order, order_dim=order_dim, cumsum=cumsum, minus_log=minus_log,
+                           alpha_name=alpha_name, dalpha_coords=None, alpha0_coords=False) for m in pair]
+        dist = concat([abs(alpha - m.alpha0) for m in pair], dim="state")
+        w = xr_weights_minkowski(dist, dim="state")
+        num = sum(p * w.isel(state=i) for i, p in enumerate(preds))
+        return num / w.sum("state")
+
+
+class InterpModel(StateCollection):
+    """One polynomial through the value and the first ``order`` derivatives at
+    every state (Hermite interpolation; reference models.py:861-946)."""
+
+    def _hermite_inverse(self, order):
+        key = ("hermite", order)
+        if key not in self._cache:
+            npoly = len(self) * (order + 1)
+            p = np.arange(npoly)
+            rows = []
+            for a0 in self.alpha0:
+                for j in range(order + 1):
+                    # d^j/da^j a^p = p!/(p-j)! a^(p-j), zero below the diagonal
+                    fall = np.array([math.perm(int(q), j) if q >= j else 0 for q in p], dtype=float)
+                    powr = np.where(p >= j, np.power(float(a0), np.maximum(p - j, 0)), 0.0)
+                    rows.append(fall * powr)
+            self._cache[key] = np.linalg.inv(np.array(rows))
+        return self._cache[key]
+
+    def coefs(self, order=None, order_dim="porder", minus_log=None):
+        if order is None:
+            order = self.order
+        inv = self._hermite_inverse(order)                       # [porder, state*(order+1)]
+        ds = [m.derivs(order, norm=False, minus_log=minus_log, order_dim="order") for m in self.states]
+        first = ds[0]
+        rest = [d for d in first.dims if d != "order"]
+        stacked = np.concatenate([d.transpose("order", *rest).values for d in ds], axis=0)
+        vals = np.tensordot(inv, stacked, axes=(1, 0))
+        out = DataArray(vals, (order_dim, *rest), None, first.name)
+        out._inherit({k: v for k, v in first._coords.items() if "order" not in v[0]})
+        return out
+
+    def predict(self, alpha, order=None, order_dim="porder", minus_log=None, alpha_name=None):
+        if order is None:
+            order = self.order
+        if alpha_name is None:
+            alpha_name = self.alpha_name
+        coefs = self.coefs(order=order, order_dim=order_dim, minus_log=minus_log)
+        alpha = xrwrap_alpha(alpha, name=alpha_name)
+        p = DataArray(np.arange(coefs.sizes[order_dim]), order_dim)
+        return ((alpha**p) * coefs).sum(order_dim)
+
+
+class InterpModelPiecewise(StateCollection, PiecewiseMixin):
+    """Two-state Hermite interpolation chosen per alpha (reference models.py:949-1006)."""
+
+    def single_interpmodel(self, *state_indices):
+        key = ("pair", tuple(int(i) for i in state_indices))
+        if key not in self._cache:
+            i, j = key[1]
+            self._cache[key] = InterpModel([self[i], self[j]])
+        return self._cache[key]
+
+    def predict(self, alpha, order=None, order_dim="porder", minus_log=None, alpha_name=None, method=None,
+                bounded=False):
+        self._check_alpha(alpha, bounded)
+        if alpha_name is None:
+            alpha_name = self.alpha_name
+        kws = dict(order=order, order_dim=order_dim, minus_log=minus_log, alpha_name=alpha_name)
+        if len(self) == 2:
+            return self.single_interpmodel(0, 1).predict(alpha, **kws)
+        seq = [float(a) for a in _alpha_seq(alpha)]
+        outs = [self.single_interpmodel(*self._indices_alpha(a, method)).predict(a, **kws) for a in seq]
+        if len(outs) == 1:
+            return outs[0]
+        return concat(outs, dim=DataArray(np.asarray(seq), alpha_name))
