@@ -713,3 +713,38 @@ def test_interpmodel_polynomial(xtrap):
         want = np.zeros(4)
         want[i + 1] = 1.0
         np.testing.assert_array_equal(xtrap.InterpModel([ex1, ex2]).coefs().values, want)
+
+
+# ---------------------------------------------------------------------------
+# tests/test_stack.py -- GP-regression input out of resampled state collections
+# ---------------------------------------------------------------------------
+def test_stack_states(xtrap):
+    from thermoextrap_amd import stack
+    from thermoextrap_amd.xrlite import DataArray, assert_allclose, concat
+
+    shape, dims = (30, 2, 4), ["rec", "pair", "position"]
+    rng = np.random.default_rng(1)
+    xems = []
+    for beta in [0.1, 10.0]:
+        x = DataArray(rng.random(shape), dims, coords={"position": np.linspace(0, 2, shape[-1])})
+        u = DataArray(rng.random(shape[0]), dims[0])
+        data = xtrap.DataCentralMomentsVals.from_vals(x, u, order=3, central=True)
+        xems.append(xtrap.beta.factory_extrapmodel(beta, data))
+    states = xtrap.StateCollection(xems).resample(sampler={"nrep": 5})
+    a = concat([s.derivs(norm=False) for s in states], dim=DataArray(np.array(states.alpha0), states.alpha_name))
+    b = stack.states_derivs_concat(states)
+    assert b.dims[0] == "beta" and set(b.dims) == {"beta", "order", "rep", "pair", "position"}
+    assert_allclose(a, b)
+    gp = stack.GPRData(states.states)
+    xd, yd = gp.array_data()
+    assert xd.shape == (2 * 4, 2) and len(yd) == 2 * 4 and yd[0].shape == (8, 2)
+    mv = stack.to_mean_var(b, "rep").transpose("beta", "order", "pair", "position", "stats")
+    np.testing.assert_allclose(np.stack(yd, axis=1), mv.values.reshape(8, 8, 2))
+    np.testing.assert_allclose(xd[:, 0], np.repeat([0.1, 10.0], 4))
+    np.testing.assert_allclose(xd[:, 1], np.tile(np.arange(4), 2))
+    xd2, yd2 = gp.array_data(order=1)
+    assert xd2.shape == (4, 2) and yd2[0].shape == (4, 2)
+    np.testing.assert_allclose(yd2[3], yd[3][[0, 1, 4, 5]])
+    # mean of replicate derivatives sits near the un-resampled derivative
+    d0 = xems[0].derivs(norm=False)
+    assert np.abs(mv.isel(beta=0, stats=0).values - d0.transpose("order", "pair", "position").values).max() < 1.0

@@ -22,7 +22,7 @@ _LAZY = {
     "ExtrapWeightedModel": "models", "InterpModel": "models", "InterpModelPiecewise": "models",
     "DataArray": "xrlite",
 }
-_MODULES = {"distributed", "gpr_input", "beta", "data", "models", "moments", "idealgas", "symbolic", "engine", "xrlite", "volume", "volume_idealgas", "lnpi"}
+_MODULES = {"stack", "distributed", "gpr_input", "beta", "data", "models", "moments", "idealgas", "symbolic", "engine", "xrlite", "volume", "volume_idealgas", "lnpi"}
 
 
 def __getattr__(name):

@@ -139,6 +139,8 @@ class DataArray:
     def _new(self, values, dims, drop=()):
         out = DataArray(values, dims, None, self.name, self.attrs)
         out._inherit(self._coords, drop)
+        if hasattr(self, "_levels"):
+            out._levels = self._levels
         return out
 
     def _inherit(self, coords, drop=()):
@@ -211,6 +213,8 @@ class DataArray:
                 index_coords(d, sel, False)
         res = DataArray(out_vals, tuple(out_dims), None, self.name, self.attrs)
         res._inherit(new_coords)
+        if hasattr(self, "_levels"):
+            res._levels = self._levels
         return res
 
     def sel(self, indexers: Mapping | None = None, drop: bool = False, **kw):
@@ -281,6 +285,52 @@ class DataArray:
 
     def astype(self, dtype):
         return self._new(self.values.astype(dtype), self.dims)
+
+    # ---- stacking (the slice of MultiIndex behaviour stack.py needs) -------
+    def stack(self, dimensions: Mapping | None = None, **kw):
+        """Flatten groups of dims into new trailing dims; every flattened dim
+        leaves a level coordinate of its name on the new dim (positions when
+        it had no labels)."""
+        groups = dict(dimensions or {})
+        groups.update(kw)
+        out = self
+        for new, ds in groups.items():
+            ds = (ds,) if isinstance(ds, (str, bytes)) else tuple(ds)
+            if new in out.dims:
+                raise ValueError(f"{new!r} conflicts with existing {out.dims}")
+            keep = tuple(d for d in out.dims if d not in ds)
+            t = out.transpose(*keep, *ds)
+            sizes = [t.sizes[d] for d in ds]
+            vals = t.values.reshape(*[t.sizes[d] for d in keep], int(np.prod(sizes, dtype=np.int64)))
+            res = DataArray(vals, (*keep, new), None, out.name, out.attrs)
+            res._inherit({k: v for k, v in t._coords.items() if not set(v[0]) & set(ds)})
+            grids = np.meshgrid(*[t._coords[d][1] if d in t._coords and t._coords[d][0] == (d,) else np.arange(n)
+                                  for d, n in zip(ds, sizes)], indexing="ij")
+            for d, g in zip(ds, grids):
+                res._coords[d] = ((new,), g.reshape(-1))
+            res._levels = {**getattr(out, "_levels", {}), new: ds}
+            out = res
+        return out
+
+    @property
+    def indexes(self) -> dict:
+        """dim -> index; a stacked dim gives a ``LevelIndex`` of tuples."""
+        out = {}
+        levels = getattr(self, "_levels", {})
+        for d in self.dims:
+            if d in levels and all(n in self._coords for n in levels[d]):
+                out[d] = LevelIndex(levels[d], [self._coords[n][1] for n in levels[d]])
+            elif d in self._coords and self._coords[d][0] == (d,):
+                out[d] = self._coords[d][1]
+        return out
+
+    def groupby(self, dim):
+        """Iterate ``(position, slice)`` along ``dim`` (one group per element)."""
+        for i in range(self.sizes[dim]):
+            yield i, self.isel({dim: i})
+
+    def pipe(self, func, *args, **kwargs):
+        return func(self, *args, **kwargs)
 
     # ---- reductions -------------------------------------------------------
     def _reduce(self, fn, dim=None, **kw):
@@ -360,6 +410,24 @@ class DataArray:
                 return self._binary(b, lambda x, y: ufunc(x, y, **kwargs))
             return self._binary(a, lambda x, y: ufunc(x, y, **kwargs), True)
         return NotImplemented
+
+
+class LevelIndex:
+    """Names + per-level label arrays of a stacked dim; ``values`` are tuples."""
+
+    def __init__(self, names, arrays):
+        self.names = tuple(names)
+        self.arrays = [np.asarray(a) for a in arrays]
+
+    @property
+    def values(self):
+        return list(zip(*[a.tolist() for a in self.arrays]))
+
+    def __len__(self):
+        return len(self.arrays[0])
+
+    def __iter__(self):
+        return iter(self.values)
 
 
 def _expand(a: DataArray, dims) -> np.ndarray:
