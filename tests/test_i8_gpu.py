@@ -1,0 +1,106 @@
+"""The int8-sliced bootstrap kernel (txm_resample_i8.hip) against the FP64 kernel run on
+the explicit frequency table of the SAME sampler stream (whose bit-exactness against the
+CPU restatement oracle/philox_oracle.c is pinned in test_kernels_gpu.py), and against
+the oracle itself at small sizes.  TXM_I8=1 forces the int8 path, TXM_I8=0 the FP64 one.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng(txm):
+    from thermoextrap_amd import engine
+
+    return engine
+
+
+def data(N, C, seed, heavy=False):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    u = 174.85 + 5.31 * torch.randn(N, generator=g, dtype=torch.float64, device="cuda")
+    a = torch.linspace(-1.0, 1.0, C, dtype=torch.float64, device="cuda")
+    x = 3.0 + a[None, :] * 0.7 + (0.01 + 0.003 * a[None, :]) * u[:, None] \
+        + 0.4 * torch.randn(N, C, generator=g, dtype=torch.float64, device="cuda")
+    if heavy:  # outliers: one window sees values 1e4 x the spread
+        x[N // 3] += 4.0e3
+        u[N // 2] += 5.0e4
+    return x, u
+
+
+def scale(x, u, K):
+    sc = torch.empty((x.shape[1], 2, K), dtype=torch.float64, device="cuda")
+    for b in range(K):
+        sc[:, 0, b] = u.std() ** b
+        sc[:, 1, b] = x.std(dim=0) * u.std() ** b
+    return sc
+
+
+def err(a, b, sc):
+    return ((a - b).abs() / (b.abs() + sc)).max().item()
+
+
+@pytest.mark.parametrize("N,C,order,nrep,weighted", [
+    (1024, 32, 4, 64, False),       # exactly one full tile
+    (1500, 32, 4, 70, False),       # sliding partial last tile, ragged replicate group
+    (5000, 5, 4, 3, False),         # few columns, few replicates
+    (40000, 32, 4, 130, False),     # three windows, two chunks
+    (40000, 17, 3, 64, True),       # order 3 (u-row shares block 4), weights
+    (20000, 32, 2, 100, True),      # order 2 (no shared blocks)
+    (70001, 1, 4, 65, False),       # 1-D observable
+])
+def test_i8_matches_fp64_on_same_stream(eng, monkeypatch, N, C, order, nrep, weighted):
+    x, u = data(N, C, 5)
+    w = None
+    if weighted:
+        w = 0.25 + torch.rand(N, dtype=torch.float64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(9))
+    K = order + 1
+    s = eng.DeviceSampler(20261003 + N, nrep, N)
+    monkeypatch.setenv("TXM_I8", "1")
+    got = eng.resample_vals(x, u, order, sampler=s, w=w)
+    again = eng.resample_vals(x, u, order, sampler=s, w=w)
+    assert torch.equal(got, again)                       # deterministic
+    monkeypatch.setenv("TXM_I8", "0")
+    ref_fused = eng.resample_vals(x, u, order, sampler=s, w=w)
+    ref = eng.resample_vals(x, u, order, freq=s.freq(), w=w)
+    assert got.shape == (nrep, C, 2, K) and torch.isfinite(got).all()
+    sc = scale(x, u, K)[None]
+    assert err(ref_fused, ref, sc) < 5e-13
+    assert err(got, ref, sc) < 5e-13, err(got, ref, sc)
+    # replicate weight = sum of f * w, u-row identical across columns
+    assert torch.allclose(got[:, :, 0, 0], ref[:, :, 0, 0], rtol=1e-14, atol=0)
+    assert (got[:, :, 0, :] == got[:, :1, 0, :]).all()
+
+
+def test_i8_vs_oracle_truth(eng, monkeypatch, orc):
+    """Small case against the long-double two-pass oracle on the materialised frequencies."""
+    N, C, order, nrep = 3000, 6, 4, 5
+    x, u = data(N, C, 21)
+    s = eng.DeviceSampler(77, nrep, N)
+    monkeypatch.setenv("TXM_I8", "1")
+    got = eng.resample_vals(x, u, order, sampler=s).cpu().numpy()
+    f = s.freq().cpu().numpy()
+    xh, uh = x.cpu().numpy(), u.cpu().numpy()
+    for r in range(nrep):
+        truth = orc.truth_cov(xh, uh, order, w=f[r].astype(np.float64))
+        sc = scale(x, u, order + 1).cpu().numpy()
+        assert (np.abs(got[r] - truth) / (np.abs(truth) + sc)).max() < 1e-12
+
+
+def test_i8_outliers_and_pivot(eng, monkeypatch):
+    """Per-window scaling: one window holds values 1e4 x the spread of the rest; a far pivot."""
+    N, C, order, nrep = 50000, 32, 4, 64
+    x, u = data(N, C, 33, heavy=True)
+    s = eng.DeviceSampler(4242, nrep, N)
+    monkeypatch.setenv("TXM_I8", "0")
+    ref = eng.resample_vals(x, u, order, freq=s.freq())
+    monkeypatch.setenv("TXM_I8", "1")
+    got = eng.resample_vals(x, u, order, sampler=s)
+    sc = scale(x, u, order + 1)[None]
+    assert err(got, ref, sc) < 2e-12, err(got, ref, sc)
+    st = eng.reduce_vals(x, u, order)
+    piv = torch.cat([st[0, 0, 1:2] + 2.0 * u.std(), st[:, 1, 0] - 3.0 * x.std(dim=0)]).contiguous()
+    got2 = eng.resample_vals(x, u, order, sampler=s, pivot=piv)
+    assert err(got2, ref, sc) < 1e-8

@@ -14,8 +14,9 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libtxmom.so"
-SOURCES = ["txm_api.hip", "txm_reduce.hip", "txm_sampler.hip", "txm_small.hip", "txm_resample.hip", "txm_perturb.hip"]
-HEADERS = ["txm_common.h", "txm_pivot.h", "txm_sampler.h", "../../include/txmom.h"]
+SOURCES = ["txm_api.hip", "txm_reduce.hip", "txm_sampler.hip", "txm_small.hip", "txm_resample.hip", "txm_resample_i8.hip",
+           "txm_perturb.hip"]
+HEADERS = ["txm_common.h", "txm_pivot.h", "txm_sampler.h", "txm_resample_i8.h", "../../include/txmom.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed"]
 
 

@@ -24,8 +24,11 @@
 // explicit int64 freq table (parity mode).
 #include <type_traits>
 
+#include <stdlib.h>
+
 #include "txm_sampler.h"
 #include "txm_pivot.h"
+#include "txm_resample_i8.h"
 
 namespace txm {
 
@@ -477,13 +480,54 @@ static ResamplePlan plan_resample(int64_t N, int64_t C, int64_t nrep, int K) {
   return p;
 }
 
+// int8-sliced path (txm_resample_i8.hip): 64 replicates x all columns per workgroup,
+// chunks of whole scaling windows, one workgroup per CU.
+struct I8Plan {
+  int n_rbg, n_chunks;
+  int64_t tiles_per_chunk, nrep_pad, ntiles, nwin;
+  size_t off_pivot, off_px, off_pu, off_wt, total;
+};
+
+static I8Plan plan_i8(int64_t N, int64_t C, int64_t nrep, int K) {
+  I8Plan p;
+  p.n_rbg = (int)cdiv(nrep, I8_REPS);
+  p.nrep_pad = (int64_t)p.n_rbg * I8_REPS;
+  p.ntiles = cdiv(N, SM_T);
+  p.nwin = cdiv(p.ntiles, I8_WIN_TILES);
+  int64_t nc = cdiv(cdiv((int64_t)num_cus(), p.n_rbg), 8) * 8;
+  if (nc < 8) nc = 8;
+  p.tiles_per_chunk = cdiv(p.nwin, nc) * I8_WIN_TILES;
+  p.n_chunks = (int)(cdiv(cdiv(p.ntiles, p.tiles_per_chunk), 8) * 8);
+  p.off_pivot = 0;
+  p.off_px = align_up((size_t)(1 + C) * sizeof(double), 256);
+  p.off_pu = p.off_px + align_up((size_t)p.n_chunks * p.nrep_pad * I8_CPAD * K * sizeof(double), 256);
+  p.off_wt = p.off_pu + align_up((size_t)p.n_chunks * p.nrep_pad * K * sizeof(double), 256);
+  p.total = p.off_wt + align_up((size_t)p.nwin * I8_WT_STRIDE * sizeof(double), 256);
+  return p;
+}
+
+// TXM_I8=0 keeps the FP64 kernel, TXM_I8=1 takes the int8 path whenever it applies;
+// by default it is used where it pays: many replicates, enough columns to fill a block.
+static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K) {
+  if (!i8_supported(N, C, nrep, K)) return false;
+  const char *e = getenv("TXM_I8");
+  if (e && e[0] == '0') return false;
+  if (e && e[0] == '1') return true;
+  return C >= 12 && nrep >= 48 && N >= 4 * I8_WIN_TILES * SM_T;
+}
+
 }  // namespace txm
 
 using namespace txm;
 
 extern "C" size_t txm_resample_vals_ws_bytes(int64_t N, int64_t C, int64_t nrep, int order) {
   if (N < 1 || C < 1 || nrep < 1 || order < 0 || order > TXM_MAX_ORDER) return 0;
-  return plan_resample(N, C, nrep, order + 1).total;
+  size_t n = plan_resample(N, C, nrep, order + 1).total;
+  if (i8_supported(N, C, nrep, order + 1)) {
+    const size_t m = plan_i8(N, C, nrep, order + 1).total;
+    if (m > n) n = m;
+  }
+  return n;
 }
 
 #define TXM_K_SWITCH(K_, CALL)                          \
@@ -544,6 +588,52 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
   TXM_REQUIRE(explicit_ != (spec != nullptr && counts != nullptr),
               "resample_vals: give either freq or (spec, counts)");
   const int K = order + 1;
+  if (!explicit_ && use_i8(N, C, nrep, K)) {
+    const I8Plan q = plan_i8(N, C, nrep, K);
+    if (ws_bytes < q.total) {
+      set_error("resample_vals: workspace too small (%zu < %zu)", ws_bytes, q.total);
+      return TXM_ERR_WORKSPACE;
+    }
+    TXM_REQUIRE(spec->ndat == N && spec->nrep == nrep, "resample_vals: sampler spec does not match N/nrep");
+    hipStream_t st = (hipStream_t)stream;
+    double *piv = (double *)((char *)ws + q.off_pivot);
+    if (pivot) {
+      TXM_HIP(hipMemcpyAsync(piv, pivot, sizeof(double) * (size_t)(1 + C), hipMemcpyDeviceToDevice, st));
+    } else {
+      hipLaunchKernelGGL(pivot_kernel, dim3((unsigned)(1 + C)), dim3(256), 0, st, x, ldx_s, (int64_t)1,
+                         u, (int64_t)1, N, piv);
+      TXM_LAUNCH_CHECK();
+    }
+    I8Args b;
+    b.x = x; b.ldx_s = ldx_s; b.u = u; b.w = w; b.N = N; b.C = C; b.nrep = nrep;
+    b.counts = counts;
+    b.k0 = (uint32_t)spec->seed;
+    b.k1 = (uint32_t)(spec->seed >> 32);
+    b.ntiles = q.ntiles;
+    b.last_tile_size = (uint32_t)(N - (q.ntiles - 1) * SM_T);
+    b.pivot = piv;
+    b.wtab = (double *)((char *)ws + q.off_wt);
+    b.nwin = q.nwin;
+    b.part_x = (double *)((char *)ws + q.off_px);
+    b.part_u = (double *)((char *)ws + q.off_pu);
+    b.n_chunks = q.n_chunks; b.n_rbg = q.n_rbg; b.tiles_per_chunk = q.tiles_per_chunk;
+    b.nrep_pad = q.nrep_pad;
+    TXM_HIP(hipMemsetAsync(b.part_x, 0, q.off_wt - q.off_px, st));
+    const int rc = launch_resample_i8(b, K, w != nullptr, st);
+    if (rc != TXM_OK) return rc;
+    const int64_t ne = nrep * C;
+#define TXM_I8_FIN(KK)                                                                                 \
+  hipLaunchKernelGGL((resample_finalize_kernel<KK>), dim3((unsigned)cdiv(ne, 256)), dim3(256), 0, st, \
+                     b.part_x, b.part_u, q.n_chunks, q.nrep_pad, (int64_t)I8_CPAD, nrep, C, piv, out)
+    switch (K) {
+      case 3: TXM_I8_FIN(3); break;
+      case 4: TXM_I8_FIN(4); break;
+      default: TXM_I8_FIN(5); break;
+    }
+#undef TXM_I8_FIN
+    TXM_LAUNCH_CHECK();
+    return TXM_OK;
+  }
   const ResamplePlan p = plan_resample(N, C, nrep, K);
   if (ws_bytes < p.total) {
     set_error("resample_vals: workspace too small (%zu < %zu)", ws_bytes, p.total);

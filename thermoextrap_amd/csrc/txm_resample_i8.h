@@ -1,0 +1,45 @@
+// txm_resample_i8.h -- internal interface of the int8-sliced bootstrap kernel
+// (txm_resample_i8.hip), called from txm_resample_vals (txm_resample.hip).
+#pragma once
+#include "txm_common.h"
+
+namespace txm {
+
+constexpr int I8_REPS = 64;        // replicates per workgroup (2 MFMA row blocks of 32)
+constexpr int I8_NSL = 7;          // signed 8-bit slices of the 51-bit fixed-point operand
+constexpr int I8_WIN_TILES = 16;   // sampler tiles per scaling window (16384 samples)
+constexpr int I8_CPAD = 32;        // columns of one MFMA column block
+constexpr int I8_WT_STRIDE = 80;   // doubles per window-table entry
+
+// Window table entry w (doubles):  [0] 1/max|u-pu|   [1] 1/max|w| (1 when unweighted)
+//   [2 + j]      descale of power j      = max|w| * max|u-pu|^j          (j < 9)
+//   [12 + c]     scale of column c       = 2^50 / max|x_c - px_c|        (c < 32)
+//   [44 + c]     descale of column c     = max|x_c - px_c| * 2^-50
+constexpr int I8_WT_INVDU = 0, I8_WT_INVW = 1, I8_WT_DSP = 2, I8_WT_SC = 12, I8_WT_DSC = 44;
+
+struct I8Args {
+  const double *x;
+  int64_t ldx_s;
+  const double *u;
+  const double *w;
+  int64_t N, C, nrep;
+  const uint32_t *counts;  // [nrep][ntiles]
+  uint32_t k0, k1;
+  int64_t ntiles;
+  uint32_t last_tile_size;
+  const double *pivot;     // [1 + C]
+  double *wtab;            // [nwin][I8_WT_STRIDE]
+  int64_t nwin;
+  double *part_x;          // [n_chunks][nrep_pad][32][K]   (zeroed by the launcher)
+  double *part_u;          // [n_chunks][nrep_pad][K]
+  int n_chunks, n_rbg;
+  int64_t tiles_per_chunk; // multiple of I8_WIN_TILES
+  int64_t nrep_pad;
+};
+
+// true when the int8 path can take this problem (device-sampler mode only)
+bool i8_supported(int64_t N, int64_t C, int64_t nrep, int K);
+// launches the window-scale pass and the bootstrap kernel; partial sums land in part_x/part_u
+int launch_resample_i8(const I8Args &a, int K, bool weighted, hipStream_t st);
+
+}  // namespace txm
