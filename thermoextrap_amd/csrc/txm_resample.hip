@@ -500,8 +500,8 @@ static I8Plan plan_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   p.n_chunks = (int)(cdiv(cdiv(p.ntiles, p.tiles_per_chunk), 8) * 8);
   p.off_pivot = 0;
   p.off_px = align_up((size_t)(1 + C) * sizeof(double), 256);
-  p.off_pu = p.off_px + align_up((size_t)p.n_chunks * p.nrep_pad * I8_CPAD * K * sizeof(double), 256);
-  p.off_wt = p.off_pu + align_up((size_t)p.n_chunks * p.nrep_pad * K * sizeof(double), 256);
+  p.off_pu = p.off_px + align_up((size_t)p.n_chunks * I8_NSL * p.nrep_pad * I8_CPAD * K * sizeof(double), 256);
+  p.off_wt = p.off_pu + align_up((size_t)p.n_chunks * I8_NSL * p.nrep_pad * K * sizeof(double), 256);
   p.total = p.off_wt + align_up((size_t)p.nwin * I8_WT_STRIDE * sizeof(double), 256);
   return p;
 }
@@ -624,8 +624,9 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
     const int64_t ne = nrep * C;
 #define TXM_I8_FIN(KK)                                                                                 \
   hipLaunchKernelGGL((resample_finalize_kernel<KK>), dim3((unsigned)cdiv(ne, 256)), dim3(256), 0, st, \
-                     b.part_x, b.part_u, q.n_chunks, q.nrep_pad, (int64_t)I8_CPAD, nrep, C, piv, out)
+                     b.part_x, b.part_u, q.n_chunks * I8_NSL, q.nrep_pad, (int64_t)I8_CPAD, nrep, C, piv, out)
     switch (K) {
+      case 2: TXM_I8_FIN(2); break;
       case 3: TXM_I8_FIN(3); break;
       case 4: TXM_I8_FIN(4); break;
       default: TXM_I8_FIN(5); break;

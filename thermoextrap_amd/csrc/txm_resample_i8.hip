@@ -11,26 +11,25 @@
 // Only the data operand needs slicing, and that work is shared by all 64 replicates of
 // a workgroup:
 //
-//   per window of 16 tiles (16384 samples) the pre-pass measures max|du|, max|w|,
+//   per window of 64 tiles (65536 samples) the pre-pass measures max|du|, max|w|,
 //   max|dx_c|; inside a window every monomial m = (w/wmax)(du/dumax)^j * (dx_c/dxmax_c)
 //   lies in [-1, 1] and  X = rint(m * 2^50)  is a 52-bit signed integer obtained with ONE
 //   v_fma_f64 against the magic constant 1.5*2^52 (+ a per-byte bias of 0x80), whose
 //   mantissa bytes -- after an XOR with 0x80 -- are seven signed base-256 digits
 //   X = sum_i d_i 256^i, d_i in [-128, 127].  Then
 //        sum_k f_k X_k = sum_i 256^i * (sum_k f_k d_ik)      exactly, in int32 accumulators,
-//   flushed per window through a 7-term Horner in FP64 and the window's descale.
+//   flushed per window into one FP64 partial sum per digit (x 256^i x the window descale).
 //   Rounding: one rint per monomial at 2^-51 of the WINDOW maximum (unbiased), against
 //   2^-53 per element in FP64 -- far below the FP64 accumulation error of the sums.
 //
-// Workgroup = 4 waves x one wave per SIMD (512 VGPRs: 21 int32 accumulator tiles each),
-// 64 replicates x all (K+1) column blocks [block j < K: power j of the 32 observables,
-// block K: the K u-row sums].  Per sampler tile (1024 samples):
-//   1. stage 3 of the sampler fills the WG's count tile   cnt[sample/4][rep][4 x u8]  (64 KiB)
-//   2. 32 k-steps of 32 samples: every lane slices (1 column) x (4 samples) x (K powers)
+// Workgroup = 8 waves, two per SIMD (256 registers each, <= 10 int32 accumulator tiles),
+// 64 replicates x all operand fragments: fragment j*7+i = digit i of power j of the 32
+// observables; the K u-row monomials (dx = 1) pack their 7K digits into the columns of
+// ceil(7K/32) further fragments.  Per sampler tile (1024 samples):
+//   1. stage 3 of the sampler fills the WG's count tile   cnt[rep][sample/4 (+pad)][4 x u8]  (65 KiB)
+//   2. 32 k-steps of 32 samples: every lane slices (1 column) x (2 samples) x (K powers)
 //      of chunk s+1 into the other B buffer while the MFMAs of chunk s run.
-// LDS: 64 KiB counts + 2 x (K+1)*7 KiB B chunks.
-#include <type_traits>
-
+// LDS: 65 KiB counts + 2 x (7K + ceil(7K/32)) KiB of B chunks (139 KiB at order 4).
 #include "txm_resample_i8.h"
 #include "txm_sampler.h"
 
@@ -39,10 +38,16 @@ namespace txm {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-constexpr int I8_BLOCK = 256;
-constexpr int I8_CNT_BYTES = SM_T * I8_REPS;  // 65536
-constexpr int I8_FRAG = 1024;                 // one 32 x 32 int8 MFMA operand
-constexpr int I8_STEPS = SM_T / 32;           // k-steps per tile
+constexpr int I8_BLOCK = 512;
+constexpr int I8_WAVES = I8_BLOCK / 64;
+constexpr int I8_REPS_WAVE = I8_REPS / I8_WAVES;  // replicates whose counts one wave draws
+// count tile: cnt[rep][260 words], word g = the u8 counts of samples 4g..4g+3.  The 4-word pad
+// spreads one replicate's words (the scatter of a wave) and one word of 32 replicates (the A
+// operand read of a wave) over all LDS banks.
+constexpr int I8_CNT_ROW = SM_T / 4 + 4;          // words per replicate row
+constexpr int I8_CNT_BYTES = I8_REPS * I8_CNT_ROW * 4;  // 66560
+constexpr int I8_FRAG = 1024;                     // one 32 x 32 int8 MFMA operand
+constexpr int I8_STEPS = SM_T / 32;               // k-steps per tile
 constexpr int64_t I8_WIN_SAMPLES = (int64_t)I8_WIN_TILES * SM_T;
 
 // ---------------------------------------------------------------------------
@@ -115,7 +120,7 @@ __device__ __forceinline__ void i8_tile_calls(uint32_t *cnt, uint32_t k0, uint32
       const uint32_t f = (word >> (10 * k)) & 1023u;
       uint32_t inc = 1u << ((f & 3u) << 3);
       if (!ALL_VALID) inc = ((uint32_t)(wi * 3 + k) < nd) ? inc : 0u;
-      atomicAdd(&cnt[(f >> 2) * I8_REPS + rl], inc);
+      atomicAdd(&cnt[rl * I8_CNT_ROW + (f >> 2)], inc);
     }
   }
 }
@@ -123,7 +128,7 @@ __device__ __forceinline__ void i8_tile_calls(uint32_t *cnt, uint32_t k0, uint32
 __device__ __forceinline__ void i8_fill_full(const I8Args &a, uint32_t *cnt, int64_t rep0w, uint32_t rl0,
                                              int64_t t, int lane) {
 #pragma unroll 1
-  for (int p = 0; p < 8; ++p) {
+  for (int p = 0; p < I8_REPS_WAVE / 2; ++p) {
     const int64_t ra = rep0w + 2 * p, rb = ra + 1;
     if (ra >= a.nrep) break;  // wave-uniform
     const uint32_t na = a.counts[(size_t)ra * a.ntiles + t];
@@ -145,65 +150,64 @@ __device__ __forceinline__ void i8_fill_full(const I8Args &a, uint32_t *cnt, int
 }
 
 // ---------------------------------------------------------------------------
-// 4 fixed-point words -> 7 digit words (byte e of word i = digit i of sample e)
-__device__ __forceinline__ void i8_slice4(const double (&r)[4], uint32_t (&W)[I8_NSL]) {
-  uint32_t lo[4], hi[4];
+// 2 fixed-point words -> 4 words holding the 7 digit pairs: T[0] = {digit 0 | digit 1},
+// T[1] = {2 | 3}, T[2] = {4 | 5}, T[3] = {6 | -}; each 16-bit half = (sample 0, sample 1).
+// Digits 0..5 are the mantissa bytes XOR 0x80 (the bytes carry a +128 bias from the magic
+// constant).  Digit 6 is left as the raw exponent-adjacent byte 0x38 + d6: the constant 56
+// is taken out at flush time as 56 * (sum of counts), which the sampler knows exactly.
+constexpr int I8_D6_BIAS = 0x38;
+__device__ __forceinline__ void i8_slice2(double r0, double r1, uint32_t (&T)[4]) {
+  const uint64_t b0 = (uint64_t)__double_as_longlong(r0), b1 = (uint64_t)__double_as_longlong(r1);
+  const uint32_t l0 = (uint32_t)b0, l1 = (uint32_t)b1, h0 = (uint32_t)(b0 >> 32), h1 = (uint32_t)(b1 >> 32);
+  T[0] = __builtin_amdgcn_perm(l1, l0, 0x05010400u) ^ 0x80808080u;
+  T[1] = __builtin_amdgcn_perm(l1, l0, 0x07030602u) ^ 0x80808080u;
+  T[2] = __builtin_amdgcn_perm(h1, h0, 0x05010400u) ^ 0x80808080u;
+  T[3] = __builtin_amdgcn_perm(h1, h0, 0x07030602u);
+}
+
+__device__ __forceinline__ void i8_store7(unsigned char *base, const uint32_t (&T)[4], int stride) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const uint64_t b = (uint64_t)__double_as_longlong(r[e]);
-    lo[e] = (uint32_t)b ^ 0x80808080u;
-    hi[e] = ((uint32_t)(b >> 32) ^ 0x00008080u) - 0x00380000u;
+  for (int i = 0; i < I8_NSL; ++i) {
+    const uint32_t v = (i & 1) ? (T[i >> 1] >> 16) : T[i >> 1];
+    *reinterpret_cast<uint16_t *>(base + i * stride) = (uint16_t)v;
   }
-  const uint32_t a01 = __builtin_amdgcn_perm(lo[1], lo[0], 0x05010400u);
-  const uint32_t b01 = __builtin_amdgcn_perm(lo[1], lo[0], 0x07030602u);
-  const uint32_t a23 = __builtin_amdgcn_perm(lo[3], lo[2], 0x05010400u);
-  const uint32_t b23 = __builtin_amdgcn_perm(lo[3], lo[2], 0x07030602u);
-  W[0] = __builtin_amdgcn_perm(a23, a01, 0x05040100u);
-  W[1] = __builtin_amdgcn_perm(a23, a01, 0x07060302u);
-  W[2] = __builtin_amdgcn_perm(b23, b01, 0x05040100u);
-  W[3] = __builtin_amdgcn_perm(b23, b01, 0x07060302u);
-  const uint32_t c01 = __builtin_amdgcn_perm(hi[1], hi[0], 0x05010400u);
-  const uint32_t d01 = __builtin_amdgcn_perm(hi[1], hi[0], 0x07030602u);
-  const uint32_t c23 = __builtin_amdgcn_perm(hi[3], hi[2], 0x05010400u);
-  const uint32_t d23 = __builtin_amdgcn_perm(hi[3], hi[2], 0x07030602u);
-  W[4] = __builtin_amdgcn_perm(c23, c01, 0x05040100u);
-  W[5] = __builtin_amdgcn_perm(c23, c01, 0x07060302u);
-  W[6] = __builtin_amdgcn_perm(d23, d01, 0x05040100u);
 }
 
 // 1.5 * 2^52 + 0x80 in each of the six low mantissa bytes
 constexpr double I8_MAGIC = 6755399441055744.0 + 141289400074368.0;
 
 struct I8Chunk {
-  double x[4], u[4], w[4];
+  double x[2], u[2], w[2];
 };
 
 template <int K, bool WEIGHTED>
-__global__ __launch_bounds__(I8_BLOCK, 1) void resample_i8_kernel(const I8Args a) {
-  constexpr int NBLK = K + 1, NFR = NBLK * I8_NSL;
+__global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
+  constexpr int NPOW = K * I8_NSL;          // fragments of the observable blocks
+  constexpr int UF = (8 * K + 31) / 32;     // fragments of the packed u-row digits (column 8 j + i)
+  constexpr int NPW = (NPOW + UF + I8_WAVES - 1) / I8_WAVES;  // fragments per wave (x 2 replicate halves)
+  constexpr int NFR = NPW * I8_WAVES;       // padded: the tail fragments stay zero
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   uint32_t *cnt = reinterpret_cast<uint32_t *>(lds);
   unsigned char *bb0 = lds + I8_CNT_BYTES;
   unsigned char *bb1 = bb0 + NFR * I8_FRAG;
+  uint32_t *fsum = reinterpret_cast<uint32_t *>(bb1 + NFR * I8_FRAG);  // [64] draws per replicate in the window
 
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int n32 = lane & 31, half = lane >> 5;
-  // slicing role: column c, sample group g (4 samples) of every chunk
-  const int g = lane & 7, cslot = lane >> 3;
-  const int c = wave * 8 + cslot;
-  const bool c_ok = c < a.C;
-  const int64_t cc = c_ok ? c : 0;
-  // u-row role: power jsel (lanes of column slots 0 and 1)
-  const int jsel = wave + 4 * cslot;
-  const bool urow = cslot < 2 && jsel < K;
-  const uint32_t woff = (uint32_t)(c * 32 + g * 4);
-  const uint32_t uoff = (uint32_t)((K * I8_NSL * 32 + (urow ? jsel : 0)) * 32 + g * 4);
+  // slicing role: column c, sample pair g2 of every chunk.  Each half-wave (one LDS pass)
+  // holds the even or the odd pairs of 4 columns, so that its 32 b16 stores to one digit
+  // row group fall into 32 different dwords / banks.
+  const int g2 = 2 * (lane & 7) + (lane >> 5), cslot = (lane >> 3) & 3;
+  const int c = wave * 4 + cslot;
+  const int64_t cc = c < a.C ? c : 0;  // columns >= C re-read column 0: their sums are never flushed
+  // u-row role: power `wave`, lanes of column slot 0
+  const bool urow = cslot == 0 && wave < K;
+  const uint32_t woff = (uint32_t)(c * 32 + g2 * 2);
+  const uint32_t uoff = (uint32_t)((NPOW + (wave >> 2)) * I8_FRAG + (wave & 3) * 8 * 32 + g2 * 2);
   const uint32_t roff = (uint32_t)(n32 * 32 + half * 16);
-  const uint32_t aoff = (uint32_t)(half * 4 * I8_REPS + n32);
-  // MFMA role: block `wave` for both replicate halves, plus half `wave & 1` of block 4 + wave / 2
-  static_assert(NBLK >= 4 && NBLK <= 6, "every wave owns one full block; blocks 4, 5 are shared by wave pairs");
-  const int sb = 4 + (wave >> 1), shh = wave & 1;
-  const bool has_sh = sb < NBLK;
+  const uint32_t aoff = (uint32_t)(n32 * I8_CNT_ROW + half * 4);
+  // MFMA role: fragments [f_lo, f_hi) for both replicate halves
+  const int f_lo = wave * NPW;
 
   const int b = blockIdx.x;
   const int xcd = b & 7, q = b >> 3;
@@ -217,60 +221,78 @@ __global__ __launch_bounds__(I8_BLOCK, 1) void resample_i8_kernel(const I8Args a
   const double pu = a.pivot[0];
   const double px = a.pivot[1 + cc];
 
-  v16i acc[3][I8_NSL];
+  v16i acc[NPW][2];
 #pragma unroll
-  for (int e = 0; e < 3; ++e)
-#pragma unroll
-    for (int i = 0; i < I8_NSL; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[e][i][r] = 0;
+  for (int e = 0; e < NPW; ++e) {
+    acc[e][0] = (v16i)(0);
+    acc[e][1] = (v16i)(0);
+  }
 
-  // rows of the B buffers that are never written (columns >= C, u-row block rows >= K) stay zero
+  // rows of the B buffers that are never written (columns >= C, unused u-row columns) stay zero
   for (int e = threadIdx.x; e < 2 * NFR * I8_FRAG / 16; e += I8_BLOCK)
     reinterpret_cast<uint4 *>(bb0)[e] = make_uint4(0, 0, 0, 0);
 
   double inv_du = 0.0, inv_w = 1.0, sc = 0.0;
 
-  // ---- flush the int32 accumulators of one window into the FP64 partial sums ----
+  // ---- flush the int32 accumulators of one window into the per-digit FP64 partial sums ----
   // D layout of v_mfma_i32_32x32x32_i8: column = lane & 31, row = 8 * (reg / 4) + 4 * (lane >> 5) + reg % 4
-#define TXM_I8_FLUSH_TILES(E, BASE, STRIDE, DSC, VALID)                                     \
-  do {                                                                                       \
-    double *const base_ = (BASE);                                                            \
-    const double dsc_ = (DSC);                                                               \
-    const bool valid_ = (VALID);                                                             \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
-      double v = (double)acc[E][I8_NSL - 1][r];                                              \
-      _Pragma("unroll") for (int i = I8_NSL - 2; i >= 0; --i) v = fma(v, 256.0, (double)acc[E][i][r]); \
-      if (valid_) base_[((r >> 2) * 8 + (r & 3)) * (STRIDE)] += v * dsc_;                    \
-    }                                                                                        \
-    _Pragma("unroll") for (int i = 0; i < I8_NSL; ++i) acc[E][i] = (v16i)(0);                \
-  } while (0)
-#define TXM_I8_FLUSH_UNIT(E, BLK, H)                                                         \
-  do {                                                                                       \
-    const int blk_ = (BLK);                                                                  \
-    const size_t row0 = (size_t)chunk * a.nrep_pad + rep0 + 32 * (H) + 4 * half;             \
-    if (blk_ < K) {                                                                          \
-      TXM_I8_FLUSH_TILES(E, a.part_x + (row0 * I8_CPAD + n32) * K + blk_, I8_CPAD * K,       \
-                         wt[I8_WT_DSP + blk_] * wt[I8_WT_DSC + n32], n32 < a.C);             \
-    } else {                                                                                 \
-      const int j_ = n32 < K ? n32 : 0;                                                      \
-      TXM_I8_FLUSH_TILES(E, a.part_u + row0 * K + j_, K, wt[I8_WT_DSP + j_] * 0x1p-50, n32 < K); \
-    }                                                                                        \
-  } while (0)
+  uint32_t fdraws = 0;  // lane rr < 8: draws of replicate rep0 + 8 wave + rr in the current window
   auto flush = [&](int64_t win) {
     const double *wt = a.wtab + win * I8_WT_STRIDE;
-    // the asm MFMAs are invisible to the hazard recognizer: let the matrix pipe drain
-    // before the VALU reads their destination registers
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-    TXM_I8_FLUSH_UNIT(0, wave, 0);
-    TXM_I8_FLUSH_UNIT(1, wave, 1);
-    if (has_sh) TXM_I8_FLUSH_UNIT(2, sb, shh);
+    if (lane < I8_REPS_WAVE) fsum[wave * I8_REPS_WAVE + lane] = fdraws;
+    fdraws = 0;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < NPW; ++e) {
+      const int f = f_lo + e;
+      if (f < NPOW + UF) {
+        int j, i, col;
+        double dsc;
+        bool valid;
+        if (f < NPOW) {
+          j = f / I8_NSL;
+          i = f % I8_NSL;
+          col = n32;
+          dsc = wt[I8_WT_DSP + j] * wt[I8_WT_DSC + n32];
+          valid = n32 < a.C;
+        } else {
+          const int n = (f - NPOW) * 32 + n32;
+          valid = (n & 7) < I8_NSL && (n >> 3) < K;
+          j = valid ? n >> 3 : 0;
+          i = valid ? n & 7 : 0;
+          col = -1;
+          dsc = wt[I8_WT_DSP + j] * 0x1p-50;
+        }
+        dsc *= (double)((int64_t)1 << (8 * i));
+        const size_t row0 = ((size_t)chunk * I8_NSL + i) * a.nrep_pad + rep0 + 4 * half;
+        double *base;
+        int64_t stride;
+        if (col >= 0) {
+          base = a.part_x + (row0 * I8_CPAD + col) * K + j;
+          stride = (int64_t)I8_CPAD * K;
+        } else {
+          base = a.part_u + row0 * K + j;
+          stride = K;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = 32 * h + (r >> 2) * 8 + (r & 3);
+            int v = acc[e][h][r];
+            if (i == I8_NSL - 1) v -= I8_D6_BIAS * (int)fsum[m + 4 * half];
+            if (valid) base[(int64_t)m * stride] += (double)v * dsc;
+          }
+          acc[e][h] = (v16i)(0);
+        }
+      }
+    }
   };
 
   auto load_chunk = [&](int64_t wbase, int s, I8Chunk &r) {
-    const int64_t i = wbase + s * 32 + g * 4;
+    const int64_t i = wbase + s * 32 + g2 * 2;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < 2; ++e) {
       r.x[e] = a.x[(i + e) * a.ldx_s + cc];
       r.u[e] = a.u[i + e];
       if constexpr (WEIGHTED) r.w[e] = a.w[i + e];
@@ -279,85 +301,61 @@ __global__ __launch_bounds__(I8_BLOCK, 1) void resample_i8_kernel(const I8Args a
 
   // ---- slice chunk `r` into B buffer `bb`; then refill r with chunk `snext` ----
   auto produce = [&](unsigned char *bb, I8Chunk &r, int64_t wbase, int snext) {
-    double du[4], dx[4], p[4], p0[WEIGHTED ? 4 : 1];
+#ifdef TXM_I8_NO_PRODUCE
+    (void)bb; (void)r; (void)wbase; (void)snext; return;
+#endif
+    double du[2], dx[2], p[2], p0[2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < 2; ++e) {
       du[e] = (r.u[e] - pu) * inv_du;
       dx[e] = (r.x[e] - px) * sc;
-      if constexpr (WEIGHTED) p[e] = p0[e] = r.w[e] * inv_w;
+      if constexpr (WEIGHTED) p[e] = r.w[e] * inv_w;
       else p[e] = 1.0;
+      p0[e] = p[e];
     }
     load_chunk(wbase, snext, r);
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       if (j > 0) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) p[e] *= du[e];
+        p[0] *= du[0];
+        p[1] *= du[1];
       }
-      double rr[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) rr[e] = fma(p[e], dx[e], I8_MAGIC);
-      uint32_t W[I8_NSL];
-      i8_slice4(rr, W);
-      if (c_ok) {
-#pragma unroll
-        for (int i = 0; i < I8_NSL; ++i)
-          *reinterpret_cast<uint32_t *>(bb + (j * I8_NSL + i) * I8_FRAG + woff) = W[i];
-      }
+      uint32_t T[4];
+      i8_slice2(fma(p[0], dx[0], I8_MAGIC), fma(p[1], dx[1], I8_MAGIC), T);
+      i8_store7(bb + j * I8_NSL * I8_FRAG + woff, T, I8_FRAG);
     }
-    // u-row block: lanes of column slot 0 slice w * du^wave, those of slot 1 (wave 0 only,
-    // K = 5) w * du^4, which is the p the loop above ends with.  One pass per wave.
+    // u-row: lanes of column slot 0 in wave j < K slice w * du^j; its digit i is column
+    // 8 j + i of the packed u-row fragments
     if (urow) {
-      double ps[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        double v = WEIGHTED ? p0[e] : 1.0;
-        if (wave >= 1) v *= du[e];
-        if (wave >= 2) v *= du[e];
-        if (wave >= 3) v *= du[e];
-        ps[e] = (cslot == 1) ? p[e] : v;
+      double v0 = p0[0], v1 = p0[1];
+      const double d0 = du[0] * du[0], d1 = du[1] * du[1];
+      switch (wave) {  // wave-uniform
+        case 1: v0 *= du[0]; v1 *= du[1]; break;
+        case 2: v0 *= d0; v1 *= d1; break;
+        case 3: v0 *= d0 * du[0]; v1 *= d1 * du[1]; break;
+        case 4: v0 *= d0 * d0; v1 *= d1 * d1; break;
+        default: break;
       }
-      double rr[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) rr[e] = fma(ps[e], 0x1p50, I8_MAGIC);
-      uint32_t W[I8_NSL];
-      i8_slice4(rr, W);
-#pragma unroll
-      for (int i = 0; i < I8_NSL; ++i) *reinterpret_cast<uint32_t *>(bb + i * I8_FRAG + uoff) = W[i];
+      uint32_t T[4];
+      i8_slice2(fma(v0, 0x1p50, I8_MAGIC), fma(v1, 0x1p50, I8_MAGIC), T);
+      i8_store7(bb + uoff, T, 32);
     }
   };
 
+  // ---- the MFMAs of chunk s: this wave's NPW fragments x both replicate halves ----
   auto mfma_step = [&](const unsigned char *bb, int s) {
-    const uint32_t *cw = cnt + s * (8 * I8_REPS) + aoff;
-    v4i A0, A1;
+#ifdef TXM_I8_NO_MFMA
+    (void)bb; (void)s; return;
+#endif
+    const uint32_t *cw = cnt + s * 8 + aoff;
+    const v4i A0 = *reinterpret_cast<const v4i *>(cw);
+    const v4i A1 = *reinterpret_cast<const v4i *>(cw + 32 * I8_CNT_ROW);
+    const unsigned char *bf = bb + f_lo * I8_FRAG + roff;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      A0[e] = (int)cw[e * I8_REPS];
-      A1[e] = (int)cw[e * I8_REPS + 32];
-    }
-#pragma unroll
-    for (int i = 0; i < I8_NSL; ++i) {
-      const v4i B = *reinterpret_cast<const v4i *>(bb + (wave * I8_NSL + i) * I8_FRAG + roff);
-      acc[0][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, B, acc[0][i], 0, 0, 0);
-      acc[1][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, B, acc[1][i], 0, 0, 0);
-    }
-    // The third unit's tiles are pinned through asm constraints (1 to the AGPRs left over by
-    // the 14 builtin tiles, 6 to VGPRs): 21 tiles do not fit the 256 AGPRs that the register
-    // allocator gives builtin accumulators.  Its A operand is read from LDS a second time
-    // (wave-uniform half) so that one straight-line sequence serves both halves and the
-    // allocator has no reason to move the tiles: a compiler-made copy right after an asm
-    // MFMA would read the destination before the matrix pipe has written it (the hazard
-    // recognizer does not look into asm).  tools/check_i8_isa.py verifies the emitted code.
-    if (has_sh) {
-      v4i As;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) As[e] = (int)cw[e * I8_REPS + 32 * shh];
-#pragma unroll
-      for (int i = 0; i < I8_NSL; ++i) {
-        const v4i B = *reinterpret_cast<const v4i *>(bb + (sb * I8_NSL + i) * I8_FRAG + roff);
-        if (i < 1) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(acc[2][i]) : "v"(As), "v"(B));
-        else asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc[2][i]) : "v"(As), "v"(B));
-      }
+    for (int e = 0; e < NPW; ++e) {
+      const v4i B = *reinterpret_cast<const v4i *>(bf + e * I8_FRAG);
+      acc[e][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, B, acc[e][0], 0, 0, 0);
+      acc[e][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, B, acc[e][1], 0, 0, 0);
     }
   };
 
@@ -373,51 +371,57 @@ __global__ __launch_bounds__(I8_BLOCK, 1) void resample_i8_kernel(const I8Args a
     if (tt_end > t_end) tt_end = t_end;
 #pragma unroll 1
     for (int64_t t = win * I8_WIN_TILES; t < tt_end; ++t) {
-    const int64_t i_tile = t * SM_T;
-    const uint32_t tsize = (t == a.ntiles - 1) ? a.last_tile_size : (uint32_t)SM_T;
-    int64_t wbase = i_tile;
-    if (wbase > a.N - SM_T) wbase = a.N - SM_T;          // the last tile slides its window back
-    const uint32_t shift = (uint32_t)(i_tile - wbase);
+      const int64_t i_tile = t * SM_T;
+      const uint32_t tsize = (t == a.ntiles - 1) ? a.last_tile_size : (uint32_t)SM_T;
+      int64_t wbase = i_tile;
+      if (wbase > a.N - SM_T) wbase = a.N - SM_T;  // the last tile slides its window back
+      const uint32_t shift = (uint32_t)(i_tile - wbase);
 
-    I8Chunk r0;
-    load_chunk(wbase, 0, r0);
+      I8Chunk r0;
+      load_chunk(wbase, 0, r0);
 
-    // ---- stage 3 of the sampler: the workgroup's 64 x 1024 count tile -------
-    for (int e = threadIdx.x; e < I8_CNT_BYTES / 16; e += I8_BLOCK)
-      reinterpret_cast<uint4 *>(cnt)[e] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-    {
-      const int64_t rep0w = rep0 + wave * 16;
-      const uint32_t rl0 = (uint32_t)wave * 16u;
-      if (tsize == (uint32_t)SM_T) {
-        i8_fill_full(a, cnt, rep0w, rl0, t, lane);
-      } else {
-        for (int rr = 0; rr < 16; ++rr) {
-          const int64_t r = rep0w + rr;
-          if (r >= a.nrep) break;  // wave-uniform
-          const uint32_t n = a.counts[(size_t)r * a.ntiles + t];
-          sampler_fine_tile(a.k0, a.k1, (uint32_t)r, (uint32_t)t, n, tsize, lane, [&](uint32_t off0) {
-            const uint32_t off = off0 + shift;
-            atomicAdd(&cnt[(off >> 2) * I8_REPS + rl0 + (uint32_t)rr], 1u << ((off & 3u) << 3));
-          });
+      // ---- stage 3 of the sampler: the workgroup's 64 x 1024 count tile -------
+      for (int e = threadIdx.x; e < I8_CNT_BYTES / 16; e += I8_BLOCK)
+        reinterpret_cast<uint4 *>(cnt)[e] = make_uint4(0, 0, 0, 0);
+      __syncthreads();
+      {
+        const int64_t rep0w = rep0 + wave * I8_REPS_WAVE;
+        const uint32_t rl0 = (uint32_t)(wave * I8_REPS_WAVE);
+#ifdef TXM_I8_NO_FILL
+        if (rep0w < 0) {
+#else
+        if (tsize == (uint32_t)SM_T) {
+#endif
+          i8_fill_full(a, cnt, rep0w, rl0, t, lane);
+        } else if (tsize != (uint32_t)SM_T) {
+          for (int rr = 0; rr < I8_REPS_WAVE; ++rr) {
+            const int64_t r = rep0w + rr;
+            if (r >= a.nrep) break;  // wave-uniform
+            const uint32_t n = a.counts[(size_t)r * a.ntiles + t];
+            sampler_fine_tile(a.k0, a.k1, (uint32_t)r, (uint32_t)t, n, tsize, lane, [&](uint32_t off0) {
+              const uint32_t off = off0 + shift;
+              atomicAdd(&cnt[(rl0 + (uint32_t)rr) * I8_CNT_ROW + (off >> 2)], 1u << ((off & 3u) << 3));
+            });
+          }
         }
       }
-    }
-    __syncthreads();
+      if (lane < I8_REPS_WAVE && rep0 + wave * I8_REPS_WAVE + lane < a.nrep)
+        fdraws += a.counts[(size_t)(rep0 + wave * I8_REPS_WAVE + lane) * a.ntiles + t];
+      __syncthreads();
 
-    // ---- contraction: chunk s on the matrix pipe, chunk s+1 through the slicer ----
-    produce(bb0, r0, wbase, 1);
-    __syncthreads();
+      // ---- contraction: chunk s on the matrix pipe, chunk s+1 through the slicer ----
+      produce(bb0, r0, wbase, 1);
+      __syncthreads();
 #pragma unroll 1
-    for (int s = 0; s < I8_STEPS; s += 2) {
-      mfma_step(bb0, s);
-      produce(bb1, r0, wbase, s + 2 < I8_STEPS ? s + 2 : I8_STEPS - 1);
-      __syncthreads();
-      mfma_step(bb1, s + 1);
-      if (s + 2 < I8_STEPS) produce(bb0, r0, wbase, s + 3 < I8_STEPS ? s + 3 : I8_STEPS - 1);
-      __syncthreads();
+      for (int s = 0; s < I8_STEPS; s += 2) {
+        mfma_step(bb0, s);
+        produce(bb1, r0, wbase, s + 2 < I8_STEPS ? s + 2 : I8_STEPS - 1);
+        __syncthreads();
+        mfma_step(bb1, s + 1);
+        if (s + 2 < I8_STEPS) produce(bb0, r0, wbase, s + 3 < I8_STEPS ? s + 3 : I8_STEPS - 1);
+        __syncthreads();
+      }
     }
-  }
     flush(win);
   }
 }
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(I8_BLOCK, 1) void resample_i8_kernel(const I8Args a
 // ---------------------------------------------------------------------------
 bool i8_supported(int64_t N, int64_t C, int64_t nrep, int K) {
   (void)nrep;
-  return N >= SM_T && C >= 1 && C <= I8_CPAD && K >= 3 && K <= 5;
+  return N >= SM_T && C >= 1 && C <= I8_CPAD && K >= 2 && K <= 5;
 }
 
 int launch_resample_i8(const I8Args &a, int K, bool weighted, hipStream_t st) {
@@ -433,7 +437,8 @@ int launch_resample_i8(const I8Args &a, int K, bool weighted, hipStream_t st) {
                      a.N, a.C, a.pivot, a.wtab);
   TXM_LAUNCH_CHECK();
   const dim3 grid((unsigned)(a.n_chunks * a.n_rbg)), block(I8_BLOCK);
-  const size_t lds = (size_t)I8_CNT_BYTES + 2u * (size_t)(K + 1) * I8_NSL * I8_FRAG;
+  const int nfr = (K * I8_NSL + (8 * K + 31) / 32 + 7) / 8 * 8;
+  const size_t lds = (size_t)I8_CNT_BYTES + 2u * (size_t)nfr * I8_FRAG + I8_REPS * sizeof(uint32_t);
 #define TXM_I8_LAUNCH(KK)                                                                      \
   do {                                                                                         \
     if (weighted) {                                                                            \
@@ -447,6 +452,7 @@ int launch_resample_i8(const I8Args &a, int K, bool weighted, hipStream_t st) {
     }                                                                                          \
   } while (0)
   switch (K) {
+    case 2: TXM_I8_LAUNCH(2); break;
     case 3: TXM_I8_LAUNCH(3); break;
     case 4: TXM_I8_LAUNCH(4); break;
     case 5: TXM_I8_LAUNCH(5); break;

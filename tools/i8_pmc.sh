@@ -1,0 +1,24 @@
+#!/bin/bash
+# PMC passes over the int8 bootstrap kernel (GPU box):  bash tools/i8_pmc.sh [N] [nrep]
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp TXM_I8=1
+N=${1:-2e7}; NREP=${2:-1000}
+i=0
+for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" \
+           "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT" \
+           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD" \
+           "SQ_INSTS_LDS_ATOMIC SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_UNALIGNED_STALL"; do
+  i=$((i+1))
+  rm -rf gpurun_out/i8_pmc$i
+  timeout -k 10 240 rocprofv3 --pmc $set --kernel-include-regex "resample_i8_kernel" -d gpurun_out/i8_pmc$i -o pmc --output-format csv -- \
+      python3 tools/prof_driver.py $N $NREP 32 4 1 > gpurun_out/i8_pmc$i.log 2>&1 || { echo "pass $i failed"; tail -5 gpurun_out/i8_pmc$i.log; }
+done
+python3 - <<'PY'
+import csv, glob, collections
+agg = collections.OrderedDict()
+for f in sorted(glob.glob("gpurun_out/i8_pmc*/**/*counter_collection.csv", recursive=True)):
+    for r in csv.DictReader(open(f)):
+        agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+for k, v in agg.items():
+    print(f"{k:32s} {sum(v)/len(v):.4e}  (n={len(v)})")
+PY
