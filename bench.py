@@ -33,6 +33,7 @@ if str(ROOT) not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector = matrix peak (the microarch guide lists no fp64 row)
+INT8_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md: I8 MFMA = 2x the BF16 rate (~2.5 PF dense); 4.4 POP/s measured (tools/mfma_i8_probe2.hip)
 
 
 def parse():
@@ -214,22 +215,51 @@ def main():
 
     alg_bytes = 8.0 * N * (C + 1)                    # samples read once
     alg_flops = 2.0 * N * nrep * K * (C + 1)         # dense contraction F.M
-    roofline = {
-        "kernel": "txm::resample_kernel (FP64 MFMA bootstrap contraction, Philox stage 3 fused)",
-        "bound": "mfma",
-        "achieved": alg_flops / (t_boot * 1e-3) / 1e12,
-        "peak": FP64_PEAK_TFLOPS,
-        "unit": "TFLOP/s",
-        "frac": alg_flops / (t_boot * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-        "traffic": pmc_traffic("txm::resample_kernel"),
-        "ms": t_boot,
-        "algorithmic_flops": alg_flops,
-        "algorithmic_bytes": alg_bytes,
-        "hbm_achieved_GBs": alg_bytes / (t_boot * 1e-3) / 1e9,
-        "hbm_frac": alg_bytes / (t_boot * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "note": "algorithmic flops = 2*N*nrep*K*(N_obs+1); fp64 peak 78.6 TF (vector = matrix); "
-                "max attainable HBM fraction for this workload is ~1 % (SURVEY 8(d))",
-    }
+    path = engine.resample_path(N, C, nrep, order)
+    tf = alg_flops / (t_boot * 1e-3) / 1e12
+    if path == "int8":
+        # executed int8 MACs: 64-replicate groups x padded sample tiles x (8 * ceil((7K + ceil(8K/32)) / 8)) operand fragments of 32 columns
+        nfr = -(-(7 * K + -(-8 * K // 32)) // 8) * 8
+        i8_ops = 2.0 * (-(-nrep // 64) * 64) * (-(-N // 1024) * 1024) * nfr * 32
+        roofline = {
+            "kernel": "txm::resample_i8_kernel (bootstrap contraction on the int8 matrix pipe by exact 7-digit "
+                      "fixed-point slicing, Philox stage 3 fused) + window-scale, memset and finalize kernels",
+            "bound": "mfma",
+            "achieved": tf,
+            "peak": FP64_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": tf / FP64_PEAK_TFLOPS,
+            "traffic": pmc_traffic("txm::resample_i8_kernel"),
+            "ms": t_boot,
+            "algorithmic_flops": alg_flops,
+            "algorithmic_bytes": alg_bytes,
+            "hbm_achieved_GBs": alg_bytes / (t_boot * 1e-3) / 1e9,
+            "hbm_frac": alg_bytes / (t_boot * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "int8_pipe": {"executed_TOPs": i8_ops / (t_boot * 1e-3) / 1e12, "peak_TOPs": INT8_PEAK_TOPS,
+                          "frac": i8_ops / (t_boot * 1e-3) / 1e12 / INT8_PEAK_TOPS},
+            "note": "achieved = ALGORITHMIC fp64 flops 2*N*nrep*K*(N_obs+1) per second against the FP64 MFMA peak "
+                    "(78.6 TF, SURVEY 8(d)); frac > 1 because the sums run, exactly, on the int8 pipe. That pipe "
+                    "is ~20 % busy: the kernel is bound by the VALU + LDS-write work of slicing the data operand "
+                    "(DESIGN.md section 7), not by the matrix pipe",
+        }
+    else:
+        roofline = {
+            "kernel": "txm::resample_kernel (FP64 MFMA bootstrap contraction, Philox stage 3 fused)",
+            "bound": "mfma",
+            "achieved": tf,
+            "peak": FP64_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": tf / FP64_PEAK_TFLOPS,
+            "traffic": pmc_traffic("txm::resample_kernel"),
+            "ms": t_boot,
+            "algorithmic_flops": alg_flops,
+            "algorithmic_bytes": alg_bytes,
+            "hbm_achieved_GBs": alg_bytes / (t_boot * 1e-3) / 1e9,
+            "hbm_frac": alg_bytes / (t_boot * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "note": "algorithmic flops = 2*N*nrep*K*(N_obs+1); fp64 peak 78.6 TF (vector = matrix); "
+                    "max attainable HBM fraction for this workload is ~1 % (SURVEY 8(d))",
+        }
+    roofline["path"] = path
     roofline_reduce = {
         "kernel": "txm::reduce_rowmajor_kernel (one-pass power-sum reduction, the HBM-bound leg of the path)",
         "bound": "hbm",

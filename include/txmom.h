@@ -138,7 +138,20 @@ int txm_sampler_freq(const txm_sampler_spec *spec_host, const uint32_t *counts, 
  * NULL lets the library estimate one.  Requires ldx_c == 1.
  * out: [nrep][C][2][K]  (rep-major, i.e. already `.transpose(rep_dim, ...)`,
  * data.py:1812).
+ *
+ * Scale mode has two kernels behind it and the library picks one per call:
+ *   TXM_PATH_FP64  the contraction on the FP64 matrix pipe (any order, any C);
+ *   TXM_PATH_INT8  the same sums on the int8 matrix pipe: per window of 65536 samples every
+ *                  monomial is scaled by the window maximum, rounded ONCE to a 51-bit
+ *                  fixed-point integer (error <= 2^-51 of the window maximum, unbiased),
+ *                  split into seven signed 8-bit digits and accumulated exactly in int32
+ *                  (order 1..4, C <= 32; taken when C > 16 and nrep >= 192).
+ * txm_resample_path reports the choice; the environment variable TXM_I8=0 / TXM_I8=1
+ * forces the FP64 / the int8 kernel wherever it applies.
  */
+#define TXM_PATH_FP64 0
+#define TXM_PATH_INT8 1
+int txm_resample_path(int64_t N, int64_t C, int64_t nrep, int order);
 size_t txm_resample_vals_ws_bytes(int64_t N, int64_t C, int64_t nrep, int order);
 int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, const double *u,
                       const double *w, int64_t N, int64_t C, int order, int64_t nrep,

@@ -513,12 +513,19 @@ static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   const char *e = getenv("TXM_I8");
   if (e && e[0] == '0') return false;
   if (e && e[0] == '1') return true;
-  return C >= 12 && nrep >= 48 && N >= 4 * I8_WIN_TILES * SM_T;
+  // measured on MI355X (tools/i8_sweep.py): C <= 16 runs one 16-column FP64 block and stays
+  // ahead; with two blocks the int8 kernel wins from ~200 replicates on (1.6x at 1000)
+  return K >= 3 && C > 16 && nrep >= 192 && N >= 4 * I8_WIN_TILES * SM_T;
 }
 
 }  // namespace txm
 
 using namespace txm;
+
+extern "C" int txm_resample_path(int64_t N, int64_t C, int64_t nrep, int order) {
+  if (N < 1 || C < 1 || nrep < 1 || order < 0 || order > TXM_MAX_ORDER) return TXM_PATH_FP64;
+  return use_i8(N, C, nrep, order + 1) ? TXM_PATH_INT8 : TXM_PATH_FP64;
+}
 
 extern "C" size_t txm_resample_vals_ws_bytes(int64_t N, int64_t C, int64_t nrep, int order) {
   if (N < 1 || C < 1 || nrep < 1 || order < 0 || order > TXM_MAX_ORDER) return 0;

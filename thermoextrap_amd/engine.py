@@ -235,6 +235,11 @@ def resample_vals(
     return out[:, 0] if squeeze else out
 
 
+def resample_path(N: int, C: int, nrep: int, order: int) -> str:
+    """Which kernel the device-sampler bootstrap takes for this shape: "fp64" or "int8"."""
+    return "int8" if _L().txm_resample_path(int(N), int(C), int(nrep), int(order)) == 1 else "fp64"
+
+
 def resample_data(data: torch.Tensor, freq: torch.Tensor | None, order: int) -> torch.Tensor:
     """data (nrec, C, 2, K); freq (nrep, nrec) or None (plain reduce) -> (nrep, C, 2, K)."""
     L = _L()
