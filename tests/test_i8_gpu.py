@@ -49,6 +49,9 @@ def err(a, b, sc):
     (40000, 32, 4, 130, False),     # several tiles, three replicate groups
     (200000, 32, 4, 64, False),     # four scaling windows in four chunks
     (150000, 9, 1, 64, True),       # order 1
+    (30000, 32, 5, 64, False),      # order 5: powers 0-2 and 3-5 in two passes
+    (30000, 20, 6, 70, True),       # order 6: 0-3 and 4-6
+    (9000, 32, 7, 64, False),       # order 7: 0-3 and 4-7
     (40000, 17, 3, 64, True),       # order 3 (u-row shares block 4), weights
     (20000, 32, 2, 100, True),      # order 2 (no shared blocks)
     (70001, 1, 4, 65, False),       # 1-D observable

@@ -636,7 +636,10 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
       case 2: TXM_I8_FIN(2); break;
       case 3: TXM_I8_FIN(3); break;
       case 4: TXM_I8_FIN(4); break;
-      default: TXM_I8_FIN(5); break;
+      case 5: TXM_I8_FIN(5); break;
+      case 6: TXM_I8_FIN(6); break;
+      case 7: TXM_I8_FIN(7); break;
+      default: TXM_I8_FIN(8); break;
     }
 #undef TXM_I8_FIN
     TXM_LAUNCH_CHECK();

@@ -180,10 +180,14 @@ struct I8Chunk {
   double x[2], u[2], w[2];
 };
 
-template <int K, bool WEIGHTED>
+// K = order + 1 fixes the layout of the partial sums; one launch slices the JN powers
+// J0 .. J0 + JN - 1 (orders above 4 take two launches: 2 x 5 accumulator tiles is what the
+// 256-register budget of a wave leaves room for).
+template <int K, int J0, int JN, bool WEIGHTED>
 __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
-  constexpr int NPOW = K * I8_NSL;          // fragments of the observable blocks
-  constexpr int UF = (8 * K + 31) / 32;     // fragments of the packed u-row digits (column 8 j + i)
+  static_assert(JN >= 1 && JN <= 5 && J0 + JN <= K, "power range");
+  constexpr int NPOW = JN * I8_NSL;         // fragments of the observable blocks
+  constexpr int UF = (8 * JN + 31) / 32;    // fragments of the packed u-row digits (column 8 jj + i)
   constexpr int NPW = (NPOW + UF + I8_WAVES - 1) / I8_WAVES;  // fragments per wave (x 2 replicate halves)
   constexpr int NFR = NPW * I8_WAVES;       // padded: the tail fragments stay zero
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
   const int c = wave * 4 + cslot;
   const int64_t cc = c < a.C ? c : 0;  // columns >= C re-read column 0: their sums are never flushed
   // u-row role: power `wave`, lanes of column slot 0
-  const bool urow = cslot == 0 && wave < K;
+  const bool urow = cslot == 0 && wave < JN;
   const uint32_t woff = (uint32_t)(c * 32 + g2 * 2);
   const uint32_t uoff = (uint32_t)((NPOW + (wave >> 2)) * I8_FRAG + (wave & 3) * 8 * 32 + g2 * 2);
   const uint32_t roff = (uint32_t)(n32 * 32 + half * 16);
@@ -250,15 +254,15 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
         double dsc;
         bool valid;
         if (f < NPOW) {
-          j = f / I8_NSL;
+          j = J0 + f / I8_NSL;
           i = f % I8_NSL;
           col = n32;
           dsc = wt[I8_WT_DSP + j] * wt[I8_WT_DSC + n32];
           valid = n32 < a.C;
         } else {
           const int n = (f - NPOW) * 32 + n32;
-          valid = (n & 7) < I8_NSL && (n >> 3) < K;
-          j = valid ? n >> 3 : 0;
+          valid = (n & 7) < I8_NSL && (n >> 3) < JN;
+          j = J0 + (valid ? n >> 3 : 0);
           i = valid ? n & 7 : 0;
           col = -1;
           dsc = wt[I8_WT_DSP + j] * 0x1p-50;
@@ -315,26 +319,27 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
     }
     load_chunk(wbase, snext, r);
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-      if (j > 0) {
+    for (int q = 0; q < J0; ++q) {
+      p[0] *= du[0];
+      p[1] *= du[1];
+    }
+#pragma unroll
+    for (int jj = 0; jj < JN; ++jj) {
+      if (jj > 0) {
         p[0] *= du[0];
         p[1] *= du[1];
       }
       uint32_t T[4];
       i8_slice2(fma(p[0], dx[0], I8_MAGIC), fma(p[1], dx[1], I8_MAGIC), T);
-      i8_store7(bb + j * I8_NSL * I8_FRAG + woff, T, I8_FRAG);
+      i8_store7(bb + jj * I8_NSL * I8_FRAG + woff, T, I8_FRAG);
     }
-    // u-row: lanes of column slot 0 in wave j < K slice w * du^j; its digit i is column
-    // 8 j + i of the packed u-row fragments
+    // u-row: lanes of column slot 0 in wave jj < JN slice w * du^(J0 + jj); its digit i is
+    // column 8 jj + i of the packed u-row fragments
     if (urow) {
       double v0 = p0[0], v1 = p0[1];
-      const double d0 = du[0] * du[0], d1 = du[1] * du[1];
-      switch (wave) {  // wave-uniform
-        case 1: v0 *= du[0]; v1 *= du[1]; break;
-        case 2: v0 *= d0; v1 *= d1; break;
-        case 3: v0 *= d0 * du[0]; v1 *= d1 * du[1]; break;
-        case 4: v0 *= d0 * d0; v1 *= d1 * d1; break;
-        default: break;
+      for (int q = 0; q < J0 + wave; ++q) {  // wave-uniform trip count
+        v0 *= du[0];
+        v1 *= du[1];
       }
       uint32_t T[4];
       i8_slice2(fma(v0, 0x1p50, I8_MAGIC), fma(v1, 0x1p50, I8_MAGIC), T);
@@ -429,38 +434,44 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
 // ---------------------------------------------------------------------------
 bool i8_supported(int64_t N, int64_t C, int64_t nrep, int K) {
   (void)nrep;
-  return N >= SM_T && C >= 1 && C <= I8_CPAD && K >= 2 && K <= 5;
+  return N >= SM_T && C >= 1 && C <= I8_CPAD && K >= 2 && K <= 8;
+}
+
+template <int K, int J0, int JN>
+static int launch_pass(const I8Args &a, bool weighted, hipStream_t st) {
+  const dim3 grid((unsigned)(a.n_chunks * a.n_rbg)), block(I8_BLOCK);
+  constexpr int nfr = (JN * I8_NSL + (8 * JN + 31) / 32 + I8_WAVES - 1) / I8_WAVES * I8_WAVES;
+  const size_t lds = (size_t)I8_CNT_BYTES + 2u * (size_t)nfr * I8_FRAG + I8_REPS * sizeof(uint32_t);
+  if (weighted) {
+    TXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_i8_kernel<K, J0, JN, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((resample_i8_kernel<K, J0, JN, true>), grid, block, lds, st, a);
+  } else {
+    TXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_i8_kernel<K, J0, JN, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((resample_i8_kernel<K, J0, JN, false>), grid, block, lds, st, a);
+  }
+  TXM_LAUNCH_CHECK();
+  return TXM_OK;
 }
 
 int launch_resample_i8(const I8Args &a, int K, bool weighted, hipStream_t st) {
   hipLaunchKernelGGL(i8_window_kernel, dim3((unsigned)a.nwin), dim3(256), 0, st, a.x, a.ldx_s, a.u, a.w,
                      a.N, a.C, a.pivot, a.wtab);
   TXM_LAUNCH_CHECK();
-  const dim3 grid((unsigned)(a.n_chunks * a.n_rbg)), block(I8_BLOCK);
-  const int nfr = (K * I8_NSL + (8 * K + 31) / 32 + 7) / 8 * 8;
-  const size_t lds = (size_t)I8_CNT_BYTES + 2u * (size_t)nfr * I8_FRAG + I8_REPS * sizeof(uint32_t);
-#define TXM_I8_LAUNCH(KK)                                                                      \
-  do {                                                                                         \
-    if (weighted) {                                                                            \
-      TXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_i8_kernel<KK, true>),  \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
-      hipLaunchKernelGGL((resample_i8_kernel<KK, true>), grid, block, lds, st, a);             \
-    } else {                                                                                   \
-      TXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_i8_kernel<KK, false>), \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
-      hipLaunchKernelGGL((resample_i8_kernel<KK, false>), grid, block, lds, st, a);            \
-    }                                                                                          \
-  } while (0)
+  int rc = TXM_OK;
   switch (K) {
-    case 2: TXM_I8_LAUNCH(2); break;
-    case 3: TXM_I8_LAUNCH(3); break;
-    case 4: TXM_I8_LAUNCH(4); break;
-    case 5: TXM_I8_LAUNCH(5); break;
+    case 2: rc = launch_pass<2, 0, 2>(a, weighted, st); break;
+    case 3: rc = launch_pass<3, 0, 3>(a, weighted, st); break;
+    case 4: rc = launch_pass<4, 0, 4>(a, weighted, st); break;
+    case 5: rc = launch_pass<5, 0, 5>(a, weighted, st); break;
+    // orders 5..7: two passes over the sampler stream, each with its own powers
+    case 6: rc = launch_pass<6, 0, 3>(a, weighted, st); if (rc == TXM_OK) rc = launch_pass<6, 3, 3>(a, weighted, st); break;
+    case 7: rc = launch_pass<7, 0, 4>(a, weighted, st); if (rc == TXM_OK) rc = launch_pass<7, 4, 3>(a, weighted, st); break;
+    case 8: rc = launch_pass<8, 0, 4>(a, weighted, st); if (rc == TXM_OK) rc = launch_pass<8, 4, 4>(a, weighted, st); break;
     default: set_error("resample_i8: order out of range"); return TXM_ERR_INVALID;
   }
-#undef TXM_I8_LAUNCH
-  TXM_LAUNCH_CHECK();
-  return TXM_OK;
+  return rc;
 }
 
 }  // namespace txm
