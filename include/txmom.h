@@ -145,8 +145,9 @@ int txm_sampler_freq(const txm_sampler_spec *spec_host, const uint32_t *counts, 
  *                  monomial is scaled by the window maximum, rounded ONCE to a 51-bit
  *                  fixed-point integer (error <= 2^-51 of the window maximum, unbiased),
  *                  split into seven signed 8-bit digits and accumulated exactly in int32
- *                  (order 1..7, C <= 32, orders above 4 in two passes over the sampler
- *                  stream; taken when order >= 2, C > 16 and nrep >= 192).
+ *                  (order 1..7; 32 columns per launch, orders above 4 in two passes over
+ *                  the sampler stream; taken when order >= 2, nrep >= 192 and every 32-column
+ *                  group holds more than 16 columns).
  * txm_resample_path reports the choice; the environment variable TXM_I8=0 / TXM_I8=1
  * forces the FP64 / the int8 kernel wherever it applies.
  */

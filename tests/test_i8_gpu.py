@@ -52,6 +52,8 @@ def err(a, b, sc):
     (30000, 32, 5, 64, False),      # order 5: powers 0-2 and 3-5 in two passes
     (30000, 20, 6, 70, True),       # order 6: 0-3 and 4-6
     (9000, 32, 7, 64, False),       # order 7: 0-3 and 4-7
+    (12000, 70, 4, 64, False),      # three column groups (32 + 32 + 6)
+    (12000, 33, 2, 70, True),       # second group with a single column
     (40000, 17, 3, 64, True),       # order 3 (u-row shares block 4), weights
     (20000, 32, 2, 100, True),      # order 2 (no shared blocks)
     (70001, 1, 4, 65, False),       # 1-D observable

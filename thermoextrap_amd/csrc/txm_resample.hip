@@ -428,10 +428,12 @@ template <int K>
 __global__ __launch_bounds__(256) void resample_finalize_kernel(
     const double *__restrict__ part_x, const double *__restrict__ part_u, int n_chunks,
     int64_t nrep_pad, int64_t C_pad, int64_t nrep, int64_t C, const double *__restrict__ pivot,
-    double *__restrict__ out) {
+    double *__restrict__ out, int64_t c_off = 0, int64_t C_total = 0) {
+  // C columns of this launch are the columns c_off .. c_off + C - 1 of the C_total output columns
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nrep * C) return;
   const int64_t r = e / C, c = e % C;
+  if (C_total == 0) C_total = C;
   double S0[K], S1[K];
 #pragma unroll
   for (int j = 0; j < K; ++j) S0[j] = S1[j] = 0.0;
@@ -445,9 +447,10 @@ __global__ __launch_bounds__(256) void resample_finalize_kernel(
     }
   }
   double st[2 * K];
-  pivot_sums_to_state<K>(S0, S1, pivot[0], pivot[1 + c], st);
+  pivot_sums_to_state<K>(S0, S1, pivot[0], pivot[1 + c_off + c], st);
+  double *o = out + (r * C_total + c_off + c) * 2 * K;
 #pragma unroll
-  for (int q = 0; q < 2 * K; ++q) out[e * 2 * K + q] = st[q];
+  for (int q = 0; q < 2 * K; ++q) o[q] = st[q];
 }
 
 struct ResamplePlan {
@@ -515,7 +518,9 @@ static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   if (e && e[0] == '1') return true;
   // measured on MI355X (tools/i8_sweep.py): C <= 16 runs one 16-column FP64 block and stays
   // ahead; with two blocks the int8 kernel wins from ~200 replicates on (1.6x at 1000)
-  return K >= 3 && C > 16 && nrep >= 192 && N >= 4 * I8_WIN_TILES * SM_T;
+  // (the last column group must also hold more than 16 columns)
+  const int64_t ctail = C % I8_CPAD;
+  return K >= 3 && C > 16 && (ctail == 0 || ctail > 16) && nrep >= 192 && N >= 4 * I8_WIN_TILES * SM_T;
 }
 
 }  // namespace txm
@@ -612,7 +617,7 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
       TXM_LAUNCH_CHECK();
     }
     I8Args b;
-    b.x = x; b.ldx_s = ldx_s; b.u = u; b.w = w; b.N = N; b.C = C; b.nrep = nrep;
+    b.x = x; b.ldx_s = ldx_s; b.u = u; b.w = w; b.N = N; b.nrep = nrep;
     b.counts = counts;
     b.k0 = (uint32_t)spec->seed;
     b.k1 = (uint32_t)(spec->seed >> 32);
@@ -625,24 +630,29 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
     b.part_u = (double *)((char *)ws + q.off_pu);
     b.n_chunks = q.n_chunks; b.n_rbg = q.n_rbg; b.tiles_per_chunk = q.tiles_per_chunk;
     b.nrep_pad = q.nrep_pad;
-    TXM_HIP(hipMemsetAsync(b.part_x, 0, q.off_wt - q.off_px, st));
-    const int rc = launch_resample_i8(b, K, w != nullptr, st);
-    if (rc != TXM_OK) return rc;
-    const int64_t ne = nrep * C;
+    // one launch (or two, orders 5-7) per group of 32 columns; the groups reuse the partial buffers
+    for (int64_t col0 = 0; col0 < C; col0 += I8_CPAD) {
+      b.col0 = col0;
+      b.C = C - col0 < I8_CPAD ? C - col0 : I8_CPAD;
+      TXM_HIP(hipMemsetAsync(b.part_x, 0, q.off_wt - q.off_px, st));
+      const int rc = launch_resample_i8(b, K, w != nullptr, st);
+      if (rc != TXM_OK) return rc;
+      const int64_t ne = nrep * b.C;
 #define TXM_I8_FIN(KK)                                                                                 \
   hipLaunchKernelGGL((resample_finalize_kernel<KK>), dim3((unsigned)cdiv(ne, 256)), dim3(256), 0, st, \
-                     b.part_x, b.part_u, q.n_chunks * I8_NSL, q.nrep_pad, (int64_t)I8_CPAD, nrep, C, piv, out)
-    switch (K) {
-      case 2: TXM_I8_FIN(2); break;
-      case 3: TXM_I8_FIN(3); break;
-      case 4: TXM_I8_FIN(4); break;
-      case 5: TXM_I8_FIN(5); break;
-      case 6: TXM_I8_FIN(6); break;
-      case 7: TXM_I8_FIN(7); break;
-      default: TXM_I8_FIN(8); break;
-    }
+                     b.part_x, b.part_u, q.n_chunks * I8_NSL, q.nrep_pad, (int64_t)I8_CPAD, nrep, b.C, piv, out, col0, C)
+      switch (K) {
+        case 2: TXM_I8_FIN(2); break;
+        case 3: TXM_I8_FIN(3); break;
+        case 4: TXM_I8_FIN(4); break;
+        case 5: TXM_I8_FIN(5); break;
+        case 6: TXM_I8_FIN(6); break;
+        case 7: TXM_I8_FIN(7); break;
+        default: TXM_I8_FIN(8); break;
+      }
 #undef TXM_I8_FIN
-    TXM_LAUNCH_CHECK();
+      TXM_LAUNCH_CHECK();
+    }
     return TXM_OK;
   }
   const ResamplePlan p = plan_resample(N, C, nrep, K);

@@ -22,12 +22,13 @@ struct I8Args {
   int64_t ldx_s;
   const double *u;
   const double *w;
-  int64_t N, C, nrep;
+  int64_t N, C, nrep;      // C <= 32: the columns col0 .. col0 + C - 1 of x (one column group per launch)
+  int64_t col0;
   const uint32_t *counts;  // [nrep][ntiles]
   uint32_t k0, k1;
   int64_t ntiles;
   uint32_t last_tile_size;
-  const double *pivot;     // [1 + C]
+  const double *pivot;     // [1 + all columns]: {pivot_u, pivot_x[...]}, indexed with col0
   double *wtab;            // [nwin][I8_WT_STRIDE]
   int64_t nwin;
   double *part_x;          // [n_chunks][7 digits][nrep_pad][32][K]   (zeroed by the launcher)

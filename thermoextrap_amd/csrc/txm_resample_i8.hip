@@ -55,7 +55,8 @@ constexpr int64_t I8_WIN_SAMPLES = (int64_t)I8_WIN_TILES * SM_T;
 __global__ __launch_bounds__(256) void i8_window_kernel(const double *__restrict__ x, int64_t ldx,
                                                         const double *__restrict__ u,
                                                         const double *__restrict__ w, int64_t N,
-                                                        int64_t C, const double *__restrict__ pivot,
+                                                        int64_t C, int64_t col0,
+                                                        const double *__restrict__ pivot,
                                                         double *__restrict__ wtab) {
   const int64_t win = blockIdx.x;
   const int64_t i0 = win * I8_WIN_SAMPLES;
@@ -64,8 +65,8 @@ __global__ __launch_bounds__(256) void i8_window_kernel(const double *__restrict
   __shared__ double shx[256], shu[256], shw[256];
   double mx = 0.0, mu = 0.0, mw = 0.0;
   if (c < C) {
-    const double px = pivot[1 + c];
-    for (int64_t i = i0 + r; i < i1; i += 8) mx = fmax(mx, fabs(x[i * ldx + c] - px));
+    const double px = pivot[1 + col0 + c];
+    for (int64_t i = i0 + r; i < i1; i += 8) mx = fmax(mx, fabs(x[i * ldx + col0 + c] - px));
   }
   const double pu = pivot[0];
   for (int64_t i = i0 + tid; i < i1; i += 256) {
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
   if (t_end > a.ntiles) t_end = a.ntiles;
 
   const double pu = a.pivot[0];
-  const double px = a.pivot[1 + cc];
+  const double px = a.pivot[1 + a.col0 + cc];
 
   v16i acc[NPW][2];
 #pragma unroll
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
     const int64_t i = wbase + s * 32 + g2 * 2;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      r.x[e] = a.x[(i + e) * a.ldx_s + cc];
+      r.x[e] = a.x[(i + e) * a.ldx_s + a.col0 + cc];
       r.u[e] = a.u[i + e];
       if constexpr (WEIGHTED) r.w[e] = a.w[i + e];
     }
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
 // ---------------------------------------------------------------------------
 bool i8_supported(int64_t N, int64_t C, int64_t nrep, int K) {
   (void)nrep;
-  return N >= SM_T && C >= 1 && C <= I8_CPAD && K >= 2 && K <= 8;
+  return N >= SM_T && C >= 1 && C <= 64 * I8_CPAD && K >= 2 && K <= 8;  // C > 32: one launch per 32 columns
 }
 
 template <int K, int J0, int JN>
@@ -457,7 +458,7 @@ static int launch_pass(const I8Args &a, bool weighted, hipStream_t st) {
 
 int launch_resample_i8(const I8Args &a, int K, bool weighted, hipStream_t st) {
   hipLaunchKernelGGL(i8_window_kernel, dim3((unsigned)a.nwin), dim3(256), 0, st, a.x, a.ldx_s, a.u, a.w,
-                     a.N, a.C, a.pivot, a.wtab);
+                     a.N, a.C, a.col0, a.pivot, a.wtab);
   TXM_LAUNCH_CHECK();
   int rc = TXM_OK;
   switch (K) {
