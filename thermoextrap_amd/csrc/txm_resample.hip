@@ -487,7 +487,7 @@ static ResamplePlan plan_resample(int64_t N, int64_t C, int64_t nrep, int K) {
 // chunks of whole scaling windows, one workgroup per CU.
 struct I8Plan {
   int n_rbg, n_chunks;
-  int64_t tiles_per_chunk, nrep_pad, ntiles, nwin;
+  int64_t tiles_per_chunk, nrep_pad, ntiles, nwin, win_tiles;
   size_t off_pivot, off_px, off_pu, off_wt, total;
 };
 
@@ -496,10 +496,15 @@ static I8Plan plan_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   p.n_rbg = (int)cdiv(nrep, I8_REPS);
   p.nrep_pad = (int64_t)p.n_rbg * I8_REPS;
   p.ntiles = cdiv(N, SM_T);
-  p.nwin = cdiv(p.ntiles, I8_WIN_TILES);
-  int64_t nc = cdiv(cdiv((int64_t)num_cus(), p.n_rbg), 8) * 8;
+  // one workgroup per CU: chunks x replicate groups should fill the CUs once, not 1.1 times
+  int64_t nc = (int64_t)num_cus() / p.n_rbg / 8 * 8;
   if (nc < 8) nc = 8;
-  p.tiles_per_chunk = cdiv(p.nwin, nc) * I8_WIN_TILES;
+  // scaling window: 64 tiles, shorter when a chunk would hold fewer than two of them (chunks are
+  // whole windows, so short windows keep the workgroups balanced on small N x many chunks)
+  p.win_tiles = I8_WIN_TILES;
+  while (p.win_tiles > 4 && p.ntiles < 2 * p.win_tiles * nc) p.win_tiles /= 4;
+  p.nwin = cdiv(p.ntiles, p.win_tiles);
+  p.tiles_per_chunk = cdiv(p.nwin, nc) * p.win_tiles;
   p.n_chunks = (int)(cdiv(cdiv(p.ntiles, p.tiles_per_chunk), 8) * 8);
   p.off_pivot = 0;
   p.off_px = align_up((size_t)(1 + C) * sizeof(double), 256);
@@ -516,11 +521,13 @@ static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   const char *e = getenv("TXM_I8");
   if (e && e[0] == '0') return false;
   if (e && e[0] == '1') return true;
-  // measured on MI355X (tools/i8_sweep.py): C <= 16 runs one 16-column FP64 block and stays
-  // ahead; with two blocks the int8 kernel wins from ~200 replicates on (1.6x at 1000)
-  // (the last column group must also hold more than 16 columns)
+  // measured on MI355X (tools/i8_sweep.py, N = 1e7): C <= 16 runs one 16-column FP64 block and stays
+  // ahead; with two blocks the int8 kernel wins from 128 replicates on at order >= 4 (1.16x; 1.6x at
+  // 1000) and from ~400 at order 2 (1.2x; 1.44x at 1000).  The last column group must also hold more
+  // than 16 columns.
   const int64_t ctail = C % I8_CPAD;
-  return K >= 3 && C > 16 && (ctail == 0 || ctail > 16) && nrep >= 192 && N >= 4 * I8_WIN_TILES * SM_T;
+  const int64_t min_rep = K >= 5 ? 128 : (K == 4 ? 256 : 384);
+  return K >= 3 && C > 16 && (ctail == 0 || ctail > 16) && nrep >= min_rep && N >= 4 * I8_WIN_TILES * SM_T;
 }
 
 }  // namespace txm
@@ -630,6 +637,7 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
     b.part_u = (double *)((char *)ws + q.off_pu);
     b.n_chunks = q.n_chunks; b.n_rbg = q.n_rbg; b.tiles_per_chunk = q.tiles_per_chunk;
     b.nrep_pad = q.nrep_pad;
+    b.win_tiles = q.win_tiles;
     // one launch (or two, orders 5-7) per group of 32 columns; the groups reuse the partial buffers
     for (int64_t col0 = 0; col0 < C; col0 += I8_CPAD) {
       b.col0 = col0;

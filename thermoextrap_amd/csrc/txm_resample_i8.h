@@ -7,7 +7,7 @@ namespace txm {
 
 constexpr int I8_REPS = 64;        // replicates per workgroup (2 MFMA row blocks of 32)
 constexpr int I8_NSL = 7;          // signed 8-bit slices of the 51-bit fixed-point operand
-constexpr int I8_WIN_TILES = 64;   // sampler tiles per scaling window (65536 samples)
+constexpr int I8_WIN_TILES = 64;   // sampler tiles per scaling window (65536 samples); short chunks use 16 or 4
 constexpr int I8_CPAD = 32;        // columns of one MFMA column block
 constexpr int I8_WT_STRIDE = 80;   // doubles per window-table entry
 
@@ -34,7 +34,8 @@ struct I8Args {
   double *part_x;          // [n_chunks][7 digits][nrep_pad][32][K]   (zeroed by the launcher)
   double *part_u;          // [n_chunks][7 digits][nrep_pad][K]
   int n_chunks, n_rbg;
-  int64_t tiles_per_chunk; // multiple of I8_WIN_TILES
+  int64_t tiles_per_chunk; // multiple of win_tiles
+  int64_t win_tiles;       // sampler tiles per scaling window: 64, 16 or 4
   int64_t nrep_pad;
 };
 

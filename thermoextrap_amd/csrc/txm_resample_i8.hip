@@ -48,19 +48,18 @@ constexpr int I8_CNT_ROW = SM_T / 4 + 4;          // words per replicate row
 constexpr int I8_CNT_BYTES = I8_REPS * I8_CNT_ROW * 4;  // 66560
 constexpr int I8_FRAG = 1024;                     // one 32 x 32 int8 MFMA operand
 constexpr int I8_STEPS = SM_T / 32;               // k-steps per tile
-constexpr int64_t I8_WIN_SAMPLES = (int64_t)I8_WIN_TILES * SM_T;
 
 // ---------------------------------------------------------------------------
 // pre-pass: per-window maxima -> scale / descale table
 __global__ __launch_bounds__(256) void i8_window_kernel(const double *__restrict__ x, int64_t ldx,
                                                         const double *__restrict__ u,
                                                         const double *__restrict__ w, int64_t N,
-                                                        int64_t C, int64_t col0,
+                                                        int64_t C, int64_t col0, int64_t win_samples,
                                                         const double *__restrict__ pivot,
                                                         double *__restrict__ wtab) {
   const int64_t win = blockIdx.x;
-  const int64_t i0 = win * I8_WIN_SAMPLES;
-  const int64_t i1 = (i0 + I8_WIN_SAMPLES < N) ? i0 + I8_WIN_SAMPLES : N;
+  const int64_t i0 = win * win_samples;
+  const int64_t i1 = (i0 + win_samples < N) ? i0 + win_samples : N;
   const int tid = threadIdx.x, c = tid & 31, r = tid >> 5;
   __shared__ double shx[256], shu[256], shw[256];
   double mx = 0.0, mu = 0.0, mw = 0.0;
@@ -365,18 +364,19 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
     }
   };
 
-  // chunks are made of whole windows (tiles_per_chunk is a multiple of I8_WIN_TILES)
-  for (int64_t win = t_begin / I8_WIN_TILES; win * I8_WIN_TILES < t_end; ++win) {
+  // chunks are made of whole windows (tiles_per_chunk is a multiple of win_tiles)
+  const int64_t WT = a.win_tiles;
+  for (int64_t win = t_begin / WT; win * WT < t_end; ++win) {
     {
       const double *wt = a.wtab + win * I8_WT_STRIDE;
       inv_du = wt[I8_WT_INVDU];
       if constexpr (WEIGHTED) inv_w = wt[I8_WT_INVW];
       sc = wt[I8_WT_SC + cc];
     }
-    int64_t tt_end = (win + 1) * I8_WIN_TILES;
+    int64_t tt_end = (win + 1) * WT;
     if (tt_end > t_end) tt_end = t_end;
 #pragma unroll 1
-    for (int64_t t = win * I8_WIN_TILES; t < tt_end; ++t) {
+    for (int64_t t = win * WT; t < tt_end; ++t) {
       const int64_t i_tile = t * SM_T;
       const uint32_t tsize = (t == a.ntiles - 1) ? a.last_tile_size : (uint32_t)SM_T;
       int64_t wbase = i_tile;
@@ -458,7 +458,7 @@ static int launch_pass(const I8Args &a, bool weighted, hipStream_t st) {
 
 int launch_resample_i8(const I8Args &a, int K, bool weighted, hipStream_t st) {
   hipLaunchKernelGGL(i8_window_kernel, dim3((unsigned)a.nwin), dim3(256), 0, st, a.x, a.ldx_s, a.u, a.w,
-                     a.N, a.C, a.col0, a.pivot, a.wtab);
+                     a.N, a.C, a.col0, a.win_tiles * SM_T, a.pivot, a.wtab);
   TXM_LAUNCH_CHECK();
   int rc = TXM_OK;
   switch (K) {
