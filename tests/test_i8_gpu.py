@@ -121,3 +121,59 @@ def test_i8_outliers_and_pivot(eng, monkeypatch, orc):
     piv = torch.cat([st[0, 0, 1:2] + 2.0 * u.std(), st[:, 1, 0] - 3.0 * x.std(dim=0)]).contiguous()
     got2 = eng.resample_vals(x, u, order, sampler=s, pivot=piv)
     assert err(got2, got, torch.as_tensor(sc, device="cuda")[None]) < 5e-6
+
+
+def test_i8_nsamp_differs_from_ndat(eng, monkeypatch):
+    """Replicates of 3 N / 2 and N / 3 draws (cmomy's nsamp): the count-sum correction of the top digit
+    and the exact replicate weight depend on the per-tile draw counts, not on N."""
+    N, C, order, nrep = 50000, 24, 4, 64
+    x, u = data(N, C, 41)
+    sc = scale(x, u, order + 1)[None]
+    for nsamp in (N * 3 // 2, N // 3):
+        s = eng.DeviceSampler(5, nrep, N, nsamp=nsamp)
+        monkeypatch.setenv("TXM_I8", "1")
+        got = eng.resample_vals(x, u, order, sampler=s)
+        monkeypatch.setenv("TXM_I8", "0")
+        ref = eng.resample_vals(x, u, order, freq=s.freq())
+        assert (got[:, :, 0, 0] == float(nsamp)).all()
+        assert err(got, ref, sc) < 5e-13, err(got, ref, sc)
+
+
+def test_i8_weights_with_zeros_and_constant_columns(eng, monkeypatch):
+    """Zero weights, a constant observable (zero spread -> zero column scale) and an observable equal to u."""
+    N, C, order, nrep = 30000, 20, 3, 64
+    x, u = data(N, C, 43)
+    x[:, 3] = 2.5
+    x[:, 7] = u
+    w = torch.rand(N, dtype=torch.float64, device="cuda")
+    w[::5] = 0.0
+    s = eng.DeviceSampler(6, nrep, N)
+    monkeypatch.setenv("TXM_I8", "1")
+    got = eng.resample_vals(x, u, order, sampler=s, w=w)
+    monkeypatch.setenv("TXM_I8", "0")
+    ref = eng.resample_vals(x, u, order, freq=s.freq(), w=w)
+    sc = scale(x, u, order + 1)[None] + 1e-300
+    sc[:, 3, 1, :] = u.std() ** torch.arange(order + 1, dtype=torch.float64, device="cuda") * 1e-12 + 1e-300
+    assert torch.isfinite(got).all()
+    assert (got[:, 3, 1, 0] == 2.5).all() and (got[:, 3, 1, 1:].abs() < 1e-9).all()
+    mask = torch.ones(C, dtype=torch.bool, device="cuda")
+    mask[3] = False
+    assert err(got[:, mask], ref[:, mask], sc[:, mask]) < 5e-13
+
+
+def test_dispatch_thresholds(eng, monkeypatch):
+    monkeypatch.delenv("TXM_I8", raising=False)
+    big = 10_000_000
+    assert eng.resample_path(big, 32, 1000, 4) == "int8"
+    assert eng.resample_path(big, 32, 128, 4) == "int8"
+    assert eng.resample_path(big, 32, 100, 4) == "fp64"       # few replicates
+    assert eng.resample_path(big, 32, 300, 2) == "fp64"       # order 2 needs >= 384
+    assert eng.resample_path(big, 32, 400, 2) == "int8"
+    assert eng.resample_path(big, 8, 1000, 4) == "fp64"       # one 16-column FP64 block is cheaper
+    assert eng.resample_path(big, 64, 1000, 4) == "int8"      # two column groups
+    assert eng.resample_path(big, 40, 1000, 4) == "fp64"      # 8-column tail group
+    assert eng.resample_path(big, 32, 1000, 8) == "fp64"      # order 8: FP64 only
+    assert eng.resample_path(100_000, 32, 1000, 4) == "fp64"  # short series
+    monkeypatch.setenv("TXM_I8", "1")
+    assert eng.resample_path(5000, 3, 2, 1) == "int8"
+    assert eng.resample_path(500, 3, 2, 1) == "fp64"          # below one sampler tile: never
