@@ -453,6 +453,34 @@ __global__ __launch_bounds__(256) void resample_finalize_kernel(
   for (int q = 0; q < 2 * K; ++q) o[q] = st[q];
 }
 
+// finalize of the int8 path: partial sums of the observables come as [chunk x digit][power][replicate][32
+// columns] (what the accumulator tiles write contiguously), the u-row sums as [chunk x digit][replicate][K]
+template <int K>
+__global__ __launch_bounds__(256) void resample_finalize_i8_kernel(
+    const double *__restrict__ part_x, const double *__restrict__ part_u, int n_parts, int64_t nrep_pad,
+    int64_t nrep, int64_t C, const double *__restrict__ pivot, double *__restrict__ out, int64_t c_off,
+    int64_t C_total) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nrep * C) return;
+  const int64_t r = e / C, c = e % C;
+  double S0[K], S1[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) S0[j] = S1[j] = 0.0;
+  for (int ch = 0; ch < n_parts; ++ch) {
+    const double *pu_ = part_u + ((size_t)ch * nrep_pad + r) * K;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      S0[j] += pu_[j];
+      S1[j] += part_x[(((size_t)ch * K + j) * nrep_pad + r) * I8_CPAD + c];
+    }
+  }
+  double st[2 * K];
+  pivot_sums_to_state<K>(S0, S1, pivot[0], pivot[1 + c_off + c], st);
+  double *o = out + (r * C_total + c_off + c) * 2 * K;
+#pragma unroll
+  for (int q = 0; q < 2 * K; ++q) o[q] = st[q];
+}
+
 struct ResamplePlan {
   int nblk, colgroups, n_rbg, n_chunks;
   int64_t tiles_per_chunk, nrep_pad, C_pad, ntiles;
@@ -510,7 +538,7 @@ static I8Plan plan_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   p.off_px = align_up((size_t)(1 + C) * sizeof(double), 256);
   p.off_pu = p.off_px + align_up((size_t)p.n_chunks * I8_NSL * p.nrep_pad * I8_CPAD * K * sizeof(double), 256);
   p.off_wt = p.off_pu + align_up((size_t)p.n_chunks * I8_NSL * p.nrep_pad * K * sizeof(double), 256);
-  p.total = p.off_wt + align_up((size_t)p.nwin * I8_WT_STRIDE * sizeof(double), 256);
+  p.total = p.off_wt + align_up((size_t)p.nwin * I8_WT_STRIDE * sizeof(double) + 2048, 256);  // + timing slots of debug builds
   return p;
 }
 
@@ -647,8 +675,8 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
       if (rc != TXM_OK) return rc;
       const int64_t ne = nrep * b.C;
 #define TXM_I8_FIN(KK)                                                                                 \
-  hipLaunchKernelGGL((resample_finalize_kernel<KK>), dim3((unsigned)cdiv(ne, 256)), dim3(256), 0, st, \
-                     b.part_x, b.part_u, q.n_chunks * I8_NSL, q.nrep_pad, (int64_t)I8_CPAD, nrep, b.C, piv, out, col0, C)
+  hipLaunchKernelGGL((resample_finalize_i8_kernel<KK>), dim3((unsigned)cdiv(ne, 256)), dim3(256), 0, st, \
+                     b.part_x, b.part_u, q.n_chunks * I8_NSL, q.nrep_pad, nrep, b.C, piv, out, col0, C)
       switch (K) {
         case 2: TXM_I8_FIN(2); break;
         case 3: TXM_I8_FIN(3); break;

@@ -31,7 +31,7 @@ struct I8Args {
   const double *pivot;     // [1 + all columns]: {pivot_u, pivot_x[...]}, indexed with col0
   double *wtab;            // [nwin][I8_WT_STRIDE]
   int64_t nwin;
-  double *part_x;          // [n_chunks][7 digits][nrep_pad][32][K]   (zeroed by the launcher)
+  double *part_x;          // [n_chunks][7 digits][K][nrep_pad][32]   (zeroed by the launcher)
   double *part_u;          // [n_chunks][7 digits][nrep_pad][K]
   int n_chunks, n_rbg;
   int64_t tiles_per_chunk; // multiple of win_tiles

@@ -204,10 +204,13 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
   const int g2 = 2 * (lane & 7) + (lane >> 5), cslot = (lane >> 3) & 3;
   const int c = wave * 4 + cslot;
   const int64_t cc = c < a.C ? c : 0;  // columns >= C re-read column 0: their sums are never flushed
-  // u-row role: power `wave`, lanes of column slot 0
-  const bool urow = cslot == 0 && wave < JN;
+  // u-row role (lanes of column slot 0): wave jj < 4 slices the power J0 + jj; a fifth power goes to
+  // wave 7, whose tail fragments are padding (it runs fewer MFMAs), not to wave 4, which shares
+  // its SIMD with wave 0 (measured with TXM_I8_TIMING: the SIMD with two u-row waves set the pace)
+  const int jr = wave < 4 ? wave : 4;
+  const bool urow = cslot == 0 && jr < JN && (wave < 4 || wave == I8_WAVES - 1);
   const uint32_t woff = (uint32_t)(c * 32 + g2 * 2);
-  const uint32_t uoff = (uint32_t)((NPOW + (wave >> 2)) * I8_FRAG + (wave & 3) * 8 * 32 + g2 * 2);
+  const uint32_t uoff = (uint32_t)((NPOW + (jr >> 2)) * I8_FRAG + (jr & 3) * 8 * 32 + g2 * 2);
   const uint32_t roff = (uint32_t)(n32 * 32 + half * 16);
   const uint32_t aoff = (uint32_t)(n32 * I8_CNT_ROW + half * 4);
   // MFMA role: fragments [f_lo, f_hi) for both replicate halves
@@ -237,6 +240,13 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
     reinterpret_cast<uint4 *>(bb0)[e] = make_uint4(0, 0, 0, 0);
 
   double inv_du = 0.0, inv_w = 1.0, sc = 0.0;
+#ifdef TXM_I8_TIMING
+  long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long t0 = clock64();
+#define TXM_TICK(k) do { const long long t1_ = clock64(); tm[k] += t1_ - t0; t0 = t1_; } while (0)
+#else
+#define TXM_TICK(k) do {} while (0)
+#endif
 
   // ---- flush the int32 accumulators of one window into the per-digit FP64 partial sums ----
   // D layout of v_mfma_i32_32x32x32_i8: column = lane & 31, row = 8 * (reg / 4) + 4 * (lane >> 5) + reg % 4
@@ -272,20 +282,28 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
         double *base;
         int64_t stride;
         if (col >= 0) {
-          base = a.part_x + (row0 * I8_CPAD + col) * K + j;
-          stride = (int64_t)I8_CPAD * K;
+          // [chunk][digit][power][replicate][32 columns]: the lanes of a row write 256 contiguous bytes
+          base = a.part_x + ((((size_t)chunk * I8_NSL + i) * K + j) * a.nrep_pad + rep0 + 4 * half) * I8_CPAD + col;
+          stride = I8_CPAD;
         } else {
           base = a.part_u + row0 * K + j;
           stride = K;
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+          // 16 independent loads, then 16 stores: one memory round trip per tile instead of one per element
+          double old[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = 32 * h + (r >> 2) * 8 + (r & 3);
+            old[r] = valid ? base[(int64_t)m * stride] : 0.0;
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int m = 32 * h + (r >> 2) * 8 + (r & 3);
             int v = acc[e][h][r];
             if (i == I8_NSL - 1) v -= I8_D6_BIAS * (int)fsum[m + 4 * half];
-            if (valid) base[(int64_t)m * stride] += (double)v * dsc;
+            if (valid) base[(int64_t)m * stride] = old[r] + (double)v * dsc;
           }
           acc[e][h] = (v16i)(0);
         }
@@ -308,14 +326,13 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
 #ifdef TXM_I8_NO_PRODUCE
     (void)bb; (void)r; (void)wbase; (void)snext; return;
 #endif
-    double du[2], dx[2], p[2], p0[2];
+    double du[2], dx[2], p[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       du[e] = (r.u[e] - pu) * inv_du;
       dx[e] = (r.x[e] - px) * sc;
       if constexpr (WEIGHTED) p[e] = r.w[e] * inv_w;
       else p[e] = 1.0;
-      p0[e] = p[e];
     }
     load_chunk(wbase, snext, r);
 #pragma unroll
@@ -332,18 +349,15 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
       uint32_t T[4];
       i8_slice2(fma(p[0], dx[0], I8_MAGIC), fma(p[1], dx[1], I8_MAGIC), T);
       i8_store7(bb + jj * I8_NSL * I8_FRAG + woff, T, I8_FRAG);
-    }
-    // u-row: lanes of column slot 0 in wave jj < JN slice w * du^(J0 + jj); its digit i is
-    // column 8 jj + i of the packed u-row fragments
-    if (urow) {
-      double v0 = p0[0], v1 = p0[1];
-      for (int q = 0; q < J0 + wave; ++q) {  // wave-uniform trip count
-        v0 *= du[0];
-        v1 *= du[1];
+      // u-row: p is w * du^(J0 + jj) right now; the wave that owns this power slices it (dx = 1)
+      // into the columns 8 jj + i of the packed u-row fragments
+      if (jj == jr) {  // wave-uniform
+        if (urow) {
+          uint32_t U[4];
+          i8_slice2(fma(p[0], 0x1p50, I8_MAGIC), fma(p[1], 0x1p50, I8_MAGIC), U);
+          i8_store7(bb + uoff, U, 32);
+        }
       }
-      uint32_t T[4];
-      i8_slice2(fma(v0, 0x1p50, I8_MAGIC), fma(v1, 0x1p50, I8_MAGIC), T);
-      i8_store7(bb + uoff, T, 32);
     }
   };
 
@@ -358,9 +372,11 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
     const unsigned char *bf = bb + f_lo * I8_FRAG + roff;
 #pragma unroll
     for (int e = 0; e < NPW; ++e) {
-      const v4i B = *reinterpret_cast<const v4i *>(bf + e * I8_FRAG);
-      acc[e][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, B, acc[e][0], 0, 0, 0);
-      acc[e][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, B, acc[e][1], 0, 0, 0);
+      if (f_lo + e < NPOW + UF) {  // wave-uniform: only the last wave owns padding fragments
+        const v4i B = *reinterpret_cast<const v4i *>(bf + e * I8_FRAG);
+        acc[e][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, B, acc[e][0], 0, 0, 0);
+        acc[e][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, B, acc[e][1], 0, 0, 0);
+      }
     }
   };
 
@@ -383,13 +399,16 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
       if (wbase > a.N - SM_T) wbase = a.N - SM_T;  // the last tile slides its window back
       const uint32_t shift = (uint32_t)(i_tile - wbase);
 
+      TXM_TICK(7);
       I8Chunk r0;
       load_chunk(wbase, 0, r0);
 
       // ---- stage 3 of the sampler: the workgroup's 64 x 1024 count tile -------
       for (int e = threadIdx.x; e < I8_CNT_BYTES / 16; e += I8_BLOCK)
         reinterpret_cast<uint4 *>(cnt)[e] = make_uint4(0, 0, 0, 0);
+      TXM_TICK(0);
       __syncthreads();
+      TXM_TICK(1);
       {
         const int64_t rep0w = rep0 + wave * I8_REPS_WAVE;
         const uint32_t rl0 = (uint32_t)(wave * I8_REPS_WAVE);
@@ -413,23 +432,38 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
       }
       if (lane < I8_REPS_WAVE && rep0 + wave * I8_REPS_WAVE + lane < a.nrep)
         fdraws += a.counts[(size_t)(rep0 + wave * I8_REPS_WAVE + lane) * a.ntiles + t];
+      TXM_TICK(2);
       __syncthreads();
+      TXM_TICK(1);
 
       // ---- contraction: chunk s on the matrix pipe, chunk s+1 through the slicer ----
       produce(bb0, r0, wbase, 1);
+      TXM_TICK(4);
       __syncthreads();
+      TXM_TICK(5);
 #pragma unroll 1
       for (int s = 0; s < I8_STEPS; s += 2) {
         mfma_step(bb0, s);
+        TXM_TICK(3);
         produce(bb1, r0, wbase, s + 2 < I8_STEPS ? s + 2 : I8_STEPS - 1);
+        TXM_TICK(4);
         __syncthreads();
+        TXM_TICK(5);
         mfma_step(bb1, s + 1);
+        TXM_TICK(3);
         if (s + 2 < I8_STEPS) produce(bb0, r0, wbase, s + 3 < I8_STEPS ? s + 3 : I8_STEPS - 1);
+        TXM_TICK(4);
         __syncthreads();
+        TXM_TICK(5);
       }
     }
     flush(win);
+    TXM_TICK(6);
   }
+#ifdef TXM_I8_TIMING
+  if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 133))
+    for (int k = 0; k < 8; ++k) a.wtab[a.nwin * I8_WT_STRIDE + ((blockIdx.x ? 1 : 0) * 8 + wave) * 8 + k] = (double)tm[k];
+#endif
 }
 
 // ---------------------------------------------------------------------------
