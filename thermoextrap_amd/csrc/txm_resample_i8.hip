@@ -28,7 +28,7 @@
 // ceil(7K/32) further fragments.  Per sampler tile (1024 samples):
 //   1. stage 3 of the sampler fills the WG's count tile   cnt[rep][sample/4 (+pad)][4 x u8]  (65 KiB)
 //   2. 32 k-steps of 32 samples: every lane slices (1 column) x (2 samples) x (K powers)
-//      of chunk s+1 into the other B buffer while the MFMAs of chunk s run.
+//      of chunk s+1 into the other B buffer, the MFMAs of chunk s issued between the powers.
 // LDS: 65 KiB counts + 2 x (7K + ceil(7K/32)) KiB of B chunks (139 KiB at order 4).
 #include "txm_resample_i8.h"
 #include "txm_sampler.h"
@@ -321,11 +321,18 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
     }
   };
 
-  // ---- slice chunk `r` into B buffer `bb`; then refill r with chunk `snext` ----
-  auto produce = [&](unsigned char *bb, I8Chunk &r, int64_t wbase, int snext) {
-#ifdef TXM_I8_NO_PRODUCE
-    (void)bb; (void)r; (void)wbase; (void)snext; return;
-#endif
+  // ---- fused k-step: every LDS operand read of chunk s is issued first (the LDS queue is in
+  // order: a read issued behind the slicing stores would wait for all of them), then the two
+  // MFMAs of fragment e go out between the slicing of power e - 1 and power e ----
+  auto step = [&](const unsigned char *bcur, int s, unsigned char *bnxt, I8Chunk &r, int64_t wbase, int snext,
+                  bool slice, bool mf = true) {
+    const uint32_t *cw = cnt + s * 8 + aoff;
+    const v4i A0 = *reinterpret_cast<const v4i *>(cw);
+    const v4i A1 = *reinterpret_cast<const v4i *>(cw + 32 * I8_CNT_ROW);
+    const unsigned char *bf = bcur + f_lo * I8_FRAG + roff;
+    v4i B[NPW];
+#pragma unroll
+    for (int e = 0; e < NPW; ++e) B[e] = *reinterpret_cast<const v4i *>(bf + e * I8_FRAG);
     double du[2], dx[2], p[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -334,51 +341,48 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
       if constexpr (WEIGHTED) p[e] = r.w[e] * inv_w;
       else p[e] = 1.0;
     }
-    load_chunk(wbase, snext, r);
+    if (slice) load_chunk(wbase, snext, r);
 #pragma unroll
     for (int q = 0; q < J0; ++q) {
       p[0] *= du[0];
       p[1] *= du[1];
     }
+    constexpr int NIT = NPW > JN ? NPW : JN;
 #pragma unroll
-    for (int jj = 0; jj < JN; ++jj) {
-      if (jj > 0) {
-        p[0] *= du[0];
-        p[1] *= du[1];
+    for (int jj = 0; jj < NIT; ++jj) {
+#ifdef TXM_I8_NO_MFMA
+      if (false) {
+#else
+      if (mf && jj < NPW && f_lo + jj < NPOW + UF) {
+#endif
+        acc[jj][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, B[jj], acc[jj][0], 0, 0, 0);
+        acc[jj][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, B[jj], acc[jj][1], 0, 0, 0);
       }
-      uint32_t T[4];
-      i8_slice2(fma(p[0], dx[0], I8_MAGIC), fma(p[1], dx[1], I8_MAGIC), T);
-      i8_store7(bb + jj * I8_NSL * I8_FRAG + woff, T, I8_FRAG);
-      // u-row: p is w * du^(J0 + jj) right now; the wave that owns this power slices it (dx = 1)
-      // into the columns 8 jj + i of the packed u-row fragments
-      if (jj == jr) {  // wave-uniform
-        if (urow) {
-          uint32_t U[4];
-          i8_slice2(fma(p[0], 0x1p50, I8_MAGIC), fma(p[1], 0x1p50, I8_MAGIC), U);
-          i8_store7(bb + uoff, U, 32);
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef TXM_I8_NO_PRODUCE
+      if (false) {
+#else
+      if (slice && jj < JN) {
+#endif
+        if (jj > 0) {
+          p[0] *= du[0];
+          p[1] *= du[1];
+        }
+        uint32_t T[4];
+        i8_slice2(fma(p[0], dx[0], I8_MAGIC), fma(p[1], dx[1], I8_MAGIC), T);
+        i8_store7(bnxt + jj * I8_NSL * I8_FRAG + woff, T, I8_FRAG);
+        if (jj == jr) {
+          if (urow) {
+            uint32_t U[4];
+            i8_slice2(fma(p[0], 0x1p50, I8_MAGIC), fma(p[1], 0x1p50, I8_MAGIC), U);
+            i8_store7(bnxt + uoff, U, 32);
+          }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
-
-  // ---- the MFMAs of chunk s: this wave's NPW fragments x both replicate halves ----
-  auto mfma_step = [&](const unsigned char *bb, int s) {
-#ifdef TXM_I8_NO_MFMA
-    (void)bb; (void)s; return;
 #endif
-    const uint32_t *cw = cnt + s * 8 + aoff;
-    const v4i A0 = *reinterpret_cast<const v4i *>(cw);
-    const v4i A1 = *reinterpret_cast<const v4i *>(cw + 32 * I8_CNT_ROW);
-    const unsigned char *bf = bb + f_lo * I8_FRAG + roff;
-#pragma unroll
-    for (int e = 0; e < NPW; ++e) {
-      if (f_lo + e < NPOW + UF) {  // wave-uniform: only the last wave owns padding fragments
-        const v4i B = *reinterpret_cast<const v4i *>(bf + e * I8_FRAG);
-        acc[e][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, B, acc[e][0], 0, 0, 0);
-        acc[e][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, B, acc[e][1], 0, 0, 0);
-      }
-    }
-  };
 
   // chunks are made of whole windows (tiles_per_chunk is a multiple of win_tiles)
   const int64_t WT = a.win_tiles;
@@ -437,25 +441,25 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
       TXM_TICK(1);
 
       // ---- contraction: chunk s on the matrix pipe, chunk s+1 through the slicer ----
-      produce(bb0, r0, wbase, 1);
+      step(bb1, 0, bb0, r0, wbase, 1, true, false);  // prologue: slice chunk 0, no MFMAs
       TXM_TICK(4);
       __syncthreads();
       TXM_TICK(5);
 #pragma unroll 1
-      for (int s = 0; s < I8_STEPS; s += 2) {
-        mfma_step(bb0, s);
-        TXM_TICK(3);
-        produce(bb1, r0, wbase, s + 2 < I8_STEPS ? s + 2 : I8_STEPS - 1);
+      for (int s = 0; s < I8_STEPS - 2; s += 2) {
+        step(bb0, s, bb1, r0, wbase, s + 2, true);
         TXM_TICK(4);
         __syncthreads();
         TXM_TICK(5);
-        mfma_step(bb1, s + 1);
-        TXM_TICK(3);
-        if (s + 2 < I8_STEPS) produce(bb0, r0, wbase, s + 3 < I8_STEPS ? s + 3 : I8_STEPS - 1);
+        step(bb1, s + 1, bb0, r0, wbase, s + 3 < I8_STEPS ? s + 3 : I8_STEPS - 1, true);
         TXM_TICK(4);
         __syncthreads();
         TXM_TICK(5);
       }
+      step(bb0, I8_STEPS - 2, bb1, r0, wbase, I8_STEPS - 1, true);
+      __syncthreads();
+      step(bb1, I8_STEPS - 1, bb0, r0, wbase, I8_STEPS - 1, false);
+      __syncthreads();
     }
     flush(win);
     TXM_TICK(6);
