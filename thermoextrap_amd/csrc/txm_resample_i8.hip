@@ -382,7 +382,6 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-#endif
 
   // chunks are made of whole windows (tiles_per_chunk is a multiple of win_tiles)
   const int64_t WT = a.win_tiles;
