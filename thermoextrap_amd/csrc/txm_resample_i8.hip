@@ -109,7 +109,9 @@ template <bool ALL_VALID>
 __device__ __forceinline__ void i8_tile_calls(uint32_t *cnt, uint32_t k0, uint32_t k1, uint32_t r, uint32_t t,
                                               uint32_t c, uint32_t n, uint32_t rl) {
   const uint32_t first = c * 12u;
-  if (first >= n) return;
+  // ALL_VALID: the caller guarantees 12 (c + 1) <= n, so there is no branch and the two
+  // replicates of a pair share a basic block: their Philox chains interleave
+  if (!ALL_VALID && first >= n) return;
   const Philox4 o = philox4x32_10(c, t, r, 3u, k0, k1);
   const uint32_t nd = n - first;
 #pragma unroll
