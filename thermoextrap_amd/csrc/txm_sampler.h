@@ -33,6 +33,10 @@ struct Philox4 {
   uint32_t w[4];
 };
 
+// XOR3: fold the two XORs of a round into one v_bitop3_b32.  Measured on gfx950: the standalone sampler
+// kernels gain 9 % (58.8 -> 53.9 ms for stages 1+2 at N=1e8, nrep=1000), the fill phases fused into the
+// bootstrap kernels lose (int8 kernel 262 -> 271 ms), so only the former ask for it.
+template <bool XOR3 = false>
 __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                  uint32_t k0, uint32_t k1) {
   constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
@@ -43,7 +47,14 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
     const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
     const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
     const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    uint32_t n0, n2;
+    if constexpr (XOR3) {
+      n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96);  // a ^ b ^ c
+      n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
+    } else {
+      n0 = hi1 ^ c1 ^ k0;
+      n2 = hi0 ^ c3 ^ k1;
+    }
     c0 = n0;
     c1 = lo1;
     c2 = n2;

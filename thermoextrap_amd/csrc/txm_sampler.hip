@@ -54,13 +54,13 @@ __global__ __launch_bounds__(1024) void sampler_stage1_kernel(uint32_t k0, uint3
   const uint32_t last_size = (uint32_t)g.last_bin_size;
   uint32_t j = 0, m = 0;
   while (quota) {
-    const Philox4 o = philox4x32_10(j++, v, r, 1u, k0, k1key);
+    const Philox4 o = philox4x32_10<true>(j++, v, r, 1u, k0, k1key);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const uint32_t c = slot16(o, e) & mask;
       bool ok = quota && (c < nb1);
       if (ok && last_partial && c == nb1 - 1u) {
-        const Philox4 o2 = philox4x32_10(m++, v, r, 4u, k0, k1key);
+        const Philox4 o2 = philox4x32_10<true>(m++, v, r, 4u, k0, k1key);
         ok = (o2.w[0] & bsmask) < last_size;
       }
       if (ok) {
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void sampler_stage2_popc_kernel(
         const uint32_t c = c0 + (uint32_t)lane;
         const uint64_t first = (uint64_t)c * F;
         if (first < n) {
-          const Philox4 o = philox4x32_10(c, b, r, 2u, k0, k1key);
+          const Philox4 o = philox4x32_10<true>(c, b, r, 2u, k0, k1key);
           const uint32_t nd = (n - first < F) ? (uint32_t)(n - first) : F;
 #pragma unroll
           for (int wi = 0; wi < 4; ++wi) {
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void sampler_stage2_popc_kernel(
       uint32_t j = 0;
       const uint32_t c1 = b * 64u + (uint32_t)lane;
       while (quota) {
-        const Philox4 o = philox4x32_10(j++, c1, r, 5u, k0, k1key);
+        const Philox4 o = philox4x32_10<true>(j++, c1, r, 5u, k0, k1key);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const uint32_t off = slot16(o, e) & bsmask;
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64 * S2_WAVES) void sampler_stage2_kernel(
         const uint32_t c = c0 + (uint32_t)lane;
         const uint64_t first = (uint64_t)c * F;
         if (first < n) {
-          const Philox4 o = philox4x32_10(c, b, r, 2u, k0, k1key);
+          const Philox4 o = philox4x32_10<true>(c, b, r, 2u, k0, k1key);
           const uint32_t nd = (n - first < F) ? (uint32_t)(n - first) : F;
           uint32_t q = 0;
 #pragma unroll
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64 * S2_WAVES) void sampler_stage2_kernel(
       uint32_t j = 0;
       const uint32_t c1 = b * 64u + (uint32_t)lane;
       while (quota) {
-        const Philox4 o = philox4x32_10(j++, c1, r, 5u, k0, k1key);
+        const Philox4 o = philox4x32_10<true>(j++, c1, r, 5u, k0, k1key);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const uint32_t off = slot16(o, e) & bsmask;
