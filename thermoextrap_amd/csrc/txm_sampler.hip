@@ -47,7 +47,8 @@ __global__ __launch_bounds__(1024) void sampler_stage1_kernel(uint32_t k0, uint3
   const uint32_t nb1 = (uint32_t)g.nb1;
   for (uint32_t b = threadIdx.x; b < nb1; b += 1024u) bins[b] = 0u;
   __syncthreads();
-  uint64_t quota = (uint64_t)(nsamp / SM_V1) + ((int64_t)v < (nsamp % SM_V1) ? 1u : 0u);
+  // nsamp <= 16 * 2^30 (check_spec), so a lane's share of SM_V1 = 16384 lanes fits 32 bits
+  uint32_t quota = (uint32_t)(nsamp / SM_V1) + ((int64_t)v < (nsamp % SM_V1) ? 1u : 0u);
   const uint32_t mask = (1u << g.k1) - 1u;
   const bool last_partial = g.last_bin_size < g.BS;
   const uint32_t bsmask = (uint32_t)(g.BS - 1);
