@@ -183,40 +183,57 @@ struct I8Chunk {
 };
 
 // K = order + 1 fixes the layout of the partial sums; one launch slices the JN powers
-// J0 .. J0 + JN - 1 (orders above 4 take two launches: 2 x 5 accumulator tiles is what the
-// 256-register budget of a wave leaves room for).
+// J0 .. J0 + JN - 1 (orders above 4 take two launches: 10 accumulator tiles per wave is what the
+// 256-register budget leaves room for).
+//
+// B operand in LDS (per buffer):
+//   pair row (jj, w), w = 0..2: the digits 2w and 2w+1 of power jj.  Each slicing lane stores the
+//     ONE dword {d_2w(s0), d_2w(s1), d_2w+1(s0), d_2w+1(s1)} of its sample pair: [32 columns][16 pairs]
+//     dwords = 2 KiB, the pair index rotated by 4 * ((column >> 1) & 3) so that the consumer's two
+//     16-byte reads per row hit all banks.  The consumer de-interleaves with 8 v_perm_b32 into the
+//     two MFMA operands.  (LDS writes cost 4.5 CU-cycles per wave instruction whatever their width
+//     up to 32 bits, reads half of that: tools/lds_rate_probe.hip -- so the interleave is undone on
+//     the read side.)
+//   plain fragments [32 columns][32 k-bytes] = 1 KiB: digit 6 of every power (b16 stores), then the
+//     packed u-row fragments (column 8 jj + i = digit i of the u-row power jj).
 template <int K, int J0, int JN, bool WEIGHTED>
 __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
   static_assert(JN >= 1 && JN <= 5 && J0 + JN <= K, "power range");
-  constexpr int NPOW = JN * I8_NSL;         // fragments of the observable blocks
-  constexpr int UF = (8 * JN + 31) / 32;    // fragments of the packed u-row digits (column 8 jj + i)
-  constexpr int NPW = (NPOW + UF + I8_WAVES - 1) / I8_WAVES;  // fragments per wave (x 2 replicate halves)
-  constexpr int NFR = NPW * I8_WAVES;       // padded: the tail fragments stay zero
+  constexpr int NPAIR = 3 * JN;
+  constexpr int UF = (8 * JN + 31) / 32;
+  constexpr int NFRG = JN + UF;
+  constexpr int PAIR_B = 2048, FRAG0 = NPAIR * PAIR_B, BUF = FRAG0 + NFRG * I8_FRAG;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   uint32_t *cnt = reinterpret_cast<uint32_t *>(lds);
   unsigned char *bb0 = lds + I8_CNT_BYTES;
-  unsigned char *bb1 = bb0 + NFR * I8_FRAG;
-  uint32_t *fsum = reinterpret_cast<uint32_t *>(bb1 + NFR * I8_FRAG);  // [64] draws per replicate in the window
+  unsigned char *bb1 = bb0 + BUF;
+  uint32_t *fsum = reinterpret_cast<uint32_t *>(bb1 + BUF);  // [64] draws per replicate in the window
 
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int n32 = lane & 31, half = lane >> 5;
-  // slicing role: column c, sample pair g2 of every chunk.  Each half-wave (one LDS pass)
-  // holds the even or the odd pairs of 4 columns, so that its 32 b16 stores to one digit
-  // row group fall into 32 different dwords / banks.
-  const int g2 = 2 * (lane & 7) + (lane >> 5), cslot = (lane >> 3) & 3;
+  // slicing role: column c, sample pair g2 of every chunk (a half-wave = 16 pairs x 2 columns = 32
+  // consecutive dwords of a pair row)
+  const int g2 = lane & 15, cslot = lane >> 4;
   const int c = wave * 4 + cslot;
   const int64_t cc = c < a.C ? c : 0;  // columns >= C re-read column 0: their sums are never flushed
+  const uint32_t poff = (uint32_t)(c * 64 + ((g2 + 4 * ((c >> 1) & 3)) & 15) * 4);
+  const uint32_t foff = (uint32_t)(FRAG0 + c * 32 + g2 * 2);
   // u-row role (lanes of column slot 0): wave jj < 4 slices the power J0 + jj; a fifth power goes to
-  // wave 7, whose tail fragments are padding (it runs fewer MFMAs), not to wave 4, which shares
-  // its SIMD with wave 0 (measured with TXM_I8_TIMING: the SIMD with two u-row waves set the pace)
+  // wave 7 (fewest MFMAs), not to wave 4, which shares its SIMD with wave 0
   const int jr = wave < 4 ? wave : 4;
   const bool urow = cslot == 0 && jr < JN && (wave < 4 || wave == I8_WAVES - 1);
-  const uint32_t woff = (uint32_t)(c * 32 + g2 * 2);
-  const uint32_t uoff = (uint32_t)((NPOW + (jr >> 2)) * I8_FRAG + (jr & 3) * 8 * 32 + g2 * 2);
-  const uint32_t roff = (uint32_t)(n32 * 32 + half * 16);
+  const uint32_t uoff = (uint32_t)(FRAG0 + (JN + (jr >> 2)) * I8_FRAG + (jr & 3) * 8 * 32 + g2 * 2);
+  // MFMA role, the same shape for every wave (no per-wave code paths): the pair rows 2 wave and
+  // 2 wave + 1 (4 tiles each: two digits x two replicate halves) and the plain fragment `wave`
+  // (2 tiles).  Indices past the end are clamped: those tiles compute a duplicate that is never flushed.
+  const int p0i = 2 * wave, p1i = 2 * wave + 1, f2i = wave;
+  const int p0 = p0i < NPAIR ? p0i : NPAIR - 1, p1 = p1i < NPAIR ? p1i : NPAIR - 1, f2 = f2i < NFRG ? f2i : NFRG - 1;
+  static_assert(2 * I8_WAVES >= NPAIR && I8_WAVES >= NFRG, "every row and fragment has an owner");
+  const uint32_t prot = (uint32_t)((n32 >> 1) & 3);
+  const uint32_t pr0 = (uint32_t)(n32 * 64) + ((2u * half + prot) & 3u) * 16u;       // pairs 8 half .. 8 half + 3
+  const uint32_t pr1 = (uint32_t)(n32 * 64) + ((2u * half + 1u + prot) & 3u) * 16u;  // pairs 8 half + 4 .. + 7
+  const uint32_t fr = (uint32_t)(FRAG0 + n32 * 32 + half * 16);
   const uint32_t aoff = (uint32_t)(n32 * I8_CNT_ROW + half * 4);
-  // MFMA role: fragments [f_lo, f_hi) for both replicate halves
-  const int f_lo = wave * NPW;
 
   const int b = blockIdx.x;
   const int xcd = b & 7, q = b >> 3;
@@ -230,15 +247,12 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
   const double pu = a.pivot[0];
   const double px = a.pivot[1 + a.col0 + cc];
 
-  v16i acc[NPW][2];
+  v16i acc[10];  // slot 0: 0..3 = {digit a, half 0}, {a, 1}, {b, 0}, {b, 1}; slot 1: 4..7; slot 2: 8, 9
 #pragma unroll
-  for (int e = 0; e < NPW; ++e) {
-    acc[e][0] = (v16i)(0);
-    acc[e][1] = (v16i)(0);
-  }
+  for (int e = 0; e < 10; ++e) acc[e] = (v16i)(0);
 
   // rows of the B buffers that are never written (columns >= C, unused u-row columns) stay zero
-  for (int e = threadIdx.x; e < 2 * NFR * I8_FRAG / 16; e += I8_BLOCK)
+  for (int e = threadIdx.x; e < 2 * BUF / 16; e += I8_BLOCK)
     reinterpret_cast<uint4 *>(bb0)[e] = make_uint4(0, 0, 0, 0);
 
   double inv_du = 0.0, inv_w = 1.0, sc = 0.0;
@@ -253,64 +267,74 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
   // ---- flush the int32 accumulators of one window into the per-digit FP64 partial sums ----
   // D layout of v_mfma_i32_32x32x32_i8: column = lane & 31, row = 8 * (reg / 4) + 4 * (lane >> 5) + reg % 4
   uint32_t fdraws = 0;  // lane rr < 8: draws of replicate rep0 + 8 wave + rr in the current window
+  const double *wt = a.wtab;
+  // one tile: digit i of power J0 + jj; observable columns (urow_f < 0) or the packed u-row fragment urow_f
+  auto flush_tile = [&](v16i &T, int h, int jj, int i, int urow_f) {
+    bool valid;
+    if (urow_f >= 0) {
+      const int n = urow_f * 32 + n32;
+      valid = (n & 7) < I8_NSL && (n >> 3) < JN;
+      jj = valid ? n >> 3 : 0;
+      i = valid ? n & 7 : 0;
+    } else {
+      valid = n32 < a.C;
+    }
+    const int j = J0 + jj;
+    double dsc = wt[I8_WT_DSP + j] * (urow_f >= 0 ? 0x1p-50 : wt[I8_WT_DSC + n32]);
+    dsc *= (double)((int64_t)1 << (8 * i));
+    const size_t part = (size_t)chunk * I8_NSL + i;
+    double *base;
+    int64_t stride;
+    if (urow_f < 0) {
+      // [chunk][digit][power][replicate][32 columns]: the lanes of a row write 256 contiguous bytes
+      base = a.part_x + ((part * K + j) * a.nrep_pad + rep0 + 32 * h + 4 * half) * I8_CPAD + n32;
+      stride = I8_CPAD;
+    } else {
+      base = a.part_u + (part * a.nrep_pad + rep0 + 32 * h + 4 * half) * K + j;
+      stride = K;
+    }
+    double old[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) old[r] = valid ? base[(int64_t)((r >> 2) * 8 + (r & 3)) * stride] : 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r >> 2) * 8 + (r & 3);
+      int v = T[r];
+      if (i == I8_NSL - 1) v -= I8_D6_BIAS * (int)fsum[32 * h + m + 4 * half];
+      if (valid) base[(int64_t)m * stride] = old[r] + (double)v * dsc;
+    }
+    T = (v16i)(0);
+  };
   auto flush = [&](int64_t win) {
-    const double *wt = a.wtab + win * I8_WT_STRIDE;
+    wt = a.wtab + win * I8_WT_STRIDE;
     if (lane < I8_REPS_WAVE) fsum[wave * I8_REPS_WAVE + lane] = fdraws;
     fdraws = 0;
     __syncthreads();
-#pragma unroll
-    for (int e = 0; e < NPW; ++e) {
-      const int f = f_lo + e;
-      if (f < NPOW + UF) {
-        int j, i, col;
-        double dsc;
-        bool valid;
-        if (f < NPOW) {
-          j = J0 + f / I8_NSL;
-          i = f % I8_NSL;
-          col = n32;
-          dsc = wt[I8_WT_DSP + j] * wt[I8_WT_DSC + n32];
-          valid = n32 < a.C;
-        } else {
-          const int n = (f - NPOW) * 32 + n32;
-          valid = (n & 7) < I8_NSL && (n >> 3) < JN;
-          j = J0 + (valid ? n >> 3 : 0);
-          i = valid ? n & 7 : 0;
-          col = -1;
-          dsc = wt[I8_WT_DSP + j] * 0x1p-50;
-        }
-        dsc *= (double)((int64_t)1 << (8 * i));
-        const size_t row0 = ((size_t)chunk * I8_NSL + i) * a.nrep_pad + rep0 + 4 * half;
-        double *base;
-        int64_t stride;
-        if (col >= 0) {
-          // [chunk][digit][power][replicate][32 columns]: the lanes of a row write 256 contiguous bytes
-          base = a.part_x + ((((size_t)chunk * I8_NSL + i) * K + j) * a.nrep_pad + rep0 + 4 * half) * I8_CPAD + col;
-          stride = I8_CPAD;
-        } else {
-          base = a.part_u + row0 * K + j;
-          stride = K;
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          // 16 independent loads, then 16 stores: one memory round trip per tile instead of one per element
-          double old[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = 32 * h + (r >> 2) * 8 + (r & 3);
-            old[r] = valid ? base[(int64_t)m * stride] : 0.0;
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = 32 * h + (r >> 2) * 8 + (r & 3);
-            int v = acc[e][h][r];
-            if (i == I8_NSL - 1) v -= I8_D6_BIAS * (int)fsum[m + 4 * half];
-            if (valid) base[(int64_t)m * stride] = old[r] + (double)v * dsc;
-          }
-          acc[e][h] = (v16i)(0);
-        }
+    if (p0i < NPAIR) {
+      const int jj = p0i / 3, w = p0i % 3;
+      flush_tile(acc[0], 0, jj, 2 * w, -1);
+      flush_tile(acc[1], 1, jj, 2 * w, -1);
+      flush_tile(acc[2], 0, jj, 2 * w + 1, -1);
+      flush_tile(acc[3], 1, jj, 2 * w + 1, -1);
+    }
+    if (p1i < NPAIR) {
+      const int jj = p1i / 3, w = p1i % 3;
+      flush_tile(acc[4], 0, jj, 2 * w, -1);
+      flush_tile(acc[5], 1, jj, 2 * w, -1);
+      flush_tile(acc[6], 0, jj, 2 * w + 1, -1);
+      flush_tile(acc[7], 1, jj, 2 * w + 1, -1);
+    }
+    if (f2i < NFRG) {
+      if (f2i < JN) {
+        flush_tile(acc[8], 0, f2i, I8_NSL - 1, -1);
+        flush_tile(acc[9], 1, f2i, I8_NSL - 1, -1);
+      } else {
+        flush_tile(acc[8], 0, 0, 0, f2i - JN);
+        flush_tile(acc[9], 1, 0, 0, f2i - JN);
       }
     }
+#pragma unroll
+    for (int e = 0; e < 10; ++e) acc[e] = (v16i)(0);  // duplicates of clamped slots included
   };
 
   auto load_chunk = [&](int64_t wbase, int s, I8Chunk &r) {
@@ -323,57 +347,93 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
     }
   };
 
-  // ---- fused k-step: every LDS operand read of chunk s is issued first (the LDS queue is in
-  // order: a read issued behind the slicing stores would wait for all of them), then the two
-  // MFMAs of fragment e go out between the slicing of power e - 1 and power e ----
+  // the two MFMA operands of a pair row: D[0..7] = the dwords of pairs 8 half .. 8 half + 7 of this
+  // lane's column; the low halves are digit 2w, the high halves digit 2w + 1
+  auto deinterleave = [](const v4i &lo, const v4i &hi, v4i &Xa, v4i &Xb) {
+    Xa[0] = (int)__builtin_amdgcn_perm((uint32_t)lo[1], (uint32_t)lo[0], 0x05040100u);
+    Xa[1] = (int)__builtin_amdgcn_perm((uint32_t)lo[3], (uint32_t)lo[2], 0x05040100u);
+    Xa[2] = (int)__builtin_amdgcn_perm((uint32_t)hi[1], (uint32_t)hi[0], 0x05040100u);
+    Xa[3] = (int)__builtin_amdgcn_perm((uint32_t)hi[3], (uint32_t)hi[2], 0x05040100u);
+    Xb[0] = (int)__builtin_amdgcn_perm((uint32_t)lo[1], (uint32_t)lo[0], 0x07060302u);
+    Xb[1] = (int)__builtin_amdgcn_perm((uint32_t)lo[3], (uint32_t)lo[2], 0x07060302u);
+    Xb[2] = (int)__builtin_amdgcn_perm((uint32_t)hi[1], (uint32_t)hi[0], 0x07060302u);
+    Xb[3] = (int)__builtin_amdgcn_perm((uint32_t)hi[3], (uint32_t)hi[2], 0x07060302u);
+  };
+#define TXM_I8_MFMA2(T0, T1, B_) \
+  do { \
+    (T0) = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, (B_), (T0), 0, 0, 0); \
+    (T1) = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, (B_), (T1), 0, 0, 0); \
+  } while (0)
+
+  // ---- fused k-step: every LDS operand read of chunk s is issued first (the LDS queue is in order:
+  // a read issued behind the slicing stores would wait for all of them), then the MFMAs go out in
+  // pairs between the slicing of the powers ----
   auto step = [&](const unsigned char *bcur, int s, unsigned char *bnxt, I8Chunk &r, int64_t wbase, int snext,
                   bool slice, bool mf = true) {
     const uint32_t *cw = cnt + s * 8 + aoff;
     const v4i A0 = *reinterpret_cast<const v4i *>(cw);
     const v4i A1 = *reinterpret_cast<const v4i *>(cw + 32 * I8_CNT_ROW);
-    const unsigned char *bf = bcur + f_lo * I8_FRAG + roff;
-    v4i B[NPW];
-#pragma unroll
-    for (int e = 0; e < NPW; ++e) B[e] = *reinterpret_cast<const v4i *>(bf + e * I8_FRAG);
-    double du[2], dx[2], p[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      du[e] = (r.u[e] - pu) * inv_du;
-      dx[e] = (r.x[e] - px) * sc;
-      if constexpr (WEIGHTED) p[e] = r.w[e] * inv_w;
-      else p[e] = 1.0;
-    }
-    if (slice) load_chunk(wbase, snext, r);
-#pragma unroll
-    for (int q = 0; q < J0; ++q) {
-      p[0] *= du[0];
-      p[1] *= du[1];
-    }
-    constexpr int NIT = NPW > JN ? NPW : JN;
-#pragma unroll
-    for (int jj = 0; jj < NIT; ++jj) {
-#ifdef TXM_I8_NO_MFMA
-      if (false) {
-#else
-      if (mf && jj < NPW && f_lo + jj < NPOW + UF) {
-#endif
-        acc[jj][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, B[jj], acc[jj][0], 0, 0, 0);
-        acc[jj][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, B[jj], acc[jj][1], 0, 0, 0);
+    // MFMA part first (its operand registers are dead before the slicer needs its own)
+#ifndef TXM_I8_NO_MFMA
+    if (mf) {
+      {
+        const v4i Ra = *reinterpret_cast<const v4i *>(bcur + p0 * PAIR_B + pr0);
+        const v4i Rb = *reinterpret_cast<const v4i *>(bcur + p0 * PAIR_B + pr1);
+        v4i Xa, Xb;
+        deinterleave(Ra, Rb, Xa, Xb);
+        TXM_I8_MFMA2(acc[0], acc[1], Xa);
+        TXM_I8_MFMA2(acc[2], acc[3], Xb);
       }
       __builtin_amdgcn_sched_barrier(0);
-#ifdef TXM_I8_NO_PRODUCE
-      if (false) {
-#else
-      if (slice && jj < JN) {
+      {
+        const v4i Rc = *reinterpret_cast<const v4i *>(bcur + p1 * PAIR_B + pr0);
+        const v4i Rd = *reinterpret_cast<const v4i *>(bcur + p1 * PAIR_B + pr1);
+        v4i Xa, Xb;
+        deinterleave(Rc, Rd, Xa, Xb);
+        TXM_I8_MFMA2(acc[4], acc[5], Xa);
+        TXM_I8_MFMA2(acc[6], acc[7], Xb);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const v4i Re = *reinterpret_cast<const v4i *>(bcur + f2 * I8_FRAG + fr);
+      TXM_I8_MFMA2(acc[8], acc[9], Re);
+    }
 #endif
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef TXM_I8_NO_PRODUCE
+    if (slice) {
+      // one opaque per-lane base per store family, immediate offsets from it: the B buffers sit above
+      // 64 KiB, so constant-folded absolute LDS addresses would need a register each
+      uint32_t wp = (uint32_t)(bnxt - lds) + poff, wf = (uint32_t)(bnxt - lds) + foff;
+      asm volatile("" : "+v"(wp), "+v"(wf));
+      double du[2], dx[2], p[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        du[e] = (r.u[e] - pu) * inv_du;
+        dx[e] = (r.x[e] - px) * sc;
+        if constexpr (WEIGHTED) p[e] = r.w[e] * inv_w;
+        else p[e] = 1.0;
+      }
+      load_chunk(wbase, snext, r);
+#pragma unroll
+      for (int q = 0; q < J0; ++q) {
+        p[0] *= du[0];
+        p[1] *= du[1];
+      }
+#pragma unroll
+      for (int jj = 0; jj < JN; ++jj) {
         if (jj > 0) {
           p[0] *= du[0];
           p[1] *= du[1];
         }
         uint32_t T[4];
         i8_slice2(fma(p[0], dx[0], I8_MAGIC), fma(p[1], dx[1], I8_MAGIC), T);
-        i8_store7(bnxt + jj * I8_NSL * I8_FRAG + woff, T, I8_FRAG);
-        if (jj == jr) {
+        *reinterpret_cast<uint32_t *>(lds + wp + (jj * 3 + 0) * PAIR_B) = T[0];
+        *reinterpret_cast<uint32_t *>(lds + wp + (jj * 3 + 1) * PAIR_B) = T[1];
+        *reinterpret_cast<uint32_t *>(lds + wp + (jj * 3 + 2) * PAIR_B) = T[2];
+        *reinterpret_cast<uint16_t *>(lds + wf + jj * I8_FRAG) = (uint16_t)T[3];
+        // u-row: p is w * du^(J0 + jj) right now; the wave that owns this power slices it (dx = 1)
+        // into the columns 8 jj + i of the packed u-row fragments
+        if (jj == jr) {  // wave-uniform
           if (urow) {
             uint32_t U[4];
             i8_slice2(fma(p[0], 0x1p50, I8_MAGIC), fma(p[1], 0x1p50, I8_MAGIC), U);
@@ -381,8 +441,8 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
           }
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
+#endif
   };
 
   // chunks are made of whole windows (tiles_per_chunk is a multiple of win_tiles)
@@ -480,8 +540,8 @@ bool i8_supported(int64_t N, int64_t C, int64_t nrep, int K) {
 template <int K, int J0, int JN>
 static int launch_pass(const I8Args &a, bool weighted, hipStream_t st) {
   const dim3 grid((unsigned)(a.n_chunks * a.n_rbg)), block(I8_BLOCK);
-  constexpr int nfr = (JN * I8_NSL + (8 * JN + 31) / 32 + I8_WAVES - 1) / I8_WAVES * I8_WAVES;
-  const size_t lds = (size_t)I8_CNT_BYTES + 2u * (size_t)nfr * I8_FRAG + I8_REPS * sizeof(uint32_t);
+  constexpr int buf = 3 * JN * 2048 + (JN + (8 * JN + 31) / 32) * I8_FRAG;  // pair rows + plain fragments
+  const size_t lds = (size_t)I8_CNT_BYTES + 2u * (size_t)buf + I8_REPS * sizeof(uint32_t);
   if (weighted) {
     TXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_i8_kernel<K, J0, JN, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
