@@ -373,54 +373,63 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
     const uint32_t *cw = cnt + s * 8 + aoff;
     const v4i A0 = *reinterpret_cast<const v4i *>(cw);
     const v4i A1 = *reinterpret_cast<const v4i *>(cw + 32 * I8_CNT_ROW);
-    // MFMA part first (its operand registers are dead before the slicer needs its own)
+    // the operands of the first pair row are read before anything is stored (the LDS queue is in
+    // order); the MFMAs of a slot go out between the powers, the next slot's reads one power ahead
+    v4i Ra = (v4i)(0), Rb = (v4i)(0), Rc = (v4i)(0), Rd = (v4i)(0);
 #ifndef TXM_I8_NO_MFMA
     if (mf) {
-      {
-        const v4i Ra = *reinterpret_cast<const v4i *>(bcur + p0 * PAIR_B + pr0);
-        const v4i Rb = *reinterpret_cast<const v4i *>(bcur + p0 * PAIR_B + pr1);
-        v4i Xa, Xb;
-        deinterleave(Ra, Rb, Xa, Xb);
-        TXM_I8_MFMA2(acc[0], acc[1], Xa);
-        TXM_I8_MFMA2(acc[2], acc[3], Xb);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      {
-        const v4i Rc = *reinterpret_cast<const v4i *>(bcur + p1 * PAIR_B + pr0);
-        const v4i Rd = *reinterpret_cast<const v4i *>(bcur + p1 * PAIR_B + pr1);
-        v4i Xa, Xb;
-        deinterleave(Rc, Rd, Xa, Xb);
-        TXM_I8_MFMA2(acc[4], acc[5], Xa);
-        TXM_I8_MFMA2(acc[6], acc[7], Xb);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      const v4i Re = *reinterpret_cast<const v4i *>(bcur + f2 * I8_FRAG + fr);
-      TXM_I8_MFMA2(acc[8], acc[9], Re);
+      Ra = *reinterpret_cast<const v4i *>(bcur + p0 * PAIR_B + pr0);
+      Rb = *reinterpret_cast<const v4i *>(bcur + p0 * PAIR_B + pr1);
     }
 #endif
-    __builtin_amdgcn_sched_barrier(0);
-#ifndef TXM_I8_NO_PRODUCE
-    if (slice) {
-      // one opaque per-lane base per store family, immediate offsets from it: the B buffers sit above
-      // 64 KiB, so constant-folded absolute LDS addresses would need a register each
-      uint32_t wp = (uint32_t)(bnxt - lds) + poff, wf = (uint32_t)(bnxt - lds) + foff;
-      asm volatile("" : "+v"(wp), "+v"(wf));
-      double du[2], dx[2], p[2];
+    uint32_t wp = (uint32_t)(bnxt - lds) + poff, wf = (uint32_t)(bnxt - lds) + foff;
+    // opaque per-lane bases + immediate offsets: the B buffers sit above 64 KiB, so constant-folded
+    // absolute LDS addresses would take a register each
+    asm volatile("" : "+v"(wp), "+v"(wf));
+    double du[2], dx[2], p[2];
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        du[e] = (r.u[e] - pu) * inv_du;
-        dx[e] = (r.x[e] - px) * sc;
-        if constexpr (WEIGHTED) p[e] = r.w[e] * inv_w;
-        else p[e] = 1.0;
+    for (int e = 0; e < 2; ++e) {
+      du[e] = (r.u[e] - pu) * inv_du;
+      dx[e] = (r.x[e] - px) * sc;
+      if constexpr (WEIGHTED) p[e] = r.w[e] * inv_w;
+      else p[e] = 1.0;
+    }
+    if (slice) load_chunk(wbase, snext, r);
+#pragma unroll
+    for (int q = 0; q < J0; ++q) {
+      p[0] *= du[0];
+      p[1] *= du[1];
+    }
+    constexpr int NIT = JN > 3 ? JN : 3;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+#ifndef TXM_I8_NO_MFMA
+      if (mf) {
+        if (it == 0) {
+          Rc = *reinterpret_cast<const v4i *>(bcur + p1 * PAIR_B + pr0);
+          Rd = *reinterpret_cast<const v4i *>(bcur + p1 * PAIR_B + pr1);
+          v4i Xa, Xb;
+          deinterleave(Ra, Rb, Xa, Xb);
+          TXM_I8_MFMA2(acc[0], acc[1], Xa);
+          TXM_I8_MFMA2(acc[2], acc[3], Xb);
+        }
+        if (it == 1) {
+          Ra = *reinterpret_cast<const v4i *>(bcur + f2 * I8_FRAG + fr);
+          v4i Xa, Xb;
+          deinterleave(Rc, Rd, Xa, Xb);
+          TXM_I8_MFMA2(acc[4], acc[5], Xa);
+          TXM_I8_MFMA2(acc[6], acc[7], Xb);
+        }
+        if (it == 2) TXM_I8_MFMA2(acc[8], acc[9], Ra);
       }
-      load_chunk(wbase, snext, r);
-#pragma unroll
-      for (int q = 0; q < J0; ++q) {
-        p[0] *= du[0];
-        p[1] *= du[1];
-      }
-#pragma unroll
-      for (int jj = 0; jj < JN; ++jj) {
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef TXM_I8_NO_PRODUCE
+      if (false) {
+#else
+      if (slice && it < JN) {
+#endif
+        const int jj = it;
         if (jj > 0) {
           p[0] *= du[0];
           p[1] *= du[1];
@@ -441,8 +450,8 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
           }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
-#endif
   };
 
   // chunks are made of whole windows (tiles_per_chunk is a multiple of win_tiles)
