@@ -22,14 +22,14 @@
 //   Rounding: one rint per monomial at 2^-51 of the WINDOW maximum (unbiased), against
 //   2^-53 per element in FP64 -- far below the FP64 accumulation error of the sums.
 //
-// Workgroup = 8 waves, two per SIMD (256 registers each, <= 10 int32 accumulator tiles),
-// 64 replicates x all operand fragments: fragment j*7+i = digit i of power j of the 32
-// observables; the K u-row monomials (dx = 1) pack their 7K digits into the columns of
-// ceil(7K/32) further fragments.  Per sampler tile (1024 samples):
+// Workgroup = 8 waves, two per SIMD (256 registers each, 10 int32 accumulator tiles),
+// 64 replicates x all operand rows of the 32 observables (layout: see the kernel); the K
+// u-row monomials (dx = 1) pack their digits into the columns 8 j + i of ceil(8K/32) further
+// fragments.  Per sampler tile (1024 samples):
 //   1. stage 3 of the sampler fills the WG's count tile   cnt[rep][sample/4 (+pad)][4 x u8]  (65 KiB)
 //   2. 32 k-steps of 32 samples: every lane slices (1 column) x (2 samples) x (K powers)
 //      of chunk s+1 into the other B buffer, the MFMAs of chunk s issued between the powers.
-// LDS: 65 KiB counts + 2 x (7K + ceil(7K/32)) KiB of B chunks (139 KiB at order 4).
+// LDS: 65 KiB counts + 2 x (6K + K + ceil(8K/32)) KiB of B chunks (139 KiB at order 4).
 #include "txm_resample_i8.h"
 #include "txm_sampler.h"
 
