@@ -415,12 +415,14 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
         }
         if (it == 1) {
           Ra = *reinterpret_cast<const v4i *>(bcur + f2 * I8_FRAG + fr);
-          v4i Xa, Xb;
-          deinterleave(Rc, Rd, Xa, Xb);
-          TXM_I8_MFMA2(acc[4], acc[5], Xa);
-          TXM_I8_MFMA2(acc[6], acc[7], Xb);
+          if (p1i < NPAIR) {  // wave-uniform: the last wave's second row is a clamped duplicate
+            v4i Xa, Xb;
+            deinterleave(Rc, Rd, Xa, Xb);
+            TXM_I8_MFMA2(acc[4], acc[5], Xa);
+            TXM_I8_MFMA2(acc[6], acc[7], Xb);
+          }
         }
-        if (it == 2) TXM_I8_MFMA2(acc[8], acc[9], Ra);
+        if (it == 2 && f2i < NFRG) TXM_I8_MFMA2(acc[8], acc[9], Ra);
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);
