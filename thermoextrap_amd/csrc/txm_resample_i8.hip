@@ -179,7 +179,7 @@ __device__ __forceinline__ void i8_store7(unsigned char *base, const uint32_t (&
 constexpr double I8_MAGIC = 6755399441055744.0 + 141289400074368.0;
 
 struct I8Chunk {
-  double x[2], u[2], w[2];
+  double x[2];
 };
 
 // K = order + 1 fixes the layout of the partial sums; one launch slices the JN powers
@@ -208,6 +208,10 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
   unsigned char *bb0 = lds + I8_CNT_BYTES;
   unsigned char *bb1 = bb0 + BUF;
   uint32_t *fsum = reinterpret_cast<uint32_t *>(bb1 + BUF);  // [64] draws per replicate in the window
+  // the tile's scaled u deviations (u - pu) / max|u - pu| and weights w / max|w|: loaded once per tile by the
+  // whole workgroup instead of once per k-step by every lane
+  double *utile = reinterpret_cast<double *>(fsum + I8_REPS);
+  double *wtile = utile + SM_T;
 
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int n32 = lane & 31, half = lane >> 5;
@@ -342,8 +346,6 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       r.x[e] = a.x[(i + e) * a.ldx_s + a.col0 + cc];
-      r.u[e] = a.u[i + e];
-      if constexpr (WEIGHTED) r.w[e] = a.w[i + e];
     }
   };
 
@@ -368,8 +370,9 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
   // ---- fused k-step: every LDS operand read of chunk s is issued first (the LDS queue is in order:
   // a read issued behind the slicing stores would wait for all of them), then the MFMAs go out in
   // pairs between the slicing of the powers ----
-  auto step = [&](const unsigned char *bcur, int s, unsigned char *bnxt, I8Chunk &r, int64_t wbase, int snext,
-                  bool slice, bool mf = true) {
+  // (sl = the chunk held in r, sliced now; snext = the chunk loaded into r for the next call)
+  auto step = [&](const unsigned char *bcur, int s, unsigned char *bnxt, I8Chunk &r, int64_t wbase, int sl,
+                  int snext, bool slice, bool mf = true) {
     const uint32_t *cw = cnt + s * 8 + aoff;
     const v4i A0 = *reinterpret_cast<const v4i *>(cw);
     const v4i A1 = *reinterpret_cast<const v4i *>(cw + 32 * I8_CNT_ROW);
@@ -387,12 +390,14 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
     // absolute LDS addresses would take a register each
     asm volatile("" : "+v"(wp), "+v"(wf));
     double du[2], dx[2], p[2];
+    {
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      du[e] = (r.u[e] - pu) * inv_du;
-      dx[e] = (r.x[e] - px) * sc;
-      if constexpr (WEIGHTED) p[e] = r.w[e] * inv_w;
-      else p[e] = 1.0;
+      for (int e = 0; e < 2; ++e) {
+        du[e] = utile[sl * 32 + g2 * 2 + e];
+        dx[e] = (r.x[e] - px) * sc;
+        if constexpr (WEIGHTED) p[e] = wtile[sl * 32 + g2 * 2 + e];
+        else p[e] = 1.0;
+      }
     }
     if (slice) load_chunk(wbase, snext, r);
 #pragma unroll
@@ -478,6 +483,16 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
       TXM_TICK(7);
       I8Chunk r0;
       load_chunk(wbase, 0, r0);
+      {
+        const int i2 = 2 * (int)threadIdx.x;  // 512 threads x 2 samples
+        const double u0 = a.u[wbase + i2], u1 = a.u[wbase + i2 + 1];
+        utile[i2] = (u0 - pu) * inv_du;
+        utile[i2 + 1] = (u1 - pu) * inv_du;
+        if constexpr (WEIGHTED) {
+          wtile[i2] = a.w[wbase + i2] * inv_w;
+          wtile[i2 + 1] = a.w[wbase + i2 + 1] * inv_w;
+        }
+      }
 
       // ---- stage 3 of the sampler: the workgroup's 64 x 1024 count tile -------
       for (int e = threadIdx.x; e < I8_CNT_BYTES / 16; e += I8_BLOCK)
@@ -513,24 +528,24 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
       TXM_TICK(1);
 
       // ---- contraction: chunk s on the matrix pipe, chunk s+1 through the slicer ----
-      step(bb1, 0, bb0, r0, wbase, 1, true, false);  // prologue: slice chunk 0, no MFMAs
+      step(bb1, 0, bb0, r0, wbase, 0, 1, true, false);  // prologue: slice chunk 0, no MFMAs
       TXM_TICK(4);
       __syncthreads();
       TXM_TICK(5);
 #pragma unroll 1
       for (int s = 0; s < I8_STEPS - 2; s += 2) {
-        step(bb0, s, bb1, r0, wbase, s + 2, true);
+        step(bb0, s, bb1, r0, wbase, s + 1, s + 2, true);
         TXM_TICK(4);
         __syncthreads();
         TXM_TICK(5);
-        step(bb1, s + 1, bb0, r0, wbase, s + 3 < I8_STEPS ? s + 3 : I8_STEPS - 1, true);
+        step(bb1, s + 1, bb0, r0, wbase, s + 2, s + 3 < I8_STEPS ? s + 3 : I8_STEPS - 1, true);
         TXM_TICK(4);
         __syncthreads();
         TXM_TICK(5);
       }
-      step(bb0, I8_STEPS - 2, bb1, r0, wbase, I8_STEPS - 1, true);
+      step(bb0, I8_STEPS - 2, bb1, r0, wbase, I8_STEPS - 1, I8_STEPS - 1, true);
       __syncthreads();
-      step(bb1, I8_STEPS - 1, bb0, r0, wbase, I8_STEPS - 1, false);
+      step(bb1, I8_STEPS - 1, bb0, r0, wbase, I8_STEPS - 1, I8_STEPS - 1, false);
       __syncthreads();
     }
     flush(win);
@@ -552,7 +567,8 @@ template <int K, int J0, int JN>
 static int launch_pass(const I8Args &a, bool weighted, hipStream_t st) {
   const dim3 grid((unsigned)(a.n_chunks * a.n_rbg)), block(I8_BLOCK);
   constexpr int buf = 3 * JN * 2048 + (JN + (8 * JN + 31) / 32) * I8_FRAG;  // pair rows + plain fragments
-  const size_t lds = (size_t)I8_CNT_BYTES + 2u * (size_t)buf + I8_REPS * sizeof(uint32_t);
+  const size_t lds = (size_t)I8_CNT_BYTES + 2u * (size_t)buf + I8_REPS * sizeof(uint32_t) +
+                     (weighted ? 2u : 1u) * SM_T * sizeof(double);  // + the tile's u (and w)
   if (weighted) {
     TXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_i8_kernel<K, J0, JN, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
