@@ -147,7 +147,7 @@ int txm_sampler_freq(const txm_sampler_spec *spec_host, const uint32_t *counts, 
  *                  split into seven signed 8-bit digits and accumulated exactly in int32
  *                  (order 1..7; 32 columns per launch, orders above 4 in two passes over
  *                  the sampler stream; taken when every 32-column group holds more than 16 columns and
- *                  nrep >= 128 (order >= 4), 256 (order 3) or 384 (order 2)).
+ *                  nrep >= 64 (order >= 3) or 384 (order 2)).
  * txm_resample_path reports the choice; the environment variable TXM_I8=0 / TXM_I8=1
  * forces the FP64 / the int8 kernel wherever it applies.
  */

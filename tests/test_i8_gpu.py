@@ -165,8 +165,8 @@ def test_dispatch_thresholds(eng, monkeypatch):
     monkeypatch.delenv("TXM_I8", raising=False)
     big = 10_000_000
     assert eng.resample_path(big, 32, 1000, 4) == "int8"
-    assert eng.resample_path(big, 32, 128, 4) == "int8"
-    assert eng.resample_path(big, 32, 100, 4) == "fp64"       # few replicates
+    assert eng.resample_path(big, 32, 64, 4) == "int8"
+    assert eng.resample_path(big, 32, 48, 4) == "fp64"        # less than one replicate group
     assert eng.resample_path(big, 32, 300, 2) == "fp64"       # order 2 needs >= 384
     assert eng.resample_path(big, 32, 400, 2) == "int8"
     assert eng.resample_path(big, 8, 1000, 4) == "fp64"       # one 16-column FP64 block is cheaper

@@ -550,11 +550,11 @@ static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   if (e && e[0] == '0') return false;
   if (e && e[0] == '1') return true;
   // measured on MI355X (tools/i8_sweep.py, N = 1e7): C <= 16 runs one 16-column FP64 block and stays
-  // ahead; with two blocks the int8 kernel wins from 128 replicates on at order >= 4 (1.16x; 1.6x at
-  // 1000) and from ~400 at order 2 (1.2x; 1.44x at 1000).  The last column group must also hold more
-  // than 16 columns.
+  // ahead; with two blocks the int8 kernel wins from one full replicate group on at order >= 3 (order 4:
+  // 1.2x at 64 replicates, 1.5x at 128, 1.6x from 400) and from ~400 replicates at order 2 (1.2x).  The
+  // last column group must also hold more than 16 columns.
   const int64_t ctail = C % I8_CPAD;
-  const int64_t min_rep = K >= 5 ? 128 : (K == 4 ? 256 : 384);
+  const int64_t min_rep = K >= 4 ? 64 : 384;
   return K >= 3 && C > 16 && (ctail == 0 || ctail > 16) && nrep >= min_rep && N >= 4 * I8_WIN_TILES * SM_T;
 }
 

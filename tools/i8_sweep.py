@@ -4,10 +4,10 @@ sys.path.insert(0, ".")
 from thermoextrap_amd import engine as eng
 from bench import make_data
 N = 10_000_000
-for C in (8, 16, 20, 24, 32):
+for C in (20, 32):
     x, u = make_data(N, C, 0, torch)
-    for order in (2, 4):
-        for nrep in (64, 200, 1000):
+    for order in (2, 3, 4):
+        for nrep in (64, 128, 200, 300, 400):
             s = eng.DeviceSampler(1, nrep, N)
             t = {}
             for mode in ("1", "0"):
