@@ -286,6 +286,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
+            "arithmetic": ("f64 in / out; inside the bootstrap kernel 51-bit fixed point as seven int8 digits with exact int32 "
+                           "accumulation, FP64 partial sums" if path == "int8" else "f64 throughout"),
             "data": "synthetic",
             "config": {
                 "workload": f"central-comoment bootstrap, N_samp={N:.0e}, N_obs={C}, order={order}, nrep={nrep}, "
