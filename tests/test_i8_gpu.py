@@ -177,3 +177,31 @@ def test_dispatch_thresholds(eng, monkeypatch):
     monkeypatch.setenv("TXM_I8", "1")
     assert eng.resample_path(5000, 3, 2, 1) == "int8"
     assert eng.resample_path(500, 3, 2, 1) == "fp64"          # below one sampler tile: never
+
+
+def test_non_finite_samples_propagate(eng, monkeypatch):
+    """A NaN / inf sample poisons exactly what it poisons in the FP64 kernel: its observable column for
+    every replicate (0 * NaN inside the contraction), or everything when it sits in u."""
+    N, C, order, nrep = 70000, 20, 4, 64
+    x, u = data(N, C, 51)
+    s = eng.DeviceSampler(8, nrep, N)
+    xb = x.clone()
+    xb[12345, 3] = float("nan")
+    xb[60000, 7] = float("inf")
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TXM_I8", mode)
+        outs[mode] = eng.resample_vals(xb, u, order, sampler=s)
+    monkeypatch.setenv("TXM_I8", "0")
+    clean = eng.resample_vals(x, u, order, sampler=s)
+    sc = scale(x, u, order + 1)[None]
+    for mode, o in outs.items():
+        assert torch.isnan(o[:, 3, 1, :]).all() and not torch.isfinite(o[:, 7, 1, :]).any(), mode
+        good = [c for c in range(C) if c not in (3, 7)]
+        assert torch.isfinite(o[:, good]).all(), mode
+        assert err(o[:, good], clean[:, good], sc[:, good]) < 5e-13, mode
+    ub = u.clone()
+    ub[5] = float("inf")
+    monkeypatch.setenv("TXM_I8", "1")
+    o = eng.resample_vals(x, ub, order, sampler=s)
+    assert not torch.isfinite(o[:, :, :, 1:]).any()

@@ -62,16 +62,35 @@ __global__ __launch_bounds__(256) void i8_window_kernel(const double *__restrict
   const int64_t i1 = (i0 + win_samples < N) ? i0 + win_samples : N;
   const int tid = threadIdx.x, c = tid & 31, r = tid >> 5;
   __shared__ double shx[256], shu[256], shw[256];
+  // non-finite samples: fmax drops NaN, so track them separately and poison the window's descale
+  // factors -- the sums then come out NaN, as they do from the FP64 kernel (0 * NaN in the MFMA)
+  __shared__ int badx[32], badu;
+  if (tid < 32) badx[tid] = 0;
+  if (tid == 0) badu = 0;
+  __syncthreads();
   double mx = 0.0, mu = 0.0, mw = 0.0;
+  bool bx = false, bu = false;
   if (c < C) {
     const double px = pivot[1 + col0 + c];
-    for (int64_t i = i0 + r; i < i1; i += 8) mx = fmax(mx, fabs(x[i * ldx + col0 + c] - px));
+    for (int64_t i = i0 + r; i < i1; i += 8) {
+      const double v = fabs(x[i * ldx + col0 + c] - px);
+      bx |= !(v <= 1.7976931348623157e308);
+      mx = fmax(mx, v);
+    }
   }
   const double pu = pivot[0];
   for (int64_t i = i0 + tid; i < i1; i += 256) {
-    mu = fmax(mu, fabs(u[i] - pu));
-    if (w) mw = fmax(mw, fabs(w[i]));
+    const double v = fabs(u[i] - pu);
+    bu |= !(v <= 1.7976931348623157e308);
+    mu = fmax(mu, v);
+    if (w) {
+      const double vw = fabs(w[i]);
+      bu |= !(vw <= 1.7976931348623157e308);
+      mw = fmax(mw, vw);
+    }
   }
+  if (bx) atomicOr(&badx[c], 1);
+  if (bu) atomicOr(&badu, 1);
   shx[tid] = mx;
   shu[tid] = mu;
   shw[tid] = mw;
@@ -89,7 +108,7 @@ __global__ __launch_bounds__(256) void i8_window_kernel(const double *__restrict
   if (tid == 0) {
     wt[I8_WT_INVDU] = dumax > 0.0 ? 1.0 / dumax : 0.0;
     wt[I8_WT_INVW] = wmax > 0.0 ? 1.0 / wmax : 0.0;
-    double d = wmax;
+    double d = badu ? __longlong_as_double(0x7ff8000000000000ll) : wmax;
     for (int j = 0; j < 10; ++j) {
       wt[I8_WT_DSP + j] = d;
       d *= dumax;
@@ -98,7 +117,7 @@ __global__ __launch_bounds__(256) void i8_window_kernel(const double *__restrict
   if (tid < 32) {
     const double m = shx[tid];
     wt[I8_WT_SC + tid] = m > 0.0 ? 0x1p50 / m : 0.0;
-    wt[I8_WT_DSC + tid] = m * 0x1p-50;
+    wt[I8_WT_DSC + tid] = badx[tid] ? __longlong_as_double(0x7ff8000000000000ll) : m * 0x1p-50;
   }
 }
 
