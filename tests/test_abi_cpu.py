@@ -78,3 +78,24 @@ def test_product_never_imports_oracle():
     pat = re.compile(r"^\s*(from|import)\s+oracle\b|importlib.*oracle|liboracle", re.M)
     for p in pkg.rglob("*.py"):
         assert not pat.search(p.read_text()), f"{p} reaches into oracle/"
+
+
+def test_workspace_and_path_queries_are_pure_host_logic(lib, monkeypatch):
+    """Sizing and dispatch queries need no device: the int8-sliced kernel is chosen where it was
+    measured to win, the workspace covers whichever kernel runs, TXM_I8 overrides."""
+    monkeypatch.delenv("TXM_I8", raising=False)
+    big = 100_000_000
+    assert lib.txm_resample_path(big, 32, 1000, 4) == 1
+    assert lib.txm_resample_path(big, 32, 32, 4) == 0       # less than one 64-replicate group
+    assert lib.txm_resample_path(big, 8, 1000, 4) == 0      # a single 16-column FP64 block is cheaper
+    assert lib.txm_resample_path(big, 32, 1000, 8) == 0     # order 8: FP64 kernel only
+    assert lib.txm_resample_path(10_000, 32, 1000, 4) == 0  # short series
+    w_small = lib.txm_resample_vals_ws_bytes(1_000_000, 32, 64, 4)
+    w_big = lib.txm_resample_vals_ws_bytes(1_000_000, 32, 1000, 4)
+    assert 0 < w_small < w_big < 2**33
+    assert lib.txm_resample_vals_ws_bytes(0, 32, 64, 4) == 0
+    monkeypatch.setenv("TXM_I8", "0")
+    assert lib.txm_resample_path(big, 32, 1000, 4) == 0
+    monkeypatch.setenv("TXM_I8", "1")
+    assert lib.txm_resample_path(5000, 3, 2, 1) == 1
+    assert lib.txm_resample_path(500, 3, 2, 1) == 0         # below one sampler tile: never
