@@ -1,21 +1,23 @@
 #!/usr/bin/env python
-"""bench.py -- samples/s of the order-4 central-comoment bootstrap
-(BASELINE.json metric) on MI355X.
+"""bench.py -- samples/s of the central-comoment bootstrap hot path (BASELINE.json metric) on MI355X.
 
-One "step" = `ExtrapModel.resample({"nrep": nrep}).derivs()` through the drop-in
-API on a state point whose samples are already resident in HBM: draw the
-sampler (device multinomial: stage-1/2 kernels), run the fused bootstrap kernel
-(txm_resample_vals: Philox stage 3 + FP64-MFMA contraction + finalize),
-evaluate the derivative table on the replicate states (txm_eval_poly) and copy
-the (order+1, nrep, N_obs) derivatives to the host.
+One "step" = `ExtrapModel.resample({"nrep": nrep}).derivs()` through the drop-in API on a state
+point whose samples are already resident in HBM: draw the sampler (device multinomial: stage-1/2
+kernels), run the bootstrap (txm_resample_vals: window pre-pass with the precision guard, Philox
+stage 3 fused into the contraction, finalize), evaluate the derivative table on the replicate states
+(txm_eval_poly) and copy the (order+1, nrep, N_obs) derivatives to the host.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
-  N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config north|c2|c4|c3|c5] [--mode states|replicas]
 
-Multi-GPU: independent state points / replicate slabs shard with no data-path
-collective; each rank bootstraps its own state point (own data, own nrep
-replicates) and the result slabs are all-gathered over RCCL at the end of the
-step ("scaling": "weak").  value = (ranks * N_samp) / time per step.
+Multi-GPU (one process per GPU, RCCL): `--gpus N` with N > 1 starts the N ranks itself when it is not
+already running under torch.distributed.run (child process, before anything touches the GPU) and
+relays rank 0's JSON line; under torchrun (WORLD_SIZE set) it is a rank.
+  --mode states   (default) every rank bootstraps its own state point (own data, own nrep replicates);
+                  the replicate-state slabs are all-gathered at the end of the step.  "scaling": "weak",
+                  value = ranks * N_samp / time.
+  --mode replicas every rank holds the same state point and bootstraps nrep / ranks replicates with its
+                  own seed (thermoextrap_amd.distributed.sharded_bootstrap); one all-gather.
+                  "scaling": "strong", value = N_samp / time.
 """
 
 from __future__ import annotations
@@ -23,6 +25,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -31,9 +35,16 @@ ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector = matrix peak (the microarch guide lists no fp64 row)
-INT8_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md: I8 MFMA = 2x the BF16 rate (~2.5 PF dense); 4.4 POP/s measured (tools/mfma_i8_probe2.hip)
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector = matrix peak (77.6 measured, tools/mfma_f64_peak3.hip)
+INT8_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md: I8 MFMA = 2x the BF16 rate (~2.5 PF dense)
+
+# BASELINE.json configs: shapes of the per-sample bootstrap legs
+CONFIGS = {
+    "north": dict(n_samp=1e8, n_obs=32, order=4, nrep=1000),   # the metric's own configuration
+    "c2": dict(n_samp=1e7, n_obs=8, order=4, nrep=200),
+    "c4": dict(n_samp=1e8, n_obs=32, order=6, nrep=1000),     # + per-replicate <dx/dq> (volume callback)
+}
 
 
 def parse():
@@ -41,14 +52,39 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=5)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--n-samp", type=float, default=1e8)
-    p.add_argument("--n-obs", type=int, default=32)
-    p.add_argument("--order", type=int, default=4)
-    p.add_argument("--nrep", type=int, default=1000)
+    p.add_argument("--config", default="north", choices=sorted(CONFIGS) + ["c3", "c5"])
+    p.add_argument("--mode", default="states", choices=["states", "replicas"])
+    p.add_argument("--n-samp", type=float, default=None)
+    p.add_argument("--n-obs", type=int, default=None)
+    p.add_argument("--order", type=int, default=None)
+    p.add_argument("--nrep", type=int, default=None)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-fp64-leg", action="store_true", help="skip timing the same shape with the FP64 kernel")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU baseline duration")
     p.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0: min(cores, 16), the 1-GPU box share)")
     return p.parse_args()
+
+
+def spawn_ranks(n: int) -> int:
+    """Start `n` ranks of this script under torch.distributed.run as a CHILD process (this process has
+    not touched the GPU and never execs) and relay the JSON line rank 0 prints."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = os.environ.copy()
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    return r.returncode if line is not None or r.returncode else 1
 
 
 def make_data(N, C, seed, torch):
@@ -104,8 +140,36 @@ def cpu_baseline(C, order, nrep_full, seconds, ncores):
     }
 
 
+def pmc_traffic(kernel_prefix, shape):
+    """HBM bytes per launch from the newest committed PMC summary of this workload (separate rocprofv3
+    --pmc passes of this same command, tools/collect_profiles.py) and the file it came from; (None, None)
+    if no committed profile matches this run's shape.  NOT measured in this run."""
+    import glob
+
+    for f in sorted(glob.glob(str(ROOT / "profiles" / "*_traffic.json")), reverse=True):
+        try:
+            d = json.loads(Path(f).read_text())
+        except Exception:  # noqa: BLE001
+            continue
+        wl = d.get("workload", {})
+        got = (wl.get("n_samp", 100_000_000), wl.get("n_obs", 32), wl.get("order", 4), wl.get("nrep", 1000))
+        if tuple(int(v) for v in got) != tuple(shape):
+            continue
+        for k, v in d.get("kernels", {}).items():
+            if k.startswith(kernel_prefix):
+                return v.get("hbm_bytes_per_launch"), "profiles/" + Path(f).name
+    return None, None
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+    if args.config in ("c3", "c5"):
+        from tools import bench_states  # multi-state configurations: batched reduce / bootstrap over states
+
+        return bench_states.main(args)
+
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,45 +182,75 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        world = dist.get_world_size()  # the rank count RCCL saw
     else:
         torch.cuda.set_device(0)
 
-    import thermoextrap_amd as txa
-    from thermoextrap_amd import engine
-
-    txa.require_gpu(torch.cuda.current_device())
-
-    N, C, order, nrep = int(args.n_samp), args.n_obs, args.order, args.nrep
-    K = order + 1
-    x, u = make_data(N, C, seed=1000 + rank, torch=torch)
-
-    # ---- the state point through the public drop-in API -----------------------------
-    # DataCentralMomentsVals.from_vals reduces the samples once (txm_reduce_vals);
-    # ExtrapModel.resample({"nrep": n}) draws the sampler and bootstraps
-    # (txm_sampler_tile_counts + txm_resample_vals); .derivs() evaluates the
-    # derivative table on the replicate states (txm_eval_poly) and copies the
-    # (order+1, nrep, N_obs) result to the host.
     import thermoextrap_amd as xtrap
+    from thermoextrap_amd import distributed as txd
+    from thermoextrap_amd import engine
     from thermoextrap_amd.moments import DeviceDataArray
 
+    xtrap.require_gpu(torch.cuda.current_device())
+
+    cfg = dict(CONFIGS[args.config])
+    for k, v in (("n_samp", args.n_samp), ("n_obs", args.n_obs), ("order", args.order), ("nrep", args.nrep)):
+        if v is not None:
+            cfg[k] = v
+    N, C, order, nrep = int(cfg["n_samp"]), int(cfg["n_obs"]), int(cfg["order"]), int(cfg["nrep"])
+    K = order + 1
+    replicas = args.mode == "replicas" and world > 1
+    # states mode: every rank its own state point; replicas mode: the same state point on every rank
+    x, u = make_data(N, C, seed=1000 + (0 if replicas else rank), torch=torch)
+
+    # ---- the state point through the public drop-in API -----------------------------
     xv = DeviceDataArray(x, ("rec", "val"))
     uv = DeviceDataArray(u, ("rec",))
     data = xtrap.DataCentralMomentsVals.from_vals(xv=xv, uv=uv, order=order, central=True)
     xem = xtrap.beta.factory_extrapmodel(5.6, data)
     state = data.dxduave.device_values  # (C, 2, K)
     pivot = torch.cat([state[0, 0, 1:2], state[:, 1, 0]]).contiguous()  # {<u>, <x_c>}
-    sampler = engine.DeviceSampler(seed=0, nrep=nrep, ndat=N)
-    out = torch.empty((nrep, C, 2, K), dtype=torch.float64, device="cuda")
     results = {}
 
+    # C4: the volume callback's per-replicate <dx/dq> is a second, order-0 bootstrap over the same sampler
+    dxdq = None
+    if args.config == "c4":
+        dxdq, _ = make_data(N, C, seed=5000 + rank, torch=torch)
+
+    # live per-call timing of the bootstrap entry point inside the timed region: HIP events recorded on
+    # the stream the kernels are launched on (torch's current stream), around every engine.resample_vals call
+    boot_events = []
+    recording = {"on": False}
+    _resample_vals = engine.resample_vals
+
+    def resample_vals_timed(*a, **kw):
+        if not recording["on"]:
+            return _resample_vals(*a, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = _resample_vals(*a, **kw)
+        e1.record()
+        boot_events.append((e0, e1))
+        return out
+
+    engine.resample_vals = resample_vals_timed
+
+    def one_bootstrap(n_rep, seed):
+        boot = xem.resample(sampler={"nrep": n_rep, "device": True, "seed": seed})
+        results["derivs"] = boot.derivs(norm=False)  # host labelled array (order+1, rep, val)
+        if dxdq is not None:
+            smp = engine.DeviceSampler(seed=seed, nrep=n_rep, ndat=N)
+            results["dxdq"] = engine.resample_vals(dxdq, u, 0, sampler=smp)[:, :, 1, 0]
+        return boot.data.dxduave.device_values
+
     def step(i):
-        boot = xem.resample(sampler={"nrep": nrep, "device": True, "seed": 12345 + 1000 * i + rank})
-        derivs = boot.derivs(norm=False)  # host labelled array (order+1, rep, val)
-        results["derivs"] = derivs
-        if world > 1:
-            slab = boot.data.dxduave.device_values
-            gathered = [torch.empty_like(slab) for _ in range(world)]
-            dist.all_gather(gathered, slab)  # final gather of the replicate slabs over xGMI
+        seed = 12345 + 1000 * i
+        if replicas:
+            results["slabs"] = txd.sharded_bootstrap(one_bootstrap, nrep, seed)
+        else:
+            slab = one_bootstrap(nrep, seed + rank)
+            if world > 1:
+                results["slabs"] = txd.all_gather_slabs(slab, [nrep] * world)  # final gather over xGMI
 
     def barrier():
         if world > 1:
@@ -166,19 +260,29 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
+    recording["on"] = True
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
+    recording["on"] = False
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = 1e3 * dt / args.steps
-    value = world * N / (dt / args.steps)
+    value = (1 if replicas else world) * N / (dt / args.steps)
+    nrep_rank = len(txd.shard_range(nrep, rank, world)) if replicas else nrep
+    main_calls = [a.elapsed_time(b) for a, b in boot_events[:: (2 if dxdq is not None else 1)]]
+    t_boot = sum(main_calls) / max(len(main_calls), 1)
+    t_dxdq = None
+    if dxdq is not None:
+        d = [a.elapsed_time(b) for a, b in boot_events[1::2]]
+        t_dxdq = sum(d) / max(len(d), 1)
+    info = engine.resample_info(N, C, nrep_rank, order)
 
-    # ---- per-kernel timing with events on the launch stream (torch's current stream) -------
+    # ---- separate event timings of the other kernels of a step (same stream) -------
     def timed(fn, reps):
         evs = []
         for _ in range(reps):
@@ -188,78 +292,75 @@ def main():
             e1.record()
             evs.append((e0, e1))
         torch.cuda.synchronize()
-        ts = sorted(a.elapsed_time(b) for a, b in evs)
+        ts = [a.elapsed_time(b) for a, b in evs]
         return sum(ts) / len(ts)  # mean ms
 
-    t_boot = timed(lambda: engine.resample_vals(x, u, order, sampler=sampler, pivot=pivot, out=out), max(2, min(args.steps, 5)))
+    sampler = engine.DeviceSampler(seed=0, nrep=nrep_rank, ndat=N)
+    out = torch.empty((nrep_rank, C, 2, K), dtype=torch.float64, device="cuda")
     t_samp = timed(lambda: sampler.draw(seed=777), 3)
     t_red = timed(lambda: engine.reduce_vals(x, u, order), 10)
+    path = info["path"]
+    t_fp64 = None
+    if path == "int8" and not args.no_fp64_leg:
+        with engine.forced_path("fp64"):
+            engine.resample_vals(x, u, order, sampler=sampler, pivot=pivot, out=out)
+            t_fp64 = timed(lambda: engine.resample_vals(x, u, order, sampler=sampler, pivot=pivot, out=out), 2)
 
-    def pmc_traffic(kernel_prefix):
-        """HBM bytes per launch from the committed PMC summary (separate rocprofv3 --pmc
-        passes of this same command, tools/collect_profiles.py); None if the profiled
-        workload differs from this run's."""
-        import glob
+    shape = (N, C, order, nrep_rank)
+    alg_bytes = 8.0 * N * (C + 1)                         # samples read once
+    alg_flops = 2.0 * N * nrep_rank * K * (C + 1)         # dense contraction F.M
 
-        for f in sorted(glob.glob(str(ROOT / "profiles" / "*_traffic.json")), reverse=True):
-            try:
-                d = json.loads(Path(f).read_text())
-            except Exception:  # noqa: BLE001
-                continue
-            if (N, C, order, nrep) != (100_000_000, 32, 4, 1000):
-                return None
-            for k, v in d.get("kernels", {}).items():
-                if k.startswith(kernel_prefix):
-                    return v.get("hbm_bytes_per_launch")
-        return None
+    def fp64_block(ms, kernel, measured):
+        tf = alg_flops / (ms * 1e-3) / 1e12
+        tr, src = pmc_traffic("txm::resample_kernel", shape)
+        return {
+            "kernel": kernel, "bound": "mfma", "pipe": "fp64", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": tf / FP64_PEAK_TFLOPS, "traffic": tr, "traffic_source": src, "ms": ms, "measured": measured,
+            "algorithmic_flops": alg_flops, "algorithmic_bytes": alg_bytes,
+            "hbm_achieved_GBs": alg_bytes / (ms * 1e-3) / 1e9, "hbm_frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "note": "flops = 2*N*nrep*K*(N_obs+1) executed on v_mfma_f64_16x16x4_f64 (dense F.M, SURVEY 8(d)); fp64 "
+                    "peak 78.6 TF (vector = matrix); max attainable HBM fraction of this workload is ~1 %",
+        }
 
-    alg_bytes = 8.0 * N * (C + 1)                    # SURVEY 8(d): samples read once
-    alg_flops = 2.0 * N * nrep * K * (C + 1)         # SURVEY 8(d): dense contraction F.M
-    path = engine.resample_path(N, C, nrep, order)
-    tf = alg_flops / (t_boot * 1e-3) / 1e12
+    live = "HIP events around every txm_resample_vals call of the timed steps (window pre-pass + guard list + memset + contraction + finalize)"
+    roofline_fp64 = None
     if path == "int8":
-        # executed int8 MACs: 64-replicate groups x padded sample tiles x (8 * ceil((7K + ceil(8K/32)) / 8)) operand fragments of 32 columns
-        nfr = -(-(7 * K + -(-8 * K // 32)) // 8) * 8
-        i8_ops = 2.0 * (-(-nrep // 64) * 64) * (-(-N // 1024) * 1024) * nfr * 32
+        # executed int8 operations: what the 8 waves of a workgroup issue per k-step (txm_resample_i8.hip: two
+        # pair rows x 4 tiles + one plain fragment x 2 tiles per wave, minus the slots past the last row)
+        passes = {2: [2], 3: [3], 4: [4], 5: [5], 6: [3, 3], 7: [4, 3], 8: [4, 4]}[K]
+        n_mfma = 0  # v_mfma_i32_32x32x32_i8 issued per workgroup and k-step (32 samples x 64 replicates), all passes
+        for jn in passes:
+            npair, nfrg = 3 * jn, jn + -(-8 * jn // 32)
+            n_mfma += sum(4 * (2 * wv < npair) + 4 * (2 * wv + 1 < npair) + 2 * (wv < nfrg) for wv in range(8))
+        ksteps = -(-nrep_rank // 64) * (-(-N // 1024) * 32) * -(-C // 32)   # replicate groups x k-steps x column groups
+        i8_ops = 2.0 * 32 * 32 * 32 * n_mfma * ksteps
+        tops = i8_ops / (t_boot * 1e-3) / 1e12
+        tr, src = pmc_traffic("txm::resample_i8_kernel", shape)
         roofline = {
             "kernel": "txm::resample_i8_kernel (bootstrap contraction on the int8 matrix pipe by exact 7-digit "
-                      "fixed-point slicing, Philox stage 3 fused) + window-scale, memset and finalize kernels",
-            "bound": "mfma",
-            "achieved": tf,
-            "peak": FP64_PEAK_TFLOPS,
-            "unit": "TFLOP/s",
-            "frac": tf / FP64_PEAK_TFLOPS,
-            "traffic": pmc_traffic("txm::resample_i8_kernel"),
-            "ms": t_boot,
-            "algorithmic_flops": alg_flops,
-            "algorithmic_bytes": alg_bytes,
+                      "fixed-point slicing, Philox stage 3 fused) + window-scale/guard, memset and finalize kernels",
+            "bound": "mfma-i8", "pipe": "int8",
+            "achieved": tops, "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": tops / INT8_PEAK_TOPS,
+            "traffic": tr, "traffic_source": src,
+            "ms": t_boot, "measured": live,
+            "executed_int8_ops": i8_ops,
+            "algorithmic_flops": alg_flops, "algorithmic_bytes": alg_bytes,
+            "fp64_equiv_tflops": alg_flops / (t_boot * 1e-3) / 1e12,
             "hbm_achieved_GBs": alg_bytes / (t_boot * 1e-3) / 1e9,
             "hbm_frac": alg_bytes / (t_boot * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "int8_pipe": {"executed_TOPs": i8_ops / (t_boot * 1e-3) / 1e12, "peak_TOPs": INT8_PEAK_TOPS,
-                          "frac": i8_ops / (t_boot * 1e-3) / 1e12 / INT8_PEAK_TOPS},
-            "note": "achieved = ALGORITHMIC fp64 flops 2*N*nrep*K*(N_obs+1) per second against the FP64 MFMA peak "
-                    "(78.6 TF, SURVEY 8(d)); frac > 1 because the sums run, exactly, on the int8 pipe. That pipe "
-                    "is ~20 % busy: the kernel is bound by the VALU + LDS-write work of slicing the data operand "
-                    "(DESIGN.md section 7), not by the matrix pipe",
+            "guard_windows": info["windows"], "guard_windows_fp64": info["windows_fp64"],
+            "note": "achieved = EXECUTED v_mfma_i32_32x32x32_i8 operations per second against the dense int8 peak "
+                    "(2x bf16 = 5 POP/s); fp64_equiv_tflops = the algorithmic FP64 flops 2*N*nrep*K*(N_obs+1) per "
+                    "second -- a speed, not a fraction of any roof.  The kernel is bound by the VALU + LDS-write work "
+                    "of slicing the data operand, not by the matrix pipe (DESIGN.md 4.2b)",
         }
+        if t_fp64 is not None:
+            roofline_fp64 = fp64_block(t_fp64, "txm::resample_kernel (the same shape forced onto the FP64 MFMA kernel, "
+                                       "Philox stage 3 fused)", "HIP events around 2 forced-FP64 txm_resample_vals calls after the timed region")
     else:
-        roofline = {
-            "kernel": "txm::resample_kernel (FP64 MFMA bootstrap contraction, Philox stage 3 fused)",
-            "bound": "mfma",
-            "achieved": tf,
-            "peak": FP64_PEAK_TFLOPS,
-            "unit": "TFLOP/s",
-            "frac": tf / FP64_PEAK_TFLOPS,
-            "traffic": pmc_traffic("txm::resample_kernel"),
-            "ms": t_boot,
-            "algorithmic_flops": alg_flops,
-            "algorithmic_bytes": alg_bytes,
-            "hbm_achieved_GBs": alg_bytes / (t_boot * 1e-3) / 1e9,
-            "hbm_frac": alg_bytes / (t_boot * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "note": "algorithmic flops = 2*N*nrep*K*(N_obs+1); fp64 peak 78.6 TF (vector = matrix); "
-                    "max attainable HBM fraction for this workload is ~1 % (SURVEY 8(d))",
-        }
+        roofline = fp64_block(t_boot, "txm::resample_kernel (FP64 MFMA bootstrap contraction, Philox stage 3 fused)", live)
     roofline["path"] = path
+    tr, src = pmc_traffic("txm::reduce_rowmajor_kernel", shape)
     roofline_reduce = {
         "kernel": "txm::reduce_rowmajor_kernel (one-pass power-sum reduction, the HBM-bound leg of the path)",
         "bound": "hbm",
@@ -267,15 +368,16 @@ def main():
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": alg_bytes / (t_red * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "traffic": pmc_traffic("txm::reduce_rowmajor_kernel"),
+        "traffic": tr, "traffic_source": src,
         "algorithmic_bytes": alg_bytes,
         "ms": t_red,
         "samples_per_s": N / (t_red * 1e-3),
     }
 
     if rank == 0:
+        par = f"replicate-slabs x{world} (nrep/{world} per GPU, same state point)" if replicas else f"state-points x{world}"
         rec = {
-            "metric": "samples/s for order-4 comoment bootstrap (N_samp x N_obs x nrep resample_vals)",
+            "metric": f"samples/s for order-{order} comoment bootstrap (N_samp x N_obs x nrep resample_vals)",
             "value": value,
             "unit": "samples/s",
             "n_gpus": world,
@@ -283,23 +385,28 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if replicas else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "arithmetic": ("f64 in / out; inside the bootstrap kernel 51-bit fixed point as seven int8 digits with exact int32 "
-                           "accumulation, FP64 partial sums" if path == "int8" else "f64 throughout"),
+                           "accumulation, FP64 partial sums; windows failing the precision guard on the FP64 MFMA kernel"
+                           if path == "int8" else "f64 throughout"),
             "data": "synthetic",
             "config": {
-                "workload": f"central-comoment bootstrap, N_samp={N:.0e}, N_obs={C}, order={order}, nrep={nrep}, "
-                            "exact multinomial device sampler, one state point per GPU",
+                "workload": f"{args.config}: central-comoment bootstrap, N_samp={N:.0e}, N_obs={C}, order={order}, nrep={nrep}, "
+                            "exact multinomial device sampler" + (", + order-0 bootstrap of dx/dq" if dxdq is not None else ""),
                 "n_samp": N, "n_obs": C, "order": order, "nrep": nrep,
-                "parallelism": f"state-points x{world}",
+                "parallelism": par,
             },
             "replicate_samples_per_s": value * nrep,
             "sampler_ms": t_samp,
             "roofline": roofline,
             "roofline_reduce": roofline_reduce,
         }
+        if roofline_fp64 is not None:
+            rec["roofline_fp64_path"] = roofline_fp64
+        if t_dxdq is not None:
+            rec["dxdq_bootstrap_ms"] = t_dxdq
         if world == 1 and not args.no_cpu_baseline:
             nthr = args.cpu_threads or min(os.cpu_count() or 1, 16)
             rec["cpu_baseline"] = cpu_baseline(C, order, nrep, args.cpu_seconds, nthr)

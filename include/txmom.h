@@ -148,12 +148,24 @@ int txm_sampler_freq(const txm_sampler_spec *spec_host, const uint32_t *counts, 
  *                  (order 1..7; 32 columns per launch, orders above 4 in two passes over
  *                  the sampler stream; taken when every 32-column group holds more than 16 columns and
  *                  nrep >= 64 (order >= 3) or 384 (order 2)).
- * txm_resample_path reports the choice; the environment variable TXM_I8=0 / TXM_I8=1
- * forces the FP64 / the int8 kernel wherever it applies.
+ *                  PRECISION GUARD (data dependent, automatic): the pre-pass also takes, per window, a robust
+ *                  typical magnitude of the top-power monomial (the smallest of 64 group means of
+ *                  |w du^order dx_c|); a window whose scale exceeds 275 sqrt(n) times it -- a heavy tail, an
+ *                  outlier, weights spanning decades: the rounding would no longer stay within 1e-13 of what
+ *                  the window contributes -- is contracted by the FP64 kernel instead, in the same call, and
+ *                  the two sets of partial sums are added.  Ordinary data flags nothing.
+ * txm_resample_path reports the shape-based choice; txm_set_resample_path(TXM_PATH_FP64 / TXM_PATH_INT8)
+ * forces one kernel wherever it applies, -1 restores the automatic choice (initial value: the
+ * environment variable TXM_I8=0 / TXM_I8=1, read once).  txm_resample_vals_info reads back, from the
+ * workspace of the LAST txm_resample_vals call of that shape, info_host[0] = path taken, [1] = scaling
+ * windows x column groups, [2] = how many of them the guard sent to the FP64 kernel (synchronises).
  */
 #define TXM_PATH_FP64 0
 #define TXM_PATH_INT8 1
 int txm_resample_path(int64_t N, int64_t C, int64_t nrep, int order);
+int txm_set_resample_path(int path);
+int txm_resample_vals_info(const void *ws, int64_t N, int64_t C, int64_t nrep, int order,
+                           int64_t *info_host, txm_stream stream);
 size_t txm_resample_vals_ws_bytes(int64_t N, int64_t C, int64_t nrep, int order);
 int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, const double *u,
                       const double *w, int64_t N, int64_t C, int order, int64_t nrep,

@@ -82,8 +82,8 @@ def test_product_never_imports_oracle():
 
 def test_workspace_and_path_queries_are_pure_host_logic(lib, monkeypatch):
     """Sizing and dispatch queries need no device: the int8-sliced kernel is chosen where it was
-    measured to win, the workspace covers whichever kernel runs, TXM_I8 overrides."""
-    monkeypatch.delenv("TXM_I8", raising=False)
+    measured to win, the workspace covers whichever kernel runs, txm_set_resample_path overrides."""
+    assert lib.txm_set_resample_path(-1) == 0
     big = 100_000_000
     assert lib.txm_resample_path(big, 32, 1000, 4) == 1
     assert lib.txm_resample_path(big, 32, 32, 4) == 0       # less than one 64-replicate group
@@ -94,8 +94,11 @@ def test_workspace_and_path_queries_are_pure_host_logic(lib, monkeypatch):
     w_big = lib.txm_resample_vals_ws_bytes(1_000_000, 32, 1000, 4)
     assert 0 < w_small < w_big < 2**33
     assert lib.txm_resample_vals_ws_bytes(0, 32, 64, 4) == 0
-    monkeypatch.setenv("TXM_I8", "0")
+    assert lib.txm_set_resample_path(0) == 0
     assert lib.txm_resample_path(big, 32, 1000, 4) == 0
-    monkeypatch.setenv("TXM_I8", "1")
+    assert lib.txm_set_resample_path(1) == 0
     assert lib.txm_resample_path(5000, 3, 2, 1) == 1
     assert lib.txm_resample_path(500, 3, 2, 1) == 0         # below one sampler tile: never
+    assert lib.txm_set_resample_path(7) == -1 and b"not a path" in lib.txm_last_error()
+    assert lib.txm_set_resample_path(-1) == 0
+    assert lib.txm_resample_path(big, 32, 1000, 4) == 1

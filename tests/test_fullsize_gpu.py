@@ -125,7 +125,7 @@ def test_bootstrap_fullsize_properties(eng, N, C, order, nrep):
 
 
 @pytest.mark.parametrize("N,C,order,nrep", [(10_000_000, 32, 4, 256), (100_000_000, 32, 4, 192)])
-def test_int8_path_equals_fp64_path_fullsize(eng, monkeypatch, N, C, order, nrep):
+def test_int8_path_equals_fp64_path_fullsize(eng, N, C, order, nrep):
     """The two kernels behind scale mode on the same sampler stream, every replicate (the int8
     kernel is what the benchmark shape runs; the FP64 kernel is pinned to the oracle elsewhere)."""
     x, u = synth(N, C, 13)
@@ -133,15 +133,17 @@ def test_int8_path_equals_fp64_path_fullsize(eng, monkeypatch, N, C, order, nrep
     sc = scale_of(x.std(dim=0), u.std(), K)[None]
     s = eng.DeviceSampler(99, nrep, N)
     assert eng.resample_path(N, C, nrep, order) == "int8"
-    got = eng.resample_vals(x, u, order, sampler=s)
-    monkeypatch.setenv("TXM_I8", "0")
-    assert eng.resample_path(N, C, nrep, order) == "fp64"
-    ref = eng.resample_vals(x, u, order, sampler=s)
+    got = eng.resample_vals(x, u, order, sampler=s)               # default dispatch
+    info = eng.resample_info(N, C, nrep, order)
+    assert info["path"] == "int8" and info["windows_fp64"] == 0, info   # Gaussian data: the guard flags nothing
+    with eng.forced_path("fp64"):
+        assert eng.resample_path(N, C, nrep, order) == "fp64"
+        ref = eng.resample_vals(x, u, order, sampler=s)
     close(got, ref, sc, 1e-12)
     assert torch.equal(got[:, :, 0, 0], ref[:, :, 0, 0])          # replicate weights are exact in both
-    monkeypatch.setenv("TXM_I8", "1")
     w = 0.5 + torch.rand(N, dtype=torch.float64, device="cuda")
     gw = eng.resample_vals(x, u, order, sampler=s, w=w)
-    monkeypatch.setenv("TXM_I8", "0")
-    rw = eng.resample_vals(x, u, order, sampler=s, w=w)
+    assert eng.resample_info(N, C, nrep, order)["windows_fp64"] == 0
+    with eng.forced_path("fp64"):
+        rw = eng.resample_vals(x, u, order, sampler=s, w=w)
     close(gw, rw, sc, 1e-12)

@@ -79,6 +79,12 @@ struct ResampleArgs {
   int64_t tiles_per_chunk;
   int64_t nrep_pad;         // n_rbg * 64
   int64_t C_pad;            // col groups * NBLK * 16
+  // listed mode (precision-guard fallback of the int8 path): chunk c contracts the runs list[c], list[c + n_chunks], ...
+  // of sub_tiles tiles each instead of its contiguous share; n_list[0] = number of runs (0: the launch is a no-op)
+  const uint32_t *list;
+  const uint32_t *n_list;
+  int sub_tiles;
+  int64_t col_off;          // x already points at the column group; its pivots start at pivot[1 + col_off]
 };
 
 // One wave: 16 replicates x (NBLK*16 columns) x one chunk of tiles.
@@ -175,6 +181,12 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
   const int64_t t_begin = (int64_t)chunk * a.tiles_per_chunk;
   int64_t t_end = t_begin + a.tiles_per_chunk;
   if (t_end > a.ntiles) t_end = a.ntiles;
+  const bool listed = a.list != nullptr;  // kernel argument: uniform
+  int64_t nruns = 1;
+  if (listed) {
+    nruns = (int64_t)*a.n_list;
+    if (nruns == 0) return;  // nothing flagged: the finalize kernel does not read this launch's partial sums
+  }
 
   const double pu = a.pivot[0];
   // Columns beyond C (padding of the last 16-column block) re-read column 0:
@@ -186,7 +198,7 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
   for (int bl = 0; bl < NBLK; ++bl) {
     const int64_t c = col0 + bl * 16 + row;
     ccol[bl] = c < a.C ? c : 0;
-    px[bl] = a.pivot[1 + ccol[bl]];
+    px[bl] = a.pivot[1 + a.col_off + ccol[bl]];
   }
 
   v4f64 acc[K][NBLK];
@@ -213,8 +225,18 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
     int64_t fi[EXPLICIT ? RS_GROUP : 1];  // parity mode: raw int64 counts
   };
 
-  for (int64_t t = t_begin; t < t_end; ++t) {
+  double cnt = 0.0;  // lanes kk == 0, unweighted: the replicate's draws in the contracted tiles (exact integers)
+  for (int64_t run = listed ? chunk : 0; run < nruns; run += listed ? a.n_chunks : 1) {
+  int64_t tb = t_begin, te = t_end;
+  if (listed) {
+    tb = (int64_t)a.list[run];
+    te = tb + a.sub_tiles;
+    if (te > a.ntiles) te = a.ntiles;
+  }
+  for (int64_t t = tb; t < te; ++t) {
     const int64_t i_tile = t * SM_T;
+    if constexpr (!WEIGHTED && !EXPLICIT)
+      if (kk == 0 && rep_ok) cnt += (double)a.counts[(size_t)my_rep * a.ntiles + t];
     const uint32_t tsize = (t == a.ntiles - 1) ? a.last_tile_size : (uint32_t)SM_T;
     // window of 1024 samples that is contracted for this tile
     int64_t wbase = i_tile;
@@ -390,6 +412,7 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
       __builtin_amdgcn_wave_barrier();
     }
   }
+  }
 
   // ---- write partial sums ---------------------------------------------------
   // D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
@@ -405,13 +428,7 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
         px_out[((size_t)rrow * a.C_pad + c) * K + j] = acc[j][bl][rg];
       }
   if (colgrp == 0) {
-    if constexpr (!WEIGHTED && !EXPLICIT) {
-      // lanes kk == 0 sum their replicate's tile counts of this chunk (exact integers)
-      double cnt = 0.0;
-      if (kk == 0 && rep_ok)
-        for (int64_t t = t_begin; t < t_end; ++t) cnt += (double)a.counts[(size_t)my_rep * a.ntiles + t];
-      usum[0] = cnt;  // other lane groups contribute 0
-    }
+    if constexpr (!WEIGHTED && !EXPLICIT) usum[0] = cnt;  // other lane groups contribute 0
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       double v = usum[j];
@@ -459,7 +476,8 @@ template <int K>
 __global__ __launch_bounds__(256) void resample_finalize_i8_kernel(
     const double *__restrict__ part_x, const double *__restrict__ part_u, int n_parts, int64_t nrep_pad,
     int64_t nrep, int64_t C, const double *__restrict__ pivot, double *__restrict__ out, int64_t c_off,
-    int64_t C_total) {
+    int64_t C_total, const double *__restrict__ fb_x, const double *__restrict__ fb_u, int fb_chunks,
+    int64_t fb_cpad, const uint32_t *__restrict__ n_list) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nrep * C) return;
   const int64_t r = e / C, c = e % C;
@@ -474,6 +492,17 @@ __global__ __launch_bounds__(256) void resample_finalize_i8_kernel(
       S1[j] += part_x[(((size_t)ch * K + j) * nrep_pad + r) * I8_CPAD + c];
     }
   }
+  // windows the precision guard handed to the FP64 kernel (same pivot: the sums simply add)
+  if (n_list[0] != 0u)
+    for (int ch = 0; ch < fb_chunks; ++ch) {
+      const double *pu_ = fb_u + ((size_t)ch * nrep_pad + r) * K;
+      const double *px_ = fb_x + (((size_t)ch * nrep_pad + r) * fb_cpad + c) * K;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        S0[j] += pu_[j];
+        S1[j] += px_[j];
+      }
+    }
   double st[2 * K];
   pivot_sums_to_state<K>(S0, S1, pivot[0], pivot[1 + c_off + c], st);
   double *o = out + (r * C_total + c_off + c) * 2 * K;
@@ -517,6 +546,10 @@ struct I8Plan {
   int n_rbg, n_chunks;
   int64_t tiles_per_chunk, nrep_pad, ntiles, nwin, win_tiles;
   size_t off_pivot, off_px, off_pu, off_wt, total;
+  // precision-guard fallback: window flags, run list, and the FP64 kernel's plan / partial sums for one column group
+  int sub_tiles;
+  size_t off_flag, off_list, off_nlist, off_fbx, off_fbu;
+  ResamplePlan fb;
 };
 
 static I8Plan plan_i8(int64_t N, int64_t C, int64_t nrep, int K) {
@@ -538,17 +571,35 @@ static I8Plan plan_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   p.off_px = align_up((size_t)(1 + C) * sizeof(double), 256);
   p.off_pu = p.off_px + align_up((size_t)p.n_chunks * I8_NSL * p.nrep_pad * I8_CPAD * K * sizeof(double), 256);
   p.off_wt = p.off_pu + align_up((size_t)p.n_chunks * I8_NSL * p.nrep_pad * K * sizeof(double), 256);
-  p.total = p.off_wt + align_up((size_t)p.nwin * I8_WT_STRIDE * sizeof(double) + 2048, 256);  // + timing slots of debug builds
+  p.off_flag = p.off_wt + align_up((size_t)p.nwin * I8_WT_STRIDE * sizeof(double) + 2048, 256);  // + timing slots of debug builds
+  p.sub_tiles = p.win_tiles < I8_SUB_TILES ? (int)p.win_tiles : I8_SUB_TILES;
+  p.off_list = p.off_flag + align_up((size_t)p.nwin * sizeof(uint32_t), 256);
+  p.off_nlist = p.off_list + align_up((size_t)p.nwin * (size_t)(p.win_tiles / p.sub_tiles) * sizeof(uint32_t), 256);
+  p.fb = plan_resample(N, C < I8_CPAD ? C : I8_CPAD, nrep, K);
+  p.off_fbx = p.off_nlist + 256;
+  p.off_fbu = p.off_fbx + align_up((size_t)p.fb.n_chunks * p.fb.nrep_pad * p.fb.C_pad * K * sizeof(double), 256);
+  p.total = p.off_fbu + align_up((size_t)p.fb.n_chunks * p.fb.nrep_pad * K * sizeof(double), 256);
   return p;
 }
 
 // TXM_I8=0 keeps the FP64 kernel, TXM_I8=1 takes the int8 path whenever it applies;
 // by default it is used where it pays: many replicates, enough columns to fill a block.
+// -1: automatic; TXM_PATH_FP64 / TXM_PATH_INT8: forced (txm_set_resample_path; the environment variable
+// TXM_I8=0/1 sets the initial value, read once)
+static int g_path_override = -2;
+static int path_override() {
+  if (g_path_override == -2) {
+    const char *e = getenv("TXM_I8");
+    g_path_override = (e && e[0] == '0') ? TXM_PATH_FP64 : (e && e[0] == '1') ? TXM_PATH_INT8 : -1;
+  }
+  return g_path_override;
+}
+
 static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   if (!i8_supported(N, C, nrep, K)) return false;
-  const char *e = getenv("TXM_I8");
-  if (e && e[0] == '0') return false;
-  if (e && e[0] == '1') return true;
+  const int ov = path_override();
+  if (ov == TXM_PATH_FP64) return false;
+  if (ov == TXM_PATH_INT8) return true;
   // measured on MI355X (tools/i8_sweep.py, N = 1e7): C <= 16 runs one 16-column FP64 block and stays
   // ahead; with two blocks the int8 kernel wins from one full replicate group on at order >= 3 (order 4:
   // 1.2x at 64 replicates, 1.5x at 128, 1.6x from 400) and from ~400 replicates at order 2 (1.2x).  The
@@ -561,6 +612,29 @@ static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K) {
 }  // namespace txm
 
 using namespace txm;
+
+extern "C" int txm_set_resample_path(int path) {
+  TXM_REQUIRE(path == -1 || path == TXM_PATH_FP64 || path == TXM_PATH_INT8, "set_resample_path: %d is not a path", path);
+  g_path_override = path;
+  return TXM_OK;
+}
+
+extern "C" int txm_resample_vals_info(const void *ws, int64_t N, int64_t C, int64_t nrep, int order,
+                                      int64_t *info_host, txm_stream stream) {
+  TXM_REQUIRE(ws && info_host, "resample_vals_info: null pointer");
+  TXM_REQUIRE(N >= 1 && C >= 1 && nrep >= 1 && order >= 0 && order <= TXM_MAX_ORDER, "resample_vals_info: bad shape");
+  info_host[0] = TXM_PATH_FP64;
+  info_host[1] = info_host[2] = 0;
+  if (!use_i8(N, C, nrep, order + 1)) return TXM_OK;
+  const I8Plan q = plan_i8(N, C, nrep, order + 1);
+  uint32_t nl[2] = {0, 0};
+  TXM_HIP(hipMemcpyAsync(nl, (const char *)ws + q.off_nlist, sizeof(nl), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  TXM_HIP(hipStreamSynchronize((hipStream_t)stream));
+  info_host[0] = TXM_PATH_INT8;
+  info_host[1] = q.nwin * cdiv(C, I8_CPAD);
+  info_host[2] = nl[1];
+  return TXM_OK;
+}
 
 extern "C" int txm_resample_path(int64_t N, int64_t C, int64_t nrep, int order) {
   if (N < 1 || C < 1 || nrep < 1 || order < 0 || order > TXM_MAX_ORDER) return TXM_PATH_FP64;
@@ -619,6 +693,31 @@ static int run_resample(ResampleArgs a, const ResamplePlan &p, bool weighted, bo
   TXM_LAUNCH_CHECK();
   return TXM_OK;
 }
+
+// the bootstrap kernel alone, in listed mode (device sampler, N >= one tile), partial sums left for the caller's finalize
+template <int K>
+static int run_listed_k(const ResampleArgs &a, const ResamplePlan &p, bool weighted, hipStream_t st) {
+  dim3 grid((unsigned)(p.n_chunks * p.n_rbg), (unsigned)p.colgroups), block(RS_BLOCK);
+  const size_t lds = (size_t)RS_WAVES * RS_TILE_BYTES;
+  if (p.nblk == 1) {
+    if (weighted) hipLaunchKernelGGL((resample_kernel<K, 1, true, false, false>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((resample_kernel<K, 1, false, false, false>), grid, block, lds, st, a);
+  } else {
+    if (weighted) hipLaunchKernelGGL((resample_kernel<K, 2, true, false, false>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((resample_kernel<K, 2, false, false, false>), grid, block, lds, st, a);
+  }
+  TXM_LAUNCH_CHECK();
+  return TXM_OK;
+}
+
+static int run_listed(const ResampleArgs &a, const ResamplePlan &p0, int K, bool weighted, hipStream_t st) {
+  // the plan was made for a full 32-column group; a narrower last group uses one 16-column block
+  ResamplePlan p = p0;
+  if (a.C <= 16) p.nblk = 1;
+  p.colgroups = 1;
+  TXM_K_SWITCH(K, return run_listed_k<KK>(a, p, weighted, st));
+  return TXM_OK;
+}
 }  // namespace txm
 
 extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, const double *u,
@@ -666,6 +765,24 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
     b.n_chunks = q.n_chunks; b.n_rbg = q.n_rbg; b.tiles_per_chunk = q.tiles_per_chunk;
     b.nrep_pad = q.nrep_pad;
     b.win_tiles = q.win_tiles;
+    b.wflag = (uint32_t *)((char *)ws + q.off_flag);
+    b.list = (uint32_t *)((char *)ws + q.off_list);
+    b.n_list = (uint32_t *)((char *)ws + q.off_nlist);
+    b.sub_tiles = q.sub_tiles;
+    TXM_HIP(hipMemsetAsync(b.n_list, 0, 256, st));
+    // the FP64 kernel in listed mode: contracts the windows the precision guard flags (none on ordinary data)
+    ResampleArgs f;
+    f.ldx_s = ldx_s; f.u = u; f.w = w; f.N = N; f.nrep = nrep;
+    f.freq = nullptr; f.counts = counts;
+    f.k0 = b.k0; f.k1 = b.k1;
+    f.ntiles = q.ntiles; f.last_tile_size = b.last_tile_size;
+    f.pivot = piv;
+    f.part_x = (double *)((char *)ws + q.off_fbx);
+    f.part_u = (double *)((char *)ws + q.off_fbu);
+    f.n_chunks = q.fb.n_chunks; f.n_rbg = q.fb.n_rbg; f.tiles_per_chunk = q.fb.tiles_per_chunk;
+    f.nrep_pad = q.fb.nrep_pad; f.C_pad = q.fb.C_pad;
+    f.list = b.list; f.n_list = b.n_list; f.sub_tiles = q.sub_tiles;
+    TXM_REQUIRE(q.fb.nrep_pad == q.nrep_pad, "resample_vals: replicate padding of the two kernels differs");
     // one launch (or two, orders 5-7) per group of 32 columns; the groups reuse the partial buffers
     for (int64_t col0 = 0; col0 < C; col0 += I8_CPAD) {
       b.col0 = col0;
@@ -673,10 +790,16 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
       TXM_HIP(hipMemsetAsync(b.part_x, 0, q.off_wt - q.off_px, st));
       const int rc = launch_resample_i8(b, K, w != nullptr, st);
       if (rc != TXM_OK) return rc;
+      f.x = x + col0; f.C = b.C; f.col_off = col0;
+      {
+        const int rc2 = run_listed(f, q.fb, K, w != nullptr, st);
+        if (rc2 != TXM_OK) return rc2;
+      }
       const int64_t ne = nrep * b.C;
 #define TXM_I8_FIN(KK)                                                                                 \
   hipLaunchKernelGGL((resample_finalize_i8_kernel<KK>), dim3((unsigned)cdiv(ne, 256)), dim3(256), 0, st, \
-                     b.part_x, b.part_u, q.n_chunks * I8_NSL, q.nrep_pad, nrep, b.C, piv, out, col0, C)
+                     b.part_x, b.part_u, q.n_chunks * I8_NSL, q.nrep_pad, nrep, b.C, piv, out, col0, C,   \
+                     f.part_x, f.part_u, q.fb.n_chunks, q.fb.C_pad, b.n_list)
       switch (K) {
         case 2: TXM_I8_FIN(2); break;
         case 3: TXM_I8_FIN(3); break;
@@ -722,6 +845,7 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
   a.part_u = (double *)((char *)ws + p.off_pu);
   a.n_chunks = p.n_chunks; a.n_rbg = p.n_rbg; a.tiles_per_chunk = p.tiles_per_chunk;
   a.nrep_pad = p.nrep_pad; a.C_pad = p.C_pad;
+  a.list = nullptr; a.n_list = nullptr; a.sub_tiles = 0; a.col_off = 0;
   TXM_K_SWITCH(K, return run_resample<KK>(a, p, w != nullptr, explicit_, out, st));
   return TXM_OK;
 }

@@ -10,6 +10,14 @@ constexpr int I8_NSL = 7;          // signed 8-bit slices of the 51-bit fixed-po
 constexpr int I8_WIN_TILES = 64;   // sampler tiles per scaling window (65536 samples); short chunks use 16 or 4
 constexpr int I8_CPAD = 32;        // columns of one MFMA column block
 constexpr int I8_WT_STRIDE = 80;   // doubles per window-table entry
+constexpr int I8_SUB_TILES = 8;    // tiles per entry of the FP64 fallback list (a flagged window = win_tiles / 8 runs)
+
+// Precision guard.  One rint per monomial at 2^-50 of the window's scale M = max|w| max|du|^j max|dx_c|: a window of n
+// samples contributes an error of ~0.41 * 2^-50 * M * sqrt(n) to a replicate's sum (sum f^2 ~ 2n, uniform rounding).
+// Held against the window's TYPICAL content n * typ, typ = a robust mean of |w du^j dx_c| (the smallest of 64 group
+// means: a handful of outliers cannot inflate it), that is within 1e-13 as long as  M <= I8_GUARD * sqrt(n) * typ.
+// M / typ grows with j, so only the top power is tested.  Windows that fail are contracted by the FP64 kernel.
+constexpr double I8_GUARD = 275.0;  // 1e-13 / (0.41 * 2^-50)
 
 // Window table entry w (doubles):  [0] 1/max|u-pu|   [1] 1/max|w| (1 when unweighted)
 //   [2 + j]      descale of power j      = max|w| * max|u-pu|^j          (j < 9)
@@ -37,6 +45,11 @@ struct I8Args {
   int64_t tiles_per_chunk; // multiple of win_tiles
   int64_t win_tiles;       // sampler tiles per scaling window: 64, 16 or 4
   int64_t nrep_pad;
+  // precision guard: flag[w] != 0 -> window w is left to the FP64 kernel (run list built by i8_list_kernel)
+  uint32_t *wflag;         // [nwin]
+  uint32_t *list;          // [nwin * (win_tiles / sub_tiles)] first tile of every run; n_list[0] = runs, n_list[1] += flagged windows
+  uint32_t *n_list;
+  int sub_tiles;           // tiles per run: min(I8_SUB_TILES, win_tiles)
 };
 
 // true when the int8 path can take this problem (device-sampler mode only)

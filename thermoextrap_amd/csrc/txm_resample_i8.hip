@@ -50,61 +50,111 @@ constexpr int I8_FRAG = 1024;                     // one 32 x 32 int8 MFMA opera
 constexpr int I8_STEPS = SM_T / 32;               // k-steps per tile
 
 // ---------------------------------------------------------------------------
-// pre-pass: per-window maxima -> scale / descale table
+// pre-pass: per-window maxima -> scale / descale table, and the precision guard (txm_resample_i8.h):
+// next to the maxima every thread keeps the mean of |w du^J dx_c| (J = the top power) over 8 consecutive
+// eighths of its rows; the smallest of a column's 64 group means (8 threads x 8 eighths) is the window's
+// typical monomial.  typ must not be the plain mean: ONE 1e4-sigma sample owns the mean of du^4 over its
+// window, and the replicates that do not draw it (37 %) see only the other samples -- which the window's
+// scale would have rounded away.
 __global__ __launch_bounds__(256) void i8_window_kernel(const double *__restrict__ x, int64_t ldx,
                                                         const double *__restrict__ u,
                                                         const double *__restrict__ w, int64_t N,
                                                         int64_t C, int64_t col0, int64_t win_samples,
-                                                        const double *__restrict__ pivot,
-                                                        double *__restrict__ wtab) {
+                                                        const double *__restrict__ pivot, int J,
+                                                        double *__restrict__ wtab,
+                                                        uint32_t *__restrict__ wflag) {
   const int64_t win = blockIdx.x;
   const int64_t i0 = win * win_samples;
   const int64_t i1 = (i0 + win_samples < N) ? i0 + win_samples : N;
   const int tid = threadIdx.x, c = tid & 31, r = tid >> 5;
-  __shared__ double shx[256], shu[256], shw[256];
+  __shared__ double shx[256], shu[256], shw[256], shg[256], shs[256];
+  __shared__ int shn[256];
   // non-finite samples: fmax drops NaN, so track them separately and poison the window's descale
   // factors -- the sums then come out NaN, as they do from the FP64 kernel (0 * NaN in the MFMA)
-  __shared__ int badx[32], badu;
+  __shared__ int badx[32], badu, flagged;
   if (tid < 32) badx[tid] = 0;
-  if (tid == 0) badu = 0;
+  if (tid == 0) badu = flagged = 0;
   __syncthreads();
-  double mx = 0.0, mu = 0.0, mw = 0.0;
+  const double pu = pivot[0];
+  const double kInf = __longlong_as_double(0x7ff0000000000000ll);
+  double mx = 0.0, mu = 0.0, mw = 0.0, gmin = kInf;
   bool bx = false, bu = false;
   if (c < C) {
     const double px = pivot[1 + col0 + c];
-    for (int64_t i = i0 + r; i < i1; i += 8) {
-      const double v = fabs(x[i * ldx + col0 + c] - px);
-      bx |= !(v <= 1.7976931348623157e308);
-      mx = fmax(mx, v);
+    const int64_t gs = win_samples / 8;  // rows per eighth (win_samples is a multiple of 4096)
+    for (int g = 0; g < 8; ++g) {
+      const int64_t ia = i0 + g * gs;
+      const int64_t ib = (ia + gs < i1) ? ia + gs : i1;
+      double s = 0.0;
+      int n = 0;
+      for (int64_t i = ia + r; i < ib; i += 8) {
+        double a = w ? fabs(w[i]) : 1.0;
+        const double du = fabs(u[i] - pu);
+        for (int q = 0; q < J; ++q) a *= du;
+        const double v = fabs(x[i * ldx + col0 + c] - px);
+        bx |= !(v <= 1.7976931348623157e308);
+        mx = fmax(mx, v);
+        s += a * v;
+        ++n;
+      }
+      if (n > 0) gmin = fmin(gmin, s / (double)n);
     }
   }
-  const double pu = pivot[0];
+  double su = 0.0;
+  int nu = 0;
   for (int64_t i = i0 + tid; i < i1; i += 256) {
     const double v = fabs(u[i] - pu);
     bu |= !(v <= 1.7976931348623157e308);
     mu = fmax(mu, v);
+    double a = 1.0;
     if (w) {
       const double vw = fabs(w[i]);
       bu |= !(vw <= 1.7976931348623157e308);
       mw = fmax(mw, vw);
+      a = vw;
     }
+    for (int q = 0; q < J; ++q) a *= v;
+    su += a;
+    ++nu;
   }
   if (bx) atomicOr(&badx[c], 1);
   if (bu) atomicOr(&badu, 1);
   shx[tid] = mx;
   shu[tid] = mu;
   shw[tid] = mw;
+  shg[tid] = gmin;
+  shs[tid] = su;
+  shn[tid] = nu;
+  __syncthreads();
+  // u row: 64 groups of 4 adjacent threads (samples = 4g .. 4g+3 mod 256) -> group means -> their minimum
+  double umin = kInf;
+  if (tid < 64) {
+    const double sg = shs[4 * tid] + shs[4 * tid + 1] + shs[4 * tid + 2] + shs[4 * tid + 3];
+    const int ng = shn[4 * tid] + shn[4 * tid + 1] + shn[4 * tid + 2] + shn[4 * tid + 3];
+    if (ng > 0) umin = sg / (double)ng;
+  }
+  __syncthreads();
+  shs[tid] = umin;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
     if (tid < off) {
       shu[tid] = fmax(shu[tid], shu[tid + off]);
       shw[tid] = fmax(shw[tid], shw[tid + off]);
-      if (off >= 32) shx[tid] = fmax(shx[tid], shx[tid + off]);  // keeps the column = tid & 31
+      shs[tid] = fmin(shs[tid], shs[tid + off]);
+      if (off >= 32) {  // keeps the column = tid & 31
+        shx[tid] = fmax(shx[tid], shx[tid + off]);
+        shg[tid] = fmin(shg[tid], shg[tid + off]);
+      }
     }
     __syncthreads();
   }
   double *wt = wtab + win * I8_WT_STRIDE;
   const double dumax = shu[0], wmax = w ? shw[0] : 1.0;
+  // guard: scale of the top power against the typical monomial (NaN / inf compare false: those windows keep
+  // the int8 path, whose poisoned descale reproduces the FP64 kernel's non-finite output)
+  double mtop = wmax;
+  for (int q = 0; q < J; ++q) mtop *= dumax;
+  const double theta = I8_GUARD * sqrt((double)(i1 - i0));
   if (tid == 0) {
     wt[I8_WT_INVDU] = dumax > 0.0 ? 1.0 / dumax : 0.0;
     wt[I8_WT_INVW] = wmax > 0.0 ? 1.0 / wmax : 0.0;
@@ -113,11 +163,51 @@ __global__ __launch_bounds__(256) void i8_window_kernel(const double *__restrict
       wt[I8_WT_DSP + j] = d;
       d *= dumax;
     }
+    if (mtop > theta * shs[0]) atomicOr(&flagged, 1);
   }
   if (tid < 32) {
     const double m = shx[tid];
     wt[I8_WT_SC + tid] = m > 0.0 ? 0x1p50 / m : 0.0;
     wt[I8_WT_DSC + tid] = badx[tid] ? __longlong_as_double(0x7ff8000000000000ll) : m * 0x1p-50;
+    if (tid < C && mtop * m > theta * shg[tid]) atomicOr(&flagged, 1);
+  }
+  __syncthreads();
+  if (tid == 0) wflag[win] = (uint32_t)flagged;
+}
+
+// flagged windows -> sorted list of tile runs for the FP64 kernel (one block: the scan keeps the order, so
+// the fallback's partial sums are added in a fixed order and results stay bitwise reproducible)
+__global__ __launch_bounds__(256) void i8_list_kernel(const uint32_t *__restrict__ wflag, int64_t nwin,
+                                                      int64_t win_tiles, int sub_tiles,
+                                                      uint32_t *__restrict__ list,
+                                                      uint32_t *__restrict__ n_list) {
+  __shared__ uint32_t sh[256];
+  __shared__ uint32_t running;
+  const int tid = threadIdx.x;
+  if (tid == 0) running = 0;
+  __syncthreads();
+  const int per = (int)(win_tiles / sub_tiles);
+  for (int64_t base = 0; base < nwin; base += 256) {
+    const int64_t wi = base + tid;
+    const uint32_t f = (wi < nwin && wflag[wi] != 0u) ? 1u : 0u;
+    sh[tid] = f;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {  // inclusive scan
+      const uint32_t v = tid >= off ? sh[tid - off] : 0u;
+      __syncthreads();
+      sh[tid] += v;
+      __syncthreads();
+    }
+    const uint32_t pos = running + sh[tid] - f;
+    if (f)
+      for (int k = 0; k < per; ++k) list[(size_t)pos * per + k] = (uint32_t)(wi * win_tiles + (int64_t)k * sub_tiles);
+    __syncthreads();
+    if (tid == 255) running += sh[255];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    n_list[0] = running * (uint32_t)per;
+    n_list[1] += running;  // over all column groups of a call (zeroed by the launcher)
   }
 }
 
@@ -483,6 +573,7 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
   // chunks are made of whole windows (tiles_per_chunk is a multiple of win_tiles)
   const int64_t WT = a.win_tiles;
   for (int64_t win = t_begin / WT; win * WT < t_end; ++win) {
+    if (a.wflag[win] != 0u) continue;  // precision guard: this window goes to the FP64 kernel (wave-uniform)
     {
       const double *wt = a.wtab + win * I8_WT_STRIDE;
       inv_du = wt[I8_WT_INVDU];
@@ -588,22 +679,29 @@ static int launch_pass(const I8Args &a, bool weighted, hipStream_t st) {
   constexpr int buf = 3 * JN * 2048 + (JN + (8 * JN + 31) / 32) * I8_FRAG;  // pair rows + plain fragments
   const size_t lds = (size_t)I8_CNT_BYTES + 2u * (size_t)buf + I8_REPS * sizeof(uint32_t) +
                      (weighted ? 2u : 1u) * SM_T * sizeof(double);  // + the tile's u (and w)
-  if (weighted) {
-    TXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_i8_kernel<K, J0, JN, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((resample_i8_kernel<K, J0, JN, true>), grid, block, lds, st, a);
-  } else {
-    TXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_i8_kernel<K, J0, JN, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((resample_i8_kernel<K, J0, JN, false>), grid, block, lds, st, a);
+  // the dynamic-LDS limit is a property of the function: set it once per instantiation (one device per process)
+  static bool lds_set[2] = {false, false};
+  if (!lds_set[weighted ? 1 : 0]) {
+    if (weighted)
+      TXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_i8_kernel<K, J0, JN, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    else
+      TXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_i8_kernel<K, J0, JN, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_set[weighted ? 1 : 0] = true;
   }
+  if (weighted) hipLaunchKernelGGL((resample_i8_kernel<K, J0, JN, true>), grid, block, lds, st, a);
+  else hipLaunchKernelGGL((resample_i8_kernel<K, J0, JN, false>), grid, block, lds, st, a);
   TXM_LAUNCH_CHECK();
   return TXM_OK;
 }
 
 int launch_resample_i8(const I8Args &a, int K, bool weighted, hipStream_t st) {
   hipLaunchKernelGGL(i8_window_kernel, dim3((unsigned)a.nwin), dim3(256), 0, st, a.x, a.ldx_s, a.u, a.w,
-                     a.N, a.C, a.col0, a.win_tiles * SM_T, a.pivot, a.wtab);
+                     a.N, a.C, a.col0, a.win_tiles * SM_T, a.pivot, K - 1, a.wtab, a.wflag);
+  TXM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(i8_list_kernel, dim3(1), dim3(256), 0, st, a.wflag, a.nwin, a.win_tiles, a.sub_tiles, a.list,
+                     a.n_list);
   TXM_LAUNCH_CHECK();
   int rc = TXM_OK;
   switch (K) {

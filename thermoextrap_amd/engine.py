@@ -8,6 +8,7 @@ data.py); nothing here knows about dims or names.
 
 from __future__ import annotations
 
+import contextlib
 import ctypes as ct
 
 import numpy as np
@@ -17,7 +18,7 @@ from . import _lib
 from ._lib import SamplerSpec, check
 
 F64 = torch.float64
-_ws_cache: dict[tuple[int, str], torch.Tensor] = {}
+_ws_cache: dict[tuple[int, int, str], torch.Tensor] = {}
 
 
 def _L():
@@ -35,8 +36,10 @@ def _ptr(t):
 
 
 def workspace(nbytes: int, tag: str = "main") -> torch.Tensor:
-    """Grow-only scratch buffer per (device, tag)."""
-    key = (torch.cuda.current_device(), tag)
+    """Grow-only scratch buffer per (device, stream, tag): calls issued on different torch streams never
+    share scratch, and a buffer is only ever used (and, when it grows, released) on the stream it was
+    allocated on, which is what torch's caching allocator assumes."""
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = None
@@ -194,17 +197,23 @@ def resample_vals(
     _check_f64_cuda(u, "u")
     squeeze = x.dim() == 1
     x2 = x.unsqueeze(1) if squeeze else x
-    if x2.stride(1) != 1 and x2.shape[1] > 1:
-        x2 = x2.contiguous()
+    if x2.dim() != 2:
+        raise ValueError("x must be (N,) or (N, C)")
     N, C = x2.shape
-    ls = x2.stride(0) if N > 1 else C
+    # the kernels want (rec, val) row-major with a row pitch >= C; anything else (transposed views,
+    # broadcast rows with stride 0, overlapping pitches) is copied
+    if not (x2.stride(1) == 1 or C == 1) or (N > 1 and x2.stride(0) < C):
+        x2 = x2.contiguous()
     if C == 1 and x2.stride(1) != 1:
         x2 = x2.contiguous()
-        ls = 1
-    ls = max(ls, C)
+    ls = max(x2.stride(0) if N > 1 else C, C)
+    if u.shape != (N,):
+        raise ValueError(f"u must have shape ({N},), got {tuple(u.shape)}")
     u = u.contiguous()
     if w is not None:
         _check_f64_cuda(w, "w")
+        if w.shape != (N,):
+            raise ValueError(f"w must have shape ({N},), got {tuple(w.shape)}")
         w = w.contiguous()
     if (freq is None) == (sampler is None):
         raise ValueError("give exactly one of freq= or sampler=")
@@ -226,6 +235,10 @@ def resample_vals(
             raise ValueError("pivot must have 1 + C entries")
     if out is None:
         out = torch.empty((nrep, C, 2, order + 1), dtype=F64, device="cuda")
+    else:
+        _check_f64_cuda(out, "out")
+        if tuple(out.shape) != (nrep, C, 2, order + 1) or not out.is_contiguous():
+            raise ValueError(f"out must be a contiguous ({nrep}, {C}, 2, {order + 1}) tensor, got {tuple(out.shape)}")
     ws = workspace(L.txm_resample_vals_ws_bytes(N, C, nrep, order))
     check(
         L.txm_resample_vals(_ptr(x2), ls, 1, _ptr(u), _ptr(w), N, C, order, nrep, _ptr(freq), spec_p, counts_p,
@@ -238,6 +251,41 @@ def resample_vals(
 def resample_path(N: int, C: int, nrep: int, order: int) -> str:
     """Which kernel the device-sampler bootstrap takes for this shape: "fp64" or "int8"."""
     return "int8" if _L().txm_resample_path(int(N), int(C), int(nrep), int(order)) == 1 else "fp64"
+
+
+_PATHS = {None: -1, "auto": -1, "fp64": 0, "int8": 1}
+_forced: str | None = None
+
+
+@contextlib.contextmanager
+def forced_path(path: str | None):
+    """Force the FP64 ("fp64") or the int8-sliced ("int8") bootstrap kernel wherever it applies
+    (txm_set_resample_path); None / "auto" is the library's own choice.  For tests and benchmarks: the
+    automatic choice plus the precision guard is what users get."""
+    global _forced
+    if path not in _PATHS:
+        raise ValueError(f"path must be one of {sorted(k for k in _PATHS if k)} or None")
+    L = _L()
+    prev = _forced
+    check(L.txm_set_resample_path(_PATHS[path]), "txm_set_resample_path")
+    _forced = path
+    try:
+        yield
+    finally:
+        check(L.txm_set_resample_path(_PATHS[prev]), "txm_set_resample_path")
+        _forced = prev
+
+
+def resample_info(N: int, C: int, nrep: int, order: int) -> dict:
+    """What the last device-sampler `resample_vals` call of this shape (on the current stream) did:
+    {"path", "windows", "windows_fp64"} -- the last one counts the scaling windows (x column groups) that the
+    precision guard of the int8 path handed to the FP64 kernel.  Synchronises."""
+    L = _L()
+    ws = workspace(L.txm_resample_vals_ws_bytes(N, C, nrep, order))
+    info = (ct.c_int64 * 4)()
+    check(L.txm_resample_vals_info(_ptr(ws), int(N), int(C), int(nrep), int(order), info, _stream()),
+          "txm_resample_vals_info")
+    return {"path": "int8" if info[0] == 1 else "fp64", "windows": int(info[1]), "windows_fp64": int(info[2])}
 
 
 def resample_data(data: torch.Tensor, freq: torch.Tensor | None, order: int) -> torch.Tensor:
@@ -309,11 +357,15 @@ def perturb(x: torch.Tensor, u: torch.Tensor, dalphas, freq: torch.Tensor | None
     if x2.stride(1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < x2.shape[1]):
         x2 = x2.contiguous()
     N, C = x2.shape
+    if u.shape != (N,):
+        raise ValueError(f"u must have shape ({N},), got {tuple(u.shape)}")
     u = u.contiguous()
     da = np.atleast_1d(np.asarray(dalphas, dtype=np.float64))
     nrep = 1
     if freq is not None:
         freq = freq.to(device="cuda", dtype=torch.int64).contiguous()
+        if freq.dim() != 2 or freq.shape[1] != N:
+            raise ValueError(f"freq must be (nrep, {N}), got {tuple(freq.shape)}")
         nrep = freq.shape[0]
     outs = []
     for a0 in range(0, len(da), 8):  # 8 perturbations per pass over the samples
