@@ -62,7 +62,43 @@ def parse():
     p.add_argument("--no-fp64-leg", action="store_true", help="skip timing the same shape with the FP64 kernel")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU baseline duration")
     p.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0: min(cores, 16), the 1-GPU box share)")
+    p.add_argument("--dry-run", action="store_true",
+                   help="no GPU: ranks rendezvous over gloo and run the sharded step with a stand-in compute (tests the launcher)")
     return p.parse_args()
+
+
+def dry_run(args):
+    """The multi-rank plumbing of this script without a GPU (tests/test_distributed_cpu.py): rendezvous (gloo),
+    thermoextrap_amd.distributed.run_step with a stand-in compute, barrier + max-over-ranks timing, rank 0's line."""
+    import torch
+    import torch.distributed as dist
+
+    from thermoextrap_amd import distributed as txd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    rank, world = txd.world()
+    nrep = 8
+
+    def compute(n, seed):
+        return torch.full((n, 2, 2, 3), float(rank), dtype=torch.float64)
+
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = txd.run_step(args.mode, compute, nrep, 100 + i)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    want = world * nrep if args.mode == "states" else nrep
+    assert out.shape[0] == want, (out.shape, want)
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run", "n_gpus": world, "steps": args.steps, "mode": args.mode,
+                          "rows": int(out.shape[0]), "ranks_seen": sorted({int(v) for v in out[:, 0, 0, 0].tolist()})}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def spawn_ranks(n: int) -> int:
@@ -165,6 +201,8 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+    if args.dry_run:
+        return dry_run(args)
     if args.config in ("c3", "c5"):
         from tools import bench_states  # multi-state configurations: batched reduce / bootstrap over states
 
@@ -244,13 +282,9 @@ def main():
         return boot.data.dxduave.device_values
 
     def step(i):
-        seed = 12345 + 1000 * i
-        if replicas:
-            results["slabs"] = txd.sharded_bootstrap(one_bootstrap, nrep, seed)
-        else:
-            slab = one_bootstrap(nrep, seed + rank)
-            if world > 1:
-                results["slabs"] = txd.all_gather_slabs(slab, [nrep] * world)  # final gather over xGMI
+        # thermoextrap_amd.distributed.run_step: the sharding (and the final all-gather over xGMI) that the
+        # 2-rank gloo test tests/test_distributed_cpu.py drives with a stand-in `compute`
+        results["slabs"] = txd.run_step("replicas" if replicas else "states", one_bootstrap, nrep, 12345 + 1000 * i)
 
     def barrier():
         if world > 1:

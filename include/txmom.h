@@ -173,6 +173,33 @@ int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, const doubl
                       const uint32_t *counts, const double *pivot, double *out, void *ws,
                       size_t ws_bytes, txm_stream stream);
 
+/* ---- (f-1) S state points of one shape in one set of launches ------------- */
+/* The reference handles a collection of states with a serial Python loop
+ * (StateCollection.resample / map_concat, models.py:614-671; one cmomy call per state).
+ * These entry points take S state points that share (N, C, order[, nrep]) -- the 16 lnPi states of
+ * BASELINE config 3, the 64 states of the GPR loop of config 5 -- and run ONE launch per kernel with
+ * the state on a grid axis.  `states_host` is a HOST array of S device-pointer triples (w NULL for all
+ * states or for none); it is copied into the workspace by the call (not stream-capturable).
+ *   txm_reduce_vals_batched:   out [S][C][2][K]            (= S x txm_reduce_vals, x row-major, pitch ldx_s)
+ *   txm_resample_vals_batched: out [S][nrep][C][2][K]      (= S x txm_resample_vals, FP64 kernel)
+ *     sampler: ONE spec over S * nrep replicates of ndat = N (state s owns replicates s*nrep ..
+ *     (s+1)*nrep - 1 of the stream, so the states' bootstrap samples are independent), with its
+ *     counts [S * nrep][ntiles]; or an explicit freq table [S * nrep][N]. */
+typedef struct txm_state_ptrs {
+  const double *x; /* [N][ldx_s] */
+  const double *u; /* [N] */
+  const double *w; /* [N] or NULL */
+} txm_state_ptrs;
+size_t txm_reduce_vals_batched_ws_bytes(int64_t S, int64_t N, int64_t C, int order);
+int txm_reduce_vals_batched(const txm_state_ptrs *states_host, int64_t S, int64_t ldx_s, int64_t N,
+                            int64_t C, int order, double *out, void *ws, size_t ws_bytes,
+                            txm_stream stream);
+size_t txm_resample_vals_batched_ws_bytes(int64_t S, int64_t N, int64_t C, int64_t nrep, int order);
+int txm_resample_vals_batched(const txm_state_ptrs *states_host, int64_t S, int64_t ldx_s, int64_t N,
+                              int64_t C, int order, int64_t nrep, const int64_t *freq,
+                              const txm_sampler_spec *spec_host, const uint32_t *counts, double *out,
+                              void *ws, size_t ws_bytes, txm_stream stream);
+
 /* ---- a4/a5: CentralMomentsData.reduce / resample_and_reduce ------------- */
 /* Block bootstrap of pre-reduced states: replicate r merges freq[r][i] copies
  * of state i.   data [nrec][C][2][K], freq [nrep][nrec] -> out [nrep][C][2][K]

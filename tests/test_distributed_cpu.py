@@ -36,6 +36,19 @@ WORKER = textwrap.dedent(
     assert torch.equal(full[:, 0, 0, 0], want), full[:, 0, 0, 0]
     assert torch.equal(full[:4, 1], torch.zeros(4, 2, 5, dtype=torch.float64))
     assert torch.equal(full[4:, 1], torch.full((3, 2, 5), 100.0, dtype=torch.float64))
+    # the step function bench.py runs, both modes (stand-in compute)
+    def compute2(n, seed):
+        out = torch.full((n, 2, 2, 3), float(seed % 1000), dtype=torch.float64)
+        out[:, 0, 0, 0] = torch.arange(n, dtype=torch.float64) + 1000 * rank
+        return out
+    st = D.run_step("states", compute2, 5, 40)
+    assert st.shape == (10, 2, 2, 3)
+    assert st[:, 0, 0, 0].tolist() == [0, 1, 2, 3, 4, 1000, 1001, 1002, 1003, 1004]
+    assert st[:5, 1, 1, 1].eq(40.0).all() and st[5:, 1, 1, 1].eq(41.0).all()      # seed + rank
+    rp = D.run_step("replicas", compute2, 5, 40)
+    assert rp.shape == (5, 2, 2, 3) and rp[:, 0, 0, 0].tolist() == [0, 1, 2, 1000, 1001]
+    sd = D.replicate_seeds(40, w)
+    assert rp[0, 1, 1, 1] == float(sd[0] % 1000) and rp[4, 1, 1, 1] == float(sd[1] % 1000)
     # state sharding: 5 states over 2 ranks, results come back in order on every rank
     states = list(range(5))
     outs = D.sharded_states(states, lambda s: torch.full((2, 2), float(s * s)))
@@ -73,3 +86,20 @@ def test_two_rank_gloo(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` (no WORLD_SIZE in the environment: what the driver runs) must start two ranks
+    itself, as a child process, and relay rank 0's single JSON line.  --dry-run swaps the GPU work for a stand-in
+    so that the launcher, the rendezvous and run_step are exercised here on the CPU."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    for mode, rows in (("states", 16), ("replicas", 8)):
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--dry-run", "--mode", mode],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, lines
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == 2 and rec["rows"] == rows and rec["ranks_seen"] == [0, 1] and rec["mode"] == mode

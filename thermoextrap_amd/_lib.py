@@ -23,6 +23,10 @@ class SamplerSpec(ct.Structure):
     _fields_ = [("seed", ct.c_uint64), ("nrep", c_i64), ("ndat", c_i64), ("nsamp", c_i64)]
 
 
+class StatePtrs(ct.Structure):
+    _fields_ = [("x", c_void_p), ("u", c_void_p), ("w", c_void_p)]
+
+
 class Atom(ct.Structure):
     _fields_ = [("src", ct.c_int32), ("pad", ct.c_int32), ("offset", c_i64), ("s_rep", c_i64), ("s_val", c_i64)]
 
@@ -66,6 +70,12 @@ SIGNATURES = {
     "txm_resample_vals": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_i64, c_i64, c_int, c_i64,
                                   c_void_p, ct.POINTER(SamplerSpec), c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_size, c_void_p]),
+    "txm_reduce_vals_batched_ws_bytes": (c_size, [c_i64, c_i64, c_i64, c_int]),
+    "txm_reduce_vals_batched": (c_int, [ct.POINTER(StatePtrs), c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p,
+                                        c_size, c_void_p]),
+    "txm_resample_vals_batched_ws_bytes": (c_size, [c_i64, c_i64, c_i64, c_i64, c_int]),
+    "txm_resample_vals_batched": (c_int, [ct.POINTER(StatePtrs), c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_void_p,
+                                          ct.POINTER(SamplerSpec), c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
     "txm_resample_data_ws_bytes": (c_size, [c_i64, c_i64, c_int]),
     "txm_resample_data": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_size,
                                   c_void_p]),

@@ -38,8 +38,16 @@ template <int K, int VEC, int LPR_LOG2, bool WEIGHTED>
 __global__ __launch_bounds__(RED_BLOCK) void reduce_rowmajor_kernel(
     const double *__restrict__ x, int64_t ldx_s, const double *__restrict__ u,
     const double *__restrict__ w, int64_t N, int64_t C, const double *__restrict__ pivot,
-    double *__restrict__ partial) {
+    double *__restrict__ partial, const txm_state_ptrs *__restrict__ batch = nullptr) {
   constexpr int LPR = 1 << LPR_LOG2;
+  if (batch != nullptr) {  // batched mode: blockIdx.z = state; per-state pivots and partial sums follow each other
+    const txm_state_ptrs bs = batch[blockIdx.z];
+    x = bs.x;
+    u = bs.u;
+    w = bs.w;
+    pivot += (int64_t)blockIdx.z * (1 + C);
+    partial += (size_t)blockIdx.z * gridDim.y * gridDim.x * (LPR * VEC) * 2 * K;
+  }
   constexpr int ROWS = RED_BLOCK / LPR;
   constexpr int UNR = 4;
   const int tid = threadIdx.x;
@@ -145,9 +153,13 @@ __global__ __launch_bounds__(RED_BLOCK) void reduce_rowmajor_kernel(
 template <int K>
 __global__ __launch_bounds__(RED_BLOCK) void finalize_rowmajor_kernel(
     const double *__restrict__ partial, int nblk_x, int cols_per_chunk, int64_t C,
-    const double *__restrict__ pivot, double *__restrict__ out) {
+    const double *__restrict__ pivot, double *__restrict__ out, int n_colchunks = 0) {
   const int64_t c = blockIdx.x;
   if (c >= C) return;
+  // batched mode: blockIdx.y = state
+  partial += (size_t)blockIdx.y * n_colchunks * nblk_x * cols_per_chunk * 2 * K;
+  pivot += (int64_t)blockIdx.y * (1 + C);
+  out += (size_t)blockIdx.y * C * 2 * K;
   const int chunk = (int)(c / cols_per_chunk), cc = (int)(c % cols_per_chunk);
   double acc[2 * K];
 #pragma unroll
@@ -373,17 +385,23 @@ size_t reduce_vals_ws_bytes_impl(int64_t N, int64_t C, int order) {
 template <int K>
 static int launch_rowmajor(const double *x, int64_t ldx_s, const double *u, const double *w,
                            int64_t N, int64_t C, const double *pivot, double *partial, double *out,
-                           hipStream_t st) {
-  const RowPlan p = plan_rowmajor(x, ldx_s, N, C);
-  dim3 grid(p.grid_x, p.chunks), block(RED_BLOCK);
+                           hipStream_t st, const txm_state_ptrs *batch = nullptr, int64_t S = 1,
+                           bool aligned16 = true) {
+  // batched: `x` is only consulted for its alignment (aligned16 = every state's x is 16-byte aligned)
+  RowPlan p = plan_rowmajor(aligned16 ? x : reinterpret_cast<const double *>(8), ldx_s, N, C);
+  if (S > 1) {  // S states share the chip
+    int gx = (int)cdiv(p.grid_x, S);
+    p.grid_x = gx < 1 ? 1 : gx;
+  }
+  dim3 grid(p.grid_x, p.chunks, (unsigned)S), block(RED_BLOCK);
 #define TXM_RM_CASE(VEC, L2)                                                                    \
   if (p.vec == VEC && p.lpr_log2 == L2) {                                                       \
     if (w)                                                                                      \
       hipLaunchKernelGGL((reduce_rowmajor_kernel<K, VEC, L2, true>), grid, block, 0, st, x,     \
-                         ldx_s, u, w, N, C, pivot, partial);                                    \
+                         ldx_s, u, w, N, C, pivot, partial, batch);                             \
     else                                                                                        \
       hipLaunchKernelGGL((reduce_rowmajor_kernel<K, VEC, L2, false>), grid, block, 0, st, x,    \
-                         ldx_s, u, w, N, C, pivot, partial);                                    \
+                         ldx_s, u, w, N, C, pivot, partial, batch);                             \
   } else
 #define TXM_RM_VEC(VEC)                                                                         \
   TXM_RM_CASE(VEC, 0) TXM_RM_CASE(VEC, 1) TXM_RM_CASE(VEC, 2) TXM_RM_CASE(VEC, 3)               \
@@ -396,8 +414,8 @@ static int launch_rowmajor(const double *x, int64_t ldx_s, const double *u, cons
 #undef TXM_RM_VEC
 #undef TXM_RM_CASE
   TXM_LAUNCH_CHECK();
-  hipLaunchKernelGGL((finalize_rowmajor_kernel<K>), dim3((unsigned)C), block, 0, st, partial,
-                     p.grid_x, p.cols_per_chunk, C, pivot, out);
+  hipLaunchKernelGGL((finalize_rowmajor_kernel<K>), dim3((unsigned)C, (unsigned)S), block, 0, st, partial,
+                     p.grid_x, p.cols_per_chunk, C, pivot, out, p.chunks);
   TXM_LAUNCH_CHECK();
   return TXM_OK;
 }
@@ -494,6 +512,45 @@ extern "C" int txm_reduce_vals(const double *x, int64_t ldx_s, int64_t ldx_c, co
     const int64_t ld_series = (C == 1) ? 0 : ldx_c;
     TXM_K_SWITCH(K, return launch_colmajor_cov<KK>(x, ld_series, u, w, N, C, pivot, partial, out, st));
   }
+  return TXM_OK;
+}
+
+extern "C" size_t txm_reduce_vals_batched_ws_bytes(int64_t S, int64_t N, int64_t C, int order) {
+  if (S < 1 || N < 0 || C < 1) return 0;
+  // pointer table + per-state pivots + per-state partial sums (the per-state grid is never larger than one state's)
+  return align_up((size_t)S * sizeof(txm_state_ptrs), 256) + align_up((size_t)S * (1 + C) * sizeof(double), 256) +
+         (size_t)S * reduce_vals_ws_bytes_impl(N, C, order);
+}
+
+extern "C" int txm_reduce_vals_batched(const txm_state_ptrs *states_host, int64_t S, int64_t ldx_s, int64_t N,
+                                       int64_t C, int order, double *out, void *ws, size_t ws_bytes,
+                                       txm_stream stream) {
+  TXM_REQUIRE(states_host && out && ws, "reduce_vals_batched: null pointer");
+  TXM_REQUIRE(S >= 1 && S <= 65535 && N >= 1 && C >= 1 && C <= 65535, "reduce_vals_batched: bad S/N/C");
+  TXM_REQUIRE(order >= 0 && order <= TXM_MAX_ORDER, "reduce_vals_batched: order %d outside [0, %d]", order, TXM_MAX_ORDER);
+  TXM_REQUIRE(ldx_s >= C, "reduce_vals_batched: row pitch ldx_s < C");
+  const bool weighted = states_host[0].w != nullptr;
+  bool aligned16 = true;
+  for (int64_t s = 0; s < S; ++s) {
+    TXM_REQUIRE(states_host[s].x && states_host[s].u, "reduce_vals_batched: state %lld has a null pointer", (long long)s);
+    TXM_REQUIRE((states_host[s].w != nullptr) == weighted, "reduce_vals_batched: weights for all states or for none");
+    aligned16 = aligned16 && (reinterpret_cast<uintptr_t>(states_host[s].x) & 15) == 0;
+  }
+  if (ws_bytes < txm_reduce_vals_batched_ws_bytes(S, N, C, order)) {
+    set_error("reduce_vals_batched: workspace too small");
+    return TXM_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  txm_state_ptrs *tab = (txm_state_ptrs *)ws;
+  TXM_HIP(hipMemcpyAsync(tab, states_host, (size_t)S * sizeof(txm_state_ptrs), hipMemcpyHostToDevice, st));
+  double *pivot = (double *)((char *)ws + align_up((size_t)S * sizeof(txm_state_ptrs), 256));
+  double *partial = (double *)((char *)pivot + align_up((size_t)S * (1 + C) * sizeof(double), 256));
+  hipLaunchKernelGGL(pivot_batch_kernel, dim3((unsigned)(1 + C), (unsigned)S), dim3(RED_BLOCK), 0, st, tab, ldx_s, N, C, pivot);
+  TXM_LAUNCH_CHECK();
+  const int K = order + 1;
+  const double *w0 = weighted ? states_host[0].w : nullptr;  // only its null-ness selects the kernel
+  TXM_K_SWITCH(K, return launch_rowmajor<KK>(states_host[0].x, ldx_s, states_host[0].u, w0, N, C, pivot, partial, out,
+                                             st, tab, S, aligned16));
   return TXM_OK;
 }
 

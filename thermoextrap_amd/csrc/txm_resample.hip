@@ -85,6 +85,10 @@ struct ResampleArgs {
   const uint32_t *n_list;
   int sub_tiles;
   int64_t col_off;          // x already points at the column group; its pivots start at pivot[1 + col_off]
+  // batched mode (txm_resample_vals_batched): blockIdx.z = state s of S state points of one shape.  x/u/w come
+  // from batch[s]; pivot, the partial sums, counts / freq rows and the sampler's replicate ids are those of the
+  // single-state layout shifted by s (replicate s * nrep + r of one sampler over S * nrep replicates)
+  const txm_state_ptrs *batch;
 };
 
 // One wave: 16 replicates x (NBLK*16 columns) x one chunk of tiles.
@@ -123,31 +127,31 @@ __device__ __forceinline__ void tile_calls(uint32_t *tw, uint32_t k0, uint32_t k
   }
 }
 
-__device__ __forceinline__ void fill_tile_full(const ResampleArgs &a, uint32_t *tw, int64_t rep0, int64_t t,
-                                               int lane) {
+__device__ __forceinline__ void fill_tile_full(const ResampleArgs &a, const uint32_t *counts, uint32_t rid0,
+                                               uint32_t *tw, int64_t rep0, int64_t t, int lane) {
 #pragma unroll 1
   for (int p = 0; p < RS_REPS / 2; ++p) {
     const int64_t ra = rep0 + 2 * p, rb = ra + 1;
     if (ra >= a.nrep) break;  // wave-uniform
-    const uint32_t na = a.counts[(size_t)ra * a.ntiles + t];
-    const uint32_t nb = rb < a.nrep ? a.counts[(size_t)rb * a.ntiles + t] : 0u;
+    const uint32_t na = counts[(size_t)ra * a.ntiles + t];
+    const uint32_t nb = rb < a.nrep ? counts[(size_t)rb * a.ntiles + t] : 0u;
     const uint32_t wsel = (uint32_t)p >> 1;                  // (2p) >> 2 == (2p+1) >> 2
     const uint32_t inc_a = 1u << (8u * ((2u * p) & 3u)), inc_b = inc_a << 8;
     // iterations 1 and 2: calls 0..63 of each replicate; when n >= 768 (wave-uniform,
     // practically always) every field is a real draw and no select is needed
-    if (na >= 768u) tile_calls<true>(tw, a.k0, a.k1, (uint32_t)ra, (uint32_t)t, (uint32_t)lane, na, inc_a, wsel);
-    else tile_calls<false>(tw, a.k0, a.k1, (uint32_t)ra, (uint32_t)t, (uint32_t)lane, na, inc_a, wsel);
-    if (nb >= 768u) tile_calls<true>(tw, a.k0, a.k1, (uint32_t)rb, (uint32_t)t, (uint32_t)lane, nb, inc_b, wsel);
-    else tile_calls<false>(tw, a.k0, a.k1, (uint32_t)rb, (uint32_t)t, (uint32_t)lane, nb, inc_b, wsel);
+    if (na >= 768u) tile_calls<true>(tw, a.k0, a.k1, rid0 + (uint32_t)ra, (uint32_t)t, (uint32_t)lane, na, inc_a, wsel);
+    else tile_calls<false>(tw, a.k0, a.k1, rid0 + (uint32_t)ra, (uint32_t)t, (uint32_t)lane, na, inc_a, wsel);
+    if (nb >= 768u) tile_calls<true>(tw, a.k0, a.k1, rid0 + (uint32_t)rb, (uint32_t)t, (uint32_t)lane, nb, inc_b, wsel);
+    else tile_calls<false>(tw, a.k0, a.k1, rid0 + (uint32_t)rb, (uint32_t)t, (uint32_t)lane, nb, inc_b, wsel);
     // iteration 3: calls 64..95 of both, 32 lanes each
     const bool hb = lane >= 32;
-    tile_calls<false>(tw, a.k0, a.k1, (uint32_t)(hb ? rb : ra), (uint32_t)t, 64u + ((uint32_t)lane & 31u),
+    tile_calls<false>(tw, a.k0, a.k1, rid0 + (uint32_t)(hb ? rb : ra), (uint32_t)t, 64u + ((uint32_t)lane & 31u),
                       hb ? nb : na, hb ? inc_b : inc_a, wsel);
     // calls >= 96 (n > 1152, a > 4 sigma event): plain loop
     const uint32_t nmax = na > nb ? na : nb;
     for (uint32_t c0 = 96u; c0 * 12u < nmax; c0 += 64u) {
-      tile_calls<false>(tw, a.k0, a.k1, (uint32_t)ra, (uint32_t)t, c0 + (uint32_t)lane, na, inc_a, wsel);
-      tile_calls<false>(tw, a.k0, a.k1, (uint32_t)rb, (uint32_t)t, c0 + (uint32_t)lane, nb, inc_b, wsel);
+      tile_calls<false>(tw, a.k0, a.k1, rid0 + (uint32_t)ra, (uint32_t)t, c0 + (uint32_t)lane, na, inc_a, wsel);
+      tile_calls<false>(tw, a.k0, a.k1, rid0 + (uint32_t)rb, (uint32_t)t, c0 + (uint32_t)lane, nb, inc_b, wsel);
     }
   }
 }
@@ -181,6 +185,25 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
   const int64_t t_begin = (int64_t)chunk * a.tiles_per_chunk;
   int64_t t_end = t_begin + a.tiles_per_chunk;
   if (t_end > a.ntiles) t_end = a.ntiles;
+  // operands of this launch's state (batched mode: state blockIdx.z)
+  const double *X = a.x, *U = a.u, *W = a.w, *PIV = a.pivot;
+  const uint32_t *CNT = a.counts;
+  const int64_t *FREQ = a.freq;
+  double *PX = a.part_x, *PU = a.part_u;
+  uint32_t rid0 = 0;
+  if (a.batch != nullptr) {
+    const int64_t sidx = blockIdx.z;
+    const txm_state_ptrs bs = a.batch[sidx];
+    X = bs.x;
+    U = bs.u;
+    W = bs.w;
+    PIV += sidx * (1 + a.C);
+    if (CNT) CNT += (size_t)sidx * a.nrep * a.ntiles;
+    if (FREQ) FREQ += (size_t)sidx * a.nrep * a.N;
+    PX += (size_t)sidx * a.n_chunks * a.nrep_pad * a.C_pad * K;
+    PU += (size_t)sidx * a.n_chunks * a.nrep_pad * K;
+    rid0 = (uint32_t)(sidx * a.nrep);
+  }
   const bool listed = a.list != nullptr;  // kernel argument: uniform
   int64_t nruns = 1;
   if (listed) {
@@ -188,7 +211,7 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
     if (nruns == 0) return;  // nothing flagged: the finalize kernel does not read this launch's partial sums
   }
 
-  const double pu = a.pivot[0];
+  const double pu = PIV[0];
   // Columns beyond C (padding of the last 16-column block) re-read column 0:
   // their sums are finite garbage that the finalize kernel never looks at, which
   // is cheaper than a mask multiply on the FP64 pipe the MFMAs need.
@@ -198,7 +221,7 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
   for (int bl = 0; bl < NBLK; ++bl) {
     const int64_t c = col0 + bl * 16 + row;
     ccol[bl] = c < a.C ? c : 0;
-    px[bl] = a.pivot[1 + a.col_off + ccol[bl]];
+    px[bl] = PIV[1 + a.col_off + ccol[bl]];
   }
 
   v4f64 acc[K][NBLK];
@@ -236,7 +259,7 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
   for (int64_t t = tb; t < te; ++t) {
     const int64_t i_tile = t * SM_T;
     if constexpr (!WEIGHTED && !EXPLICIT)
-      if (kk == 0 && rep_ok) cnt += (double)a.counts[(size_t)my_rep * a.ntiles + t];
+      if (kk == 0 && rep_ok) cnt += (double)CNT[(size_t)my_rep * a.ntiles + t];
     const uint32_t tsize = (t == a.ntiles - 1) ? a.last_tile_size : (uint32_t)SM_T;
     // window of 1024 samples that is contracted for this tile
     int64_t wbase = i_tile;
@@ -256,13 +279,13 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
       __builtin_amdgcn_wave_barrier();
       uint32_t *tw = reinterpret_cast<uint32_t *>(tile);
       if (tsize == (uint32_t)SM_T) {
-        fill_tile_full(a, tw, rep0, t, lane);
+        fill_tile_full(a, CNT, rid0, tw, rep0, t, lane);
       } else {
         for (int rr = 0; rr < RS_REPS; ++rr) {
           const int64_t r = rep0 + rr;
           if (r >= a.nrep) break;  // wave-uniform
-          const uint32_t n = a.counts[(size_t)r * a.ntiles + t];
-          sampler_fine_tile(a.k0, a.k1, (uint32_t)r, (uint32_t)t, n, tsize, lane, [&](uint32_t off0) {
+          const uint32_t n = CNT[(size_t)r * a.ntiles + t];
+          sampler_fine_tile(a.k0, a.k1, rid0 + (uint32_t)r, (uint32_t)t, n, tsize, lane, [&](uint32_t off0) {
             const uint32_t off = off0 + shift;
             atomicAdd(&tw[off * (RS_REPS / 4) + ((uint32_t)rr >> 2)], 1u << (8u * ((uint32_t)rr & 3u)));
           });
@@ -342,22 +365,22 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
       if constexpr (!SMALLN) {
         // wave-uniform row base (SGPRs, scalar ALU) + a loop-invariant 32-bit lane
         // offset: the loads need no per-step vector address arithmetic
-        const double *ur = a.u + (wbase + s0);
+        const double *ur = U + (wbase + s0);
 #pragma unroll
         for (int e = 0; e < RS_GROUP; ++e) G.u[e] = ld(ur + e, lane_uoff);
         if constexpr (WEIGHTED) {
-          const double *wr = a.w + (wbase + s0);
+          const double *wr = W + (wbase + s0);
 #pragma unroll
           for (int e = 0; e < RS_GROUP; ++e) G.w[e] = ld(wr + e, lane_uoff);
         }
 #pragma unroll
         for (int e = 0; e < RS_GROUP; ++e) {
-          const double *xr = a.x + (wbase + s0 + e) * a.ldx_s;
+          const double *xr = X + (wbase + s0 + e) * a.ldx_s;
 #pragma unroll
           for (int bl = 0; bl < NBLK; ++bl) G.x[e][bl] = ld(xr, lane_xoff[bl]);
         }
         if constexpr (EXPLICIT) {
-          const int64_t *fp = a.freq + (size_t)(rep_ok ? my_rep : 0) * a.N + ibase + s0;
+          const int64_t *fp = FREQ + (size_t)(rep_ok ? my_rep : 0) * a.N + ibase + s0;
 #pragma unroll
           for (int e = 0; e < RS_GROUP; ++e)
             G.fi[e] = (rep_ok && lbase + (uint32_t)(s0 + e) >= shift) ? fp[e] : 0;
@@ -368,12 +391,12 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
         for (int e = 0; e < RS_GROUP; ++e) {
           const int64_t ii = ibase + s0 + e;
           const int64_t ic = ii <= last ? ii : last;
-          G.u[e] = a.u[ic];
-          if constexpr (WEIGHTED) G.w[e] = a.w[ic];
+          G.u[e] = U[ic];
+          if constexpr (WEIGHTED) G.w[e] = W[ic];
 #pragma unroll
-          for (int bl = 0; bl < NBLK; ++bl) G.x[e][bl] = a.x[ic * a.ldx_s + ccol[bl]];
+          for (int bl = 0; bl < NBLK; ++bl) G.x[e][bl] = X[ic * a.ldx_s + ccol[bl]];
           if constexpr (EXPLICIT)
-            G.fi[e] = (rep_ok && ii <= last) ? a.freq[(size_t)(rep_ok ? my_rep : 0) * a.N + ic] : 0;
+            G.fi[e] = (rep_ok && ii <= last) ? FREQ[(size_t)(rep_ok ? my_rep : 0) * a.N + ic] : 0;
         }
       }
       if constexpr (!EXPLICIT) {
@@ -416,7 +439,7 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
 
   // ---- write partial sums ---------------------------------------------------
   // D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
-  double *px_out = a.part_x + ((size_t)chunk * a.nrep_pad + rep0) * a.C_pad * K;
+  double *px_out = PX + ((size_t)chunk * a.nrep_pad + rep0) * a.C_pad * K;
 #pragma unroll
   for (int j = 0; j < K; ++j)
 #pragma unroll
@@ -434,7 +457,7 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
       double v = usum[j];
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
-      if (kk == 0) a.part_u[((size_t)chunk * a.nrep_pad + rep0 + row) * K + j] = v;
+      if (kk == 0) PU[((size_t)chunk * a.nrep_pad + rep0 + row) * K + j] = v;
     }
   }
 }
@@ -451,6 +474,12 @@ __global__ __launch_bounds__(256) void resample_finalize_kernel(
   if (e >= nrep * C) return;
   const int64_t r = e / C, c = e % C;
   if (C_total == 0) C_total = C;
+  // batched mode: blockIdx.y = state; every per-state array follows the previous state's
+  const int64_t sidx = blockIdx.y;
+  part_x += (size_t)sidx * n_chunks * nrep_pad * C_pad * K;
+  part_u += (size_t)sidx * n_chunks * nrep_pad * K;
+  pivot += sidx * (1 + C);
+  out += (size_t)sidx * nrep * C_total * 2 * K;
   double S0[K], S1[K];
 #pragma unroll
   for (int j = 0; j < K; ++j) S0[j] = S1[j] = 0.0;
@@ -668,8 +697,8 @@ extern "C" size_t txm_resample_vals_ws_bytes(int64_t N, int64_t C, int64_t nrep,
 namespace txm {
 template <int K>
 static int run_resample(ResampleArgs a, const ResamplePlan &p, bool weighted, bool explicit_,
-                        double *out, hipStream_t st) {
-  dim3 grid((unsigned)(p.n_chunks * p.n_rbg), (unsigned)p.colgroups), block(RS_BLOCK);
+                        double *out, hipStream_t st, int64_t S = 1) {
+  dim3 grid((unsigned)(p.n_chunks * p.n_rbg), (unsigned)p.colgroups, (unsigned)S), block(RS_BLOCK);
   const size_t lds = explicit_ ? 0 : (size_t)RS_WAVES * RS_TILE_BYTES;
 #define TXM_RS_LAUNCH(NB, WT, EX)                                                          \
   do {                                                                                    \
@@ -688,7 +717,7 @@ static int run_resample(ResampleArgs a, const ResamplePlan &p, bool weighted, bo
 #undef TXM_RS_LAUNCH
   TXM_LAUNCH_CHECK();
   const int64_t ne = a.nrep * a.C;
-  hipLaunchKernelGGL((resample_finalize_kernel<K>), dim3((unsigned)cdiv(ne, 256)), dim3(256), 0, st,
+  hipLaunchKernelGGL((resample_finalize_kernel<K>), dim3((unsigned)cdiv(ne, 256), (unsigned)S), dim3(256), 0, st,
                      a.part_x, a.part_u, p.n_chunks, p.nrep_pad, p.C_pad, a.nrep, a.C, a.pivot, out);
   TXM_LAUNCH_CHECK();
   return TXM_OK;
@@ -781,7 +810,7 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
     f.part_u = (double *)((char *)ws + q.off_fbu);
     f.n_chunks = q.fb.n_chunks; f.n_rbg = q.fb.n_rbg; f.tiles_per_chunk = q.fb.tiles_per_chunk;
     f.nrep_pad = q.fb.nrep_pad; f.C_pad = q.fb.C_pad;
-    f.list = b.list; f.n_list = b.n_list; f.sub_tiles = q.sub_tiles;
+    f.list = b.list; f.n_list = b.n_list; f.sub_tiles = q.sub_tiles; f.batch = nullptr;
     TXM_REQUIRE(q.fb.nrep_pad == q.nrep_pad, "resample_vals: replicate padding of the two kernels differs");
     // one launch (or two, orders 5-7) per group of 32 columns; the groups reuse the partial buffers
     for (int64_t col0 = 0; col0 < C; col0 += I8_CPAD) {
@@ -845,7 +874,90 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
   a.part_u = (double *)((char *)ws + p.off_pu);
   a.n_chunks = p.n_chunks; a.n_rbg = p.n_rbg; a.tiles_per_chunk = p.tiles_per_chunk;
   a.nrep_pad = p.nrep_pad; a.C_pad = p.C_pad;
-  a.list = nullptr; a.n_list = nullptr; a.sub_tiles = 0; a.col_off = 0;
+  a.list = nullptr; a.n_list = nullptr; a.sub_tiles = 0; a.col_off = 0; a.batch = nullptr;
   TXM_K_SWITCH(K, return run_resample<KK>(a, p, w != nullptr, explicit_, out, st));
+  return TXM_OK;
+}
+
+// ---- S state points of one shape: the same kernels with the state on grid axis z -----------------------
+namespace txm {
+struct BatchPlan {
+  ResamplePlan one;  // plan of one state (the chunk count is chosen for S states together)
+  size_t off_tab, off_pivot, off_px, off_pu, total;
+};
+static BatchPlan plan_batched(int64_t S, int64_t N, int64_t C, int64_t nrep, int K) {
+  BatchPlan b;
+  ResamplePlan &p = b.one;
+  p = plan_resample(N, C, nrep, K);
+  // S states fill the chip together: fewer sample chunks per state
+  const int64_t target_wgs = (int64_t)num_cus() * 2 * 4;
+  int64_t nc = cdiv(target_wgs, (int64_t)p.n_rbg * p.colgroups * S);
+  if (nc > p.ntiles) nc = p.ntiles;
+  if (nc < 1) nc = 1;
+  nc = cdiv(nc, 8) * 8;
+  p.tiles_per_chunk = cdiv(p.ntiles, nc);
+  p.n_chunks = (int)(cdiv(cdiv(p.ntiles, p.tiles_per_chunk), 8) * 8);
+  b.off_tab = 0;
+  b.off_pivot = align_up((size_t)S * sizeof(txm_state_ptrs), 256);
+  b.off_px = b.off_pivot + align_up((size_t)S * (1 + C) * sizeof(double), 256);
+  b.off_pu = b.off_px + align_up((size_t)S * p.n_chunks * p.nrep_pad * p.C_pad * K * sizeof(double), 256);
+  b.total = b.off_pu + align_up((size_t)S * p.n_chunks * p.nrep_pad * K * sizeof(double), 256);
+  return b;
+}
+}  // namespace txm
+
+extern "C" size_t txm_resample_vals_batched_ws_bytes(int64_t S, int64_t N, int64_t C, int64_t nrep, int order) {
+  if (S < 1 || N < 1 || C < 1 || nrep < 1 || order < 0 || order > TXM_MAX_ORDER) return 0;
+  return plan_batched(S, N, C, nrep, order + 1).total;
+}
+
+extern "C" int txm_resample_vals_batched(const txm_state_ptrs *states_host, int64_t S, int64_t ldx_s, int64_t N,
+                                         int64_t C, int order, int64_t nrep, const int64_t *freq,
+                                         const txm_sampler_spec *spec, const uint32_t *counts, double *out,
+                                         void *ws, size_t ws_bytes, txm_stream stream) {
+  TXM_REQUIRE(states_host && out && ws, "resample_vals_batched: null pointer");
+  TXM_REQUIRE(S >= 1 && S <= 65535 && N >= 1 && C >= 1 && nrep >= 1, "resample_vals_batched: need S, N, C, nrep >= 1");
+  TXM_REQUIRE(order >= 0 && order <= TXM_MAX_ORDER, "resample_vals_batched: order %d outside [0, %d]", order, TXM_MAX_ORDER);
+  TXM_REQUIRE(ldx_s >= C, "resample_vals_batched: row pitch ldx_s < C");
+  const bool explicit_ = freq != nullptr;
+  TXM_REQUIRE(explicit_ != (spec != nullptr && counts != nullptr), "resample_vals_batched: give either freq or (spec, counts)");
+  const bool weighted = states_host[0].w != nullptr;
+  for (int64_t s = 0; s < S; ++s) {
+    TXM_REQUIRE(states_host[s].x && states_host[s].u, "resample_vals_batched: state %lld has a null pointer", (long long)s);
+    TXM_REQUIRE((states_host[s].w != nullptr) == weighted, "resample_vals_batched: weights for all states or for none");
+  }
+  const int K = order + 1;
+  const BatchPlan b = plan_batched(S, N, C, nrep, K);
+  if (ws_bytes < b.total) {
+    set_error("resample_vals_batched: workspace too small (%zu < %zu)", ws_bytes, b.total);
+    return TXM_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  txm_state_ptrs *tab = (txm_state_ptrs *)((char *)ws + b.off_tab);
+  TXM_HIP(hipMemcpyAsync(tab, states_host, (size_t)S * sizeof(txm_state_ptrs), hipMemcpyHostToDevice, st));
+  double *piv = (double *)((char *)ws + b.off_pivot);
+  hipLaunchKernelGGL(pivot_batch_kernel, dim3((unsigned)(1 + C), (unsigned)S), dim3(256), 0, st, tab, ldx_s, N, C, piv);
+  TXM_LAUNCH_CHECK();
+  const ResamplePlan &p = b.one;
+  ResampleArgs a;
+  a.x = nullptr; a.ldx_s = ldx_s; a.u = nullptr; a.w = nullptr; a.N = N; a.C = C; a.nrep = nrep;
+  a.freq = freq; a.counts = counts;
+  a.k0 = a.k1 = 0;
+  a.ntiles = p.ntiles;
+  a.last_tile_size = (uint32_t)(N - (p.ntiles - 1) * SM_T);
+  if (!explicit_) {
+    TXM_REQUIRE(spec->ndat == N && spec->nrep == S * nrep, "resample_vals_batched: the sampler must span S * nrep replicates of N samples");
+    TXM_REQUIRE(spec->nrep < ((int64_t)1 << 32), "resample_vals_batched: S * nrep too large");
+    a.k0 = (uint32_t)spec->seed;
+    a.k1 = (uint32_t)(spec->seed >> 32);
+  }
+  a.pivot = piv;
+  a.part_x = (double *)((char *)ws + b.off_px);
+  a.part_u = (double *)((char *)ws + b.off_pu);
+  a.n_chunks = p.n_chunks; a.n_rbg = p.n_rbg; a.tiles_per_chunk = p.tiles_per_chunk;
+  a.nrep_pad = p.nrep_pad; a.C_pad = p.C_pad;
+  a.list = nullptr; a.n_list = nullptr; a.sub_tiles = 0; a.col_off = 0;
+  a.batch = tab;
+  TXM_K_SWITCH(K, return run_resample<KK>(a, p, weighted, explicit_, out, st, S));
   return TXM_OK;
 }

@@ -92,3 +92,23 @@ def sharded_states(states: Sequence, func: Callable, group=None) -> list:
         raise ValueError("more ranks than states: give every rank at least one state")
     full = all_gather_slabs(torch.stack(outs), counts, group)
     return list(full.unbind(0))
+
+
+def run_step(mode: str, compute: Callable[[int, int], torch.Tensor], nrep: int, seed: int, group=None) -> torch.Tensor:
+    """One multi-GPU bootstrap step, the way bench.py (and a user script) shards it -- the single place both the
+    benchmark and the gloo tests go through:
+
+    "states"   every rank bootstraps ITS OWN state point: ``compute(nrep, seed + rank)`` -> ``[nrep, ...]``;
+               returns the ``[world * nrep, ...]`` concatenation of all ranks' slabs (weak scaling).
+    "replicas" every rank holds the SAME state point and computes ``nrep / world`` replicates with its own
+               seed (`sharded_bootstrap`); returns the ``[nrep, ...]`` concatenation (strong scaling).
+    One all-gather ends the step; there is no data-path collective."""
+    rank, w = world()
+    if mode == "replicas":
+        return sharded_bootstrap(compute, nrep, seed, group)
+    if mode != "states":
+        raise ValueError(f"unknown mode {mode!r}")
+    slab = compute(nrep, seed + rank)
+    if slab.shape[0] != nrep:
+        raise ValueError("compute returned the wrong number of replicates")
+    return all_gather_slabs(slab, [nrep] * w, group)

@@ -248,6 +248,80 @@ def resample_vals(
     return out[:, 0] if squeeze else out
 
 
+def _state_table(xs, us, ws):
+    """Validate S state points of one shape and build the host pointer table of the batched entry points."""
+    S = len(xs)
+    if S < 1 or len(us) != S or (ws is not None and len(ws) != S):
+        raise ValueError("need the same number (>= 1) of x, u (and w) tensors")
+    x2 = []
+    for x in xs:
+        _check_f64_cuda(x, "x")
+        x = x.unsqueeze(1) if x.dim() == 1 else x
+        if x.dim() != 2:
+            raise ValueError("every x must be (N,) or (N, C)")
+        x2.append(x if x.is_contiguous() else x.contiguous())
+    N, C = x2[0].shape
+    if any(tuple(x.shape) != (N, C) for x in x2):
+        raise ValueError("the batched path needs states of one shape (N, C)")
+    u2 = []
+    for u in us:
+        _check_f64_cuda(u, "u")
+        if u.shape != (N,):
+            raise ValueError(f"every u must have shape ({N},)")
+        u2.append(u.contiguous())
+    w2 = None
+    if ws is not None:
+        w2 = []
+        for w in ws:
+            _check_f64_cuda(w, "w")
+            if w.shape != (N,):
+                raise ValueError(f"every w must have shape ({N},)")
+            w2.append(w.contiguous())
+    tab = (_lib.StatePtrs * S)()
+    for s in range(S):
+        tab[s].x, tab[s].u = x2[s].data_ptr(), u2[s].data_ptr()
+        tab[s].w = w2[s].data_ptr() if w2 is not None else None
+    return tab, (x2, u2, w2), S, N, C
+
+
+def reduce_vals_batched(xs, us, order: int, ws=None) -> torch.Tensor:
+    """S state points of one shape in one launch per kernel (txm_reduce_vals_batched): (S, C, 2, K)."""
+    L = _L()
+    tab, keep, S, N, C = _state_table(xs, us, ws)
+    out = torch.empty((S, C, 2, order + 1), dtype=F64, device="cuda")
+    wsb = workspace(L.txm_reduce_vals_batched_ws_bytes(S, N, C, order))
+    check(L.txm_reduce_vals_batched(tab, S, C, N, C, order, _ptr(out), _ptr(wsb), wsb.numel(), _stream()),
+          "txm_reduce_vals_batched")
+    del keep
+    return out[:, 0] if xs[0].dim() == 1 else out
+
+
+def resample_vals_batched(xs, us, order: int, *, nrep: int, sampler: DeviceSampler | None = None,
+                          freq: torch.Tensor | None = None, ws=None) -> torch.Tensor:
+    """Bootstrap of S state points of one shape in one launch per kernel (txm_resample_vals_batched):
+    (S, nrep, C, 2, K).  `sampler`: ONE DeviceSampler over S * nrep replicates of N samples (state s owns
+    replicates s * nrep ...), or `freq`: (S * nrep, N) explicit counts."""
+    L = _L()
+    tab, keep, S, N, C = _state_table(xs, us, ws)
+    if (freq is None) == (sampler is None):
+        raise ValueError("give exactly one of freq= or sampler=")
+    spec_p = counts_p = None
+    if freq is not None:
+        freq = freq.to(device="cuda", dtype=torch.int64).contiguous()
+        if tuple(freq.shape) != (S * nrep, N):
+            raise ValueError(f"freq must be ({S * nrep}, {N}), got {tuple(freq.shape)}")
+    else:
+        if sampler.ndat != N or sampler.nrep != S * nrep:
+            raise ValueError(f"the sampler must span {S} x {nrep} replicates of {N} samples")
+        spec_p, counts_p = ct.byref(sampler.spec), _ptr(sampler.counts)
+    out = torch.empty((S, nrep, C, 2, order + 1), dtype=F64, device="cuda")
+    wsb = workspace(L.txm_resample_vals_batched_ws_bytes(S, N, C, nrep, order))
+    check(L.txm_resample_vals_batched(tab, S, C, N, C, order, nrep, _ptr(freq), spec_p, counts_p, _ptr(out), _ptr(wsb),
+                                      wsb.numel(), _stream()), "txm_resample_vals_batched")
+    del keep
+    return out[:, :, 0] if xs[0].dim() == 1 else out
+
+
 def resample_path(N: int, C: int, nrep: int, order: int) -> str:
     """Which kernel the device-sampler bootstrap takes for this shape: "fp64" or "int8"."""
     return "int8" if _L().txm_resample_path(int(N), int(C), int(nrep), int(order)) == 1 else "fp64"

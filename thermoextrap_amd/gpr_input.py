@@ -72,3 +72,58 @@ def input_GP_from_state(state, n_rep=100, log_scale=False, sampler=None):  # noq
         derivs = T @ derivs
         cov = np.einsum("ab,kbc,dc->kad", T, cov, T)
     return x_data, derivs, cov
+
+
+def input_GP_from_states(states, n_rep=100, log_scale=False, sampler=None):  # noqa: N802
+    """`input_GP_from_state` for a whole StateCollection (BASELINE config 5: 64 state points) with the
+    bootstrap, the derivative evaluation and the covariance over replicates each done in ONE launch for all
+    states.  The reference loops over the states calling input_GP_from_state and stacks the pieces
+    (create_GPR, gpr_active/active_utils.py:896-925: np.vstack of x and y, scipy block_diag of the per-state
+    covariances for every output); this returns exactly that `data_input` tuple:
+    x_data (S * (order+1), 2), y_data (S * (order+1), n_out), noise_cov_mat (n_out, S*(order+1), S*(order+1)).
+    Falls back to the per-state function when the states do not share a shape."""
+    import torch
+
+    from .models import StateCollection
+
+    coll = states if isinstance(states, StateCollection) else StateCollection(list(states))
+    spec = sampler if sampler is not None else {"nrep": n_rep}
+    S = len(coll)
+    if coll._batch_eligible() is None or not isinstance(spec, dict):
+        parts = [input_GP_from_state(st, n_rep=n_rep, log_scale=log_scale, sampler=sampler) for st in coll]
+    else:
+        order = coll.order
+        boot = coll.resample(spec)
+        vals, _ = boot._derivs_batched(order=order, norm=False, _device=True)      # (order+1, S, nrep, n_out)
+        n_ord, _, nrep, n_out = vals.shape
+        cov = engine.cov_over_rep(vals.permute(0, 2, 1, 3).reshape(n_ord, nrep, S * n_out))  # (S*n_out, n_ord, n_ord)
+        cov = cov.reshape(S, n_out, n_ord, n_ord).cpu().numpy()
+        # the states' own derivatives: one evaluation over the stacked un-resampled states
+        st0 = coll[0]
+        from . import moments as cm
+
+        stack = torch.stack([st.data.dxduave.device_values for st in coll])
+        d0 = st0.data
+        one = d0.new_like(dxduave=cm.CentralMomentsData(stack, mom_ndim=2, dims=("rep", *d0.dxduave.dims)), rec_dim="rep")
+        dv, _ = st0.derivatives.derivs(data=one, order=order, norm=False, minus_log=st0.minus_log, _device=True)
+        dv = dv.cpu().numpy()                                                         # (order+1, S, n_out)
+        parts = []
+        for s_, st in enumerate(coll):
+            alphas = st.alpha0 * np.ones((order + 1, 1))
+            if log_scale:
+                alphas = np.log10(alphas)
+            x_data = np.concatenate([alphas, np.arange(order + 1)[:, None]], axis=1)
+            derivs, c = dv[:, s_, :], cov[s_]
+            if log_scale:
+                T = log_scale_matrix(st.alpha0, order)
+                derivs = T @ derivs
+                c = np.einsum("ab,kbc,dc->kad", T, c, T)
+            parts.append((x_data, derivs, c))
+    x_all = np.concatenate([p_[0] for p_ in parts], axis=0)
+    y_all = np.concatenate([p_[1] for p_ in parts], axis=0)
+    n_out = parts[0][2].shape[0]
+    n_ord = parts[0][2].shape[1]
+    cov_all = np.zeros((n_out, S * n_ord, S * n_ord))
+    for s_, p_ in enumerate(parts):
+        cov_all[:, s_ * n_ord:(s_ + 1) * n_ord, s_ * n_ord:(s_ + 1) * n_ord] = p_[2]
+    return x_all, y_all, cov_all
