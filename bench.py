@@ -273,12 +273,15 @@ def main():
 
     engine.resample_vals = resample_vals_timed
 
+    from thermoextrap_amd import moments as cm
+
     def one_bootstrap(n_rep, seed):
-        boot = xem.resample(sampler={"nrep": n_rep, "device": True, "seed": seed})
+        # one sampler object per step (stage-1/2 kernels run here), shared by the moments and the callback's <dx/dq>
+        smp = cm.factory_sampler({"nrep": n_rep, "device": True, "seed": seed}, data=xv, dim="rec")
+        boot = xem.resample(sampler=smp)
         results["derivs"] = boot.derivs(norm=False)  # host labelled array (order+1, rep, val)
         if dxdq is not None:
-            smp = engine.DeviceSampler(seed=seed, nrep=n_rep, ndat=N)
-            results["dxdq"] = engine.resample_vals(dxdq, u, 0, sampler=smp)[:, :, 1, 0]
+            results["dxdq"] = engine.resample_vals(dxdq, u, 0, sampler=smp.device_sampler)[:, :, 1, 0]
         return boot.data.dxduave.device_values
 
     def step(i):

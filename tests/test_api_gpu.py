@@ -748,3 +748,92 @@ def test_stack_states(xtrap):
     # mean of replicate derivatives sits near the un-resampled derivative
     d0 = xems[0].derivs(norm=False)
     assert np.abs(mv.isel(beta=0, stats=0).values - d0.transpose("order", "pair", "position").values).max() < 1.0
+
+
+# ---------------------------------------------------------------------------
+# API-level weights and the raw / data constructors, directly (reference data.py:1062-1126, 1216-1283, 1693)
+# ---------------------------------------------------------------------------
+def _weighted_states(orc, x, u, w, order):
+    """long-double definition of the weighted comoment state of every column."""
+    return orc.truth_cov(x, u, order, w=w)
+
+
+def test_from_vals_weight_argument(fixture, xtrap, orc):
+    """`weight=` of DataCentralMomentsVals.from_vals / DataCentralMoments.from_vals reaches the kernels: the state
+    equals the long-double weighted definition, and integer weights equal repeating the rows."""
+    rng = np.random.default_rng(12)
+    x, u = fixture.legacy["x"], fixture.legacy["u"]
+    order = 4
+    w = rng.uniform(0.2, 2.0, len(u))
+    sc = np.abs(x.std(axis=0))[:, None, None] ** np.array([0, 1])[None, :, None] * u.std() ** np.arange(order + 1)[None, None, :]
+    want = _weighted_states(orc, x, u, w, order)
+    a = xtrap.DataCentralMomentsVals.from_vals(xv=fixture.x, uv=fixture.u, order=order, weight=w, central=True)
+    b = xtrap.DataCentralMoments.from_vals(xv=fixture.x, uv=fixture.u, order=order, weight=w, central=True, axis=0)
+    for d in (a, b):
+        got = np.asarray(d.values.values)
+        assert (np.abs(got - want) / (np.abs(want) + sc)).max() < 1e-12
+    np.testing.assert_allclose(np.asarray(a.values.values)[:, 0, 0], w.sum(), rtol=1e-14)
+    # integer weights == repeated rows (unweighted)
+    k = rng.integers(0, 4, len(u))
+    xr_, ur_ = np.repeat(x, k, axis=0), np.repeat(u, k)
+    c = xtrap.DataCentralMomentsVals.from_vals(xv=fixture.x, uv=fixture.u, order=order, weight=k.astype(float), central=True)
+    from thermoextrap_amd.data import xrwrap_uv, xrwrap_xv
+
+    dd = xtrap.DataCentralMomentsVals.from_vals(xv=xrwrap_xv(xr_), uv=xrwrap_uv(ur_), order=order, central=True)
+    np.testing.assert_allclose(np.asarray(c.values.values), np.asarray(dd.values.values), rtol=1e-11, atol=1e-13)
+    # derivatives see the weights: weighted model == oracle derivatives with the same weights
+    from oracle import derivs_oracle as dor
+
+    got = xtrap.beta.factory_extrapmodel(fixture.beta0, a).derivs(norm=False).values
+    ref = dor.derivs_x_ave(x, u, order, w=w)
+    np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-12)
+
+
+def test_resample_weight_argument(fixture, xtrap, orc):
+    """weights ride through DataCentralMomentsVals.resample: replicate r = state of the data with weights w_i * freq[r, i]
+    (SURVEY App. A), with explicit indices as the reference draws them."""
+    rng = np.random.default_rng(13)
+    x, u = fixture.legacy["x"], fixture.legacy["u"]
+    order, nrep = 3, 6
+    w = rng.uniform(0.2, 2.0, len(u))
+    idx = rng.choice(len(u), (nrep, len(u)))
+    freq = orc.indices_to_freq(idx, len(u))
+    d = xtrap.DataCentralMomentsVals.from_vals(xv=fixture.x, uv=fixture.u, order=order, weight=w, central=True)
+    got = np.asarray(d.resample(sampler={"indices": idx}).values.values)       # (rep, val, xmom, umom)
+    sc = np.abs(x.std(axis=0))[:, None, None] ** np.array([0, 1])[None, :, None] * u.std() ** np.arange(order + 1)[None, None, :]
+    for r in range(nrep):
+        want = _weighted_states(orc, x, u, w * freq[r], order)
+        assert (np.abs(got[r] - want) / (np.abs(want) + sc)).max() < 1e-12
+    np.testing.assert_allclose(got[:, :, 0, 0], (w[None, :] * freq).sum(axis=1)[:, None] * np.ones((1, x.shape[1])), rtol=1e-13)
+
+
+def test_from_raw_and_from_data_directly(fixture, xtrap, orc):
+    """DataCentralMoments.from_raw (raw moments <x^i u^j> with the weight in [0, 0]; reference data.py:1062-1126:
+    convert.moments_type(to="central")) and .from_data (central states; data.py:1216-1283), fed with the oracle's
+    numbers, reproduce the from_vals object; with a `rec` dim they reduce to it."""
+    from thermoextrap_amd.xrlite import DataArray
+
+    x, u = fixture.legacy["x"], fixture.legacy["u"]
+    order = fixture.order
+    cen = orc.truth_cov(x, u, order)                                            # (val, 2, K) central states
+    raw = orc.convert_cov(cen, to_central=False)                                # raw moments, weight kept in [0, 0]
+    ref = fixture.xdata                                                         # from_vals, reduced over rec
+    a = xtrap.DataCentralMoments.from_data(DataArray(cen, dims=("val", "xmom", "umom")), central=True)
+    b = xtrap.DataCentralMoments.from_raw(DataArray(raw, dims=("val", "xmom", "umom")), central=True)
+    for d in (a, b):
+        np.testing.assert_allclose(np.asarray(d.values.values), np.asarray(ref.values.values), rtol=1e-10, atol=1e-13)
+        fixture.xr_test_central(d)
+        fixture.xr_test_raw(d)
+    # blocks of samples as records: from_data / from_raw per block, then reduce == all samples at once
+    nb = 4
+    xb, ub = x.reshape(nb, -1, x.shape[1]), u.reshape(nb, -1)
+    cb = np.stack([orc.truth_cov(xb[i], ub[i], order) for i in range(nb)])      # (rec, val, 2, K)
+    rb = np.stack([orc.convert_cov(c, to_central=False) for c in cb])
+    da = xtrap.DataCentralMoments.from_data(DataArray(cb, dims=("rec", "val", "xmom", "umom")), central=True).reduce("rec")
+    db = xtrap.DataCentralMoments.from_raw(DataArray(rb, dims=("rec", "val", "xmom", "umom")), central=True).reduce("rec")
+    for d in (da, db):
+        np.testing.assert_allclose(np.asarray(d.values.values), np.asarray(ref.values.values), rtol=1e-9, atol=1e-12)
+    # derivatives from a from_raw object == the legacy oracle's
+    m = xtrap.beta.factory_extrapmodel(fixture.beta0, xtrap.DataCentralMoments.from_raw(
+        DataArray(raw, dims=("val", "xmom", "umom")), central=False))
+    np.testing.assert_allclose(m.derivs(norm=False).values, fixture.legacy["derivs"][: order + 1], rtol=1e-7)

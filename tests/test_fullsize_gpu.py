@@ -147,3 +147,56 @@ def test_int8_path_equals_fp64_path_fullsize(eng, N, C, order, nrep):
     with eng.forced_path("fp64"):
         rw = eng.resample_vals(x, u, order, sampler=s, w=w)
     close(gw, rw, sc, 1e-12)
+
+
+def test_c4_order6_bootstrap_and_dxdq_fullsize(eng):
+    """BASELINE config 4 at size: N = 1e8, N_obs = 32, order 6, nrep = 1000 -- the two-pass int8 path (powers 0-3 and
+    4-6, two passes over the sampler stream) under default dispatch -- and the volume callback's per-replicate
+    <dx/dq> (an order-0 bootstrap of a second (N, 32) array over the SAME sampler, reference volume.py:121-126 gathers
+    dxdqv[indices] instead).  Properties on all 1000 replicates; int8 == FP64 kernel on the first 64 replicates of the
+    stream at 1e-12; fused == explicit frequency table on 2 replicates."""
+    N, C, order, nrep = 100_000_000, 32, 6, 1000
+    x, u = synth(N, C, 17)
+    K = order + 1
+    st = eng.reduce_vals(x, u, order)
+    sc = scale_of(x.std(dim=0), u.std(), K)[None]
+    s = eng.DeviceSampler(20261004, nrep, N)
+    assert eng.resample_path(N, C, nrep, order) == "int8"
+    rep = eng.resample_vals(x, u, order, sampler=s)
+    info = eng.resample_info(N, C, nrep, order)
+    assert info["path"] == "int8" and info["windows_fp64"] == 0, info     # Gaussian data at order 6: nothing flagged
+    assert rep.shape == (nrep, C, 2, K) and torch.isfinite(rep).all()
+    assert (rep[:, :, 0, 0] == float(N)).all()
+    assert (rep[:, :, 0, :] == rep[:, :1, 0, :]).all()
+    z = (rep[:, :, 1, 0] - st[None, :, 1, 0]) / (x.std(dim=0)[None] / np.sqrt(N))
+    assert abs(z.mean().item()) < 15 / np.sqrt(nrep * C) and 0.85 < z.std().item() < 1.15
+    # high central moments of u: mean over replicates close to the sample's (bias O(1/N))
+    for j in (2, 4, 6):
+        r = rep[:, 0, 0, j].mean().item() / st[0, 0, j].item()
+        assert abs(r - 1.0) < 2e-4, (j, r)
+    # the first 64 replicates of the stream through the FP64 kernel: the replicate key does not depend on nrep
+    s64 = eng.DeviceSampler(20261004, 64, N)
+    assert torch.equal(s64.counts, s.counts[:64])
+    with eng.forced_path("fp64"):
+        ref = eng.resample_vals(x, u, order, sampler=s64)
+    close(rep[:64], ref, sc, 1e-12)
+    # ... and the int8 path at nrep = 64 gives the very same bits as at nrep = 1000 (window scales do not depend on nrep)
+    with eng.forced_path("int8"):
+        rep64 = eng.resample_vals(x, u, order, sampler=s64)
+    close(rep64, rep[:64], sc, 1e-13)
+    # fused == explicit table on 2 replicates, order 6
+    s2 = eng.DeviceSampler(515151, 2, N)
+    fused = eng.resample_vals(x, u, order, sampler=s2)
+    freq = s2.freq()
+    close(fused, eng.resample_vals(x, u, order, freq=freq), sc, 2e-13)
+    del rep, ref, rep64
+    # ---- per-replicate <dx/dq>: order-0 bootstrap over the same sampler
+    dxdq, _ = synth(N, C, 23)
+    m = eng.resample_vals(dxdq, u, 0, sampler=s)
+    assert m.shape == (nrep, C, 2, 1) and (m[:, :, 0, 0] == float(N)).all()
+    mean = dxdq.mean(dim=0)
+    zz = (m[:, :, 1, 0] - mean[None]) / (dxdq.std(dim=0)[None] / np.sqrt(N))
+    assert abs(zz.mean().item()) < 15 / np.sqrt(nrep * C) and 0.85 < zz.std().item() < 1.15
+    m2 = eng.resample_vals(dxdq, u, 0, sampler=s2)[:, :, 1, 0]
+    want = (freq.to(torch.float64) @ dxdq) / float(N)               # the definition: freq-weighted mean
+    np.testing.assert_allclose(m2.cpu().numpy(), want.cpu().numpy(), rtol=1e-12)

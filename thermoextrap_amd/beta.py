@@ -51,54 +51,47 @@ class SymDerivBeta(SymDerivBase):
             return cls(func=S.umean(), args=("u", "du"), expand=expand, post_func=post_func)
         return cls(func=S.u_raw(1), args=("u",), expand=expand, post_func=post_func)
 
+    # The four moment families below exist in one representation only (central moments <du^n>, <dx du^n>;
+    # raw moments <u^n>, <x u^n>); `central` is accepted for symmetry with x_ave/u_ave and must not contradict it.
+    @staticmethod
+    def _family(name, central, is_central, n, n_min, d=None, xalpha=False):
+        if central is not None and bool(central) != is_central:
+            kind = "central" if is_central else "raw"
+            raise ValueError(f"{name} is a {kind}-moment average: central={central!r} contradicts that (leave it None)")
+        n = int(n)
+        if n < n_min:
+            raise ValueError(f"{name}: moment order n={n} is below the smallest meaningful one ({n_min})")
+        if xalpha:
+            if not isinstance(d, int):
+                raise TypeError(f"{name}: with xalpha=True the derivative index d of x must be an int, got {type(d).__name__}")
+            if d < 0:
+                raise ValueError(f"{name}: derivative index d={d} is negative")
+        return n
+
     @classmethod
     def dun_ave(cls, n, expand=True, post_func=None, central=None):
         """<(u - <u>)^n>, n > 1."""
-        if central is not None and not central:
-            raise ValueError(f"central={central} must be None or evaluate to True")
-        if (n := int(n)) <= 1:
-            raise ValueError(f"n={n} must be > 1.")
+        n = cls._family("dun_ave", central, True, n, 2)
         return cls(func=S.du(n), args=("u", "du"), expand=expand, post_func=post_func)
 
     @classmethod
     def dxdun_ave(cls, n, xalpha=False, expand=True, post_func=None, d=None, central=None):
         """<dx^(d) du^n>, n > 0."""
-        if central is not None and not central:
-            raise ValueError(f"central={central} nust be `None` or evaluate to `True`")
-        if (n := int(n)) <= 0:
-            raise ValueError(f"n={n} must be positive integer.")
-        if xalpha:
-            if not isinstance(d, int):
-                raise TypeError
-            func = S.dxdu(n, d)
-        else:
-            func = S.dxdu(n)
+        n = cls._family("dxdun_ave", central, True, n, 1, d, xalpha)
+        func = S.dxdu(n, d) if xalpha else S.dxdu(n)
         return cls(func=func, args=("x1", "du", "dxdu"), expand=expand, post_func=post_func)
 
     @classmethod
     def un_ave(cls, n, expand=True, post_func=None, central=None):
         """<u^n>, n >= 1."""
-        if central is not None and central:
-            raise ValueError(f"central={central} must be `None` or evaluate to False")
-        if (n := int(n)) < 1:
-            raise ValueError(f"n={n} must be >=1.")
+        n = cls._family("un_ave", central, False, n, 1)
         return cls(func=S.u_raw(n), args=("u",), expand=expand, post_func=post_func)
 
     @classmethod
     def xun_ave(cls, n, d=None, xalpha=False, expand=True, post_func=None, central=None):
         """<x^(d) u^n>, n >= 0."""
-        if central is not None and central:
-            raise ValueError(f"central={central} must be `None` or False")
-        if (n := int(n)) < 0:
-            raise ValueError(f"n={n} must be >= 0")
-        if xalpha:
-            if not isinstance(d, int):
-                raise TypeError
-            if d < 0:
-                raise ValueError
-            func = S.xu_raw(n, d)
-        else:
-            func = S.xu_raw(n)
+        n = cls._family("xun_ave", central, False, n, 0, d, xalpha)
+        func = S.xu_raw(n, d) if xalpha else S.xu_raw(n)
         return cls(func=func, args=("u", "xu"), expand=expand, post_func=post_func)
 
     @classmethod
@@ -131,21 +124,20 @@ def factory_extrapmodel(beta, data, *, name="x_ave", n=None, d=None, xalpha=None
                         alpha_name="beta", derivatives=None, post_func=None, derivatives_kws=None):
     """ExtrapModel for a beta expansion; ``order``, ``xalpha`` and ``central``
     default to the data object's (reference beta.py:577-666)."""
-    if xalpha is None:
-        xalpha = data.xalpha
-    if central is None:
-        central = data.central
-    if order is None:
-        order = data.order
-    if xalpha != data.xalpha:
-        raise ValueError(f"xalpha={xalpha} must equal data.xalpha={data.xalpha}")
-    if central != data.central:
-        raise ValueError(f"central={central} must equal data.central={data.central}")
+    # the model must describe the data it is given: same representation (raw/central), same treatment of an
+    # alpha-dependent observable, and no order beyond what the moments were accumulated to
+    want = {"xalpha": data.xalpha if xalpha is None else xalpha, "central": data.central if central is None else central}
+    for key, val in want.items():
+        if bool(val) != bool(getattr(data, key)):
+            raise ValueError(f"the data object was built with {key}={getattr(data, key)!r}; a model with {key}={val!r} "
+                             "cannot be evaluated on it")
+    xalpha, central = want["xalpha"], want["central"]
+    order = data.order if order is None else order
     if order > data.order:
-        raise ValueError(f"order={order} must be <= data.order={data.order}")
+        raise ValueError(f"order {order} requested, but the data object only holds moments to order {data.order}")
     if derivatives is None:
         if name in {"u_ave", "un_ave", "dun_ave"} and not data.x_is_u:
-            raise ValueError("if name in [u_ave, un_ave, dun_ave] must have data.x_is_u")
+            raise ValueError(f"{name} is an average of u alone: it needs a data object built with x_is_u=True")
         derivatives = factory_derivatives(name=name, n=n, d=d, xalpha=xalpha, central=central, post_func=post_func,
                                           **(derivatives_kws or {}))
     return ExtrapModel(alpha0=beta, data=data, derivatives=derivatives, order=order, alpha_name=alpha_name)

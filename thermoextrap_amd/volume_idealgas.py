@@ -13,7 +13,7 @@ from .volume import _FirstOrderSeries
 
 @lru_cache(5)
 def factory_derivatives(refV=1.0):  # noqa: N803
-    inv = S.Poly.const(Fraction(1.0 / refV).limit_denominator(10**12)) if float(refV) != 1.0 else S.Poly.const(1)
+    inv = S.Poly.const(1 / Fraction(float(refV)))  # exact rational 1 / refV (refV itself is a dyadic rational)
     xw0, xw1, w1 = S.xu_raw(0), S.xu_raw(1), S.u_raw(1)
     return Derivatives(_FirstOrderSeries([xw0, (xw1 - xw0 * w1 + xw0) * inv]), args=("W", "xW"))
 
