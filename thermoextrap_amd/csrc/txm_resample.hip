@@ -89,7 +89,16 @@ struct ResampleArgs {
   // from batch[s]; pivot, the partial sums, counts / freq rows and the sampler's replicate ids are those of the
   // single-state layout shifted by s (replicate s * nrep + r of one sampler over S * nrep replicates)
   const txm_state_ptrs *batch;
+  // L2-sharing hint (nullptr: off).  The waves that contract one sample chunk -- 4 per workgroup x the replicate
+  // groups of the chunk, placed on one XCD by the block map -- read the same samples; left alone they drift apart
+  // by many tiles and every one of them streams the chunk from HBM again (measured: 19x the algorithmic bytes).
+  // Each wave publishes the number of tiles it has finished in progress[group][slot] and, before the next tile,
+  // sleeps (bounded) while it is more than RS_LEAD tiles ahead of the slowest STARTED, UNFINISHED wave of its
+  // group.  Purely a performance hint: every wait is bounded and no result depends on it.
+  uint32_t *progress;       // [groups = n_chunks * colgroups (* S)][64], zeroed by the launcher
 };
+constexpr uint32_t RS_LEAD = 1;          // tiles a wave may run ahead of its group
+constexpr int RS_THROTTLE_SPINS = 48;    // x ~0.3 us: bound of one wait
 
 // One wave: 16 replicates x (NBLK*16 columns) x one chunk of tiles.
 //
@@ -248,6 +257,11 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
     int64_t fi[EXPLICIT ? RS_GROUP : 1];  // parity mode: raw int64 counts
   };
 
+  uint32_t *pg = nullptr;
+  uint32_t tiles_done = 0;
+  const int pslot = (rbg * RS_WAVES + wave) & 63;
+  if (a.progress != nullptr)
+    pg = a.progress + ((size_t)((blockIdx.z * gridDim.y + colgrp) * a.n_chunks + chunk)) * 64;
   double cnt = 0.0;  // lanes kk == 0, unweighted: the replicate's draws in the contracted tiles (exact integers)
   for (int64_t run = listed ? chunk : 0; run < nruns; run += listed ? a.n_chunks : 1) {
   int64_t tb = t_begin, te = t_end;
@@ -434,8 +448,26 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
     }
+    if (pg != nullptr) {  // kernel argument: uniform
+      ++tiles_done;
+      if (lane == 0) __hip_atomic_store(&pg[pslot], tiles_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll 1
+      for (int spin = 0; spin < RS_THROTTLE_SPINS; ++spin) {
+        uint32_t v = __hip_atomic_load(&pg[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v == 0u) v = 0xffffffffu;  // slot unused or its wave not started yet: not a wave to wait for
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const uint32_t w2 = (uint32_t)__shfl_xor((int)v, o);
+          v = w2 < v ? w2 : v;
+        }
+        if (tiles_done <= v + RS_LEAD) break;
+        __builtin_amdgcn_s_sleep(32);
+      }
+    }
   }
   }
+  if (pg != nullptr && lane == 0)  // finished: never hold the others back
+    __hip_atomic_store(&pg[pslot], 0xfffffff0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   // ---- write partial sums ---------------------------------------------------
   // D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
@@ -542,7 +574,7 @@ __global__ __launch_bounds__(256) void resample_finalize_i8_kernel(
 struct ResamplePlan {
   int nblk, colgroups, n_rbg, n_chunks;
   int64_t tiles_per_chunk, nrep_pad, C_pad, ntiles;
-  size_t off_pivot, off_px, off_pu, total;
+  size_t off_pivot, off_px, off_pu, off_prog, prog_bytes, total;
 };
 
 static ResamplePlan plan_resample(int64_t N, int64_t C, int64_t nrep, int K) {
@@ -565,7 +597,9 @@ static ResamplePlan plan_resample(int64_t N, int64_t C, int64_t nrep, int K) {
   p.off_pivot = 0;
   p.off_px = align_up((size_t)(1 + C) * sizeof(double), 256);
   p.off_pu = p.off_px + align_up((size_t)p.n_chunks * p.nrep_pad * p.C_pad * K * sizeof(double), 256);
-  p.total = p.off_pu + align_up((size_t)p.n_chunks * p.nrep_pad * K * sizeof(double), 256);
+  p.off_prog = p.off_pu + align_up((size_t)p.n_chunks * p.nrep_pad * K * sizeof(double), 256);
+  p.prog_bytes = (size_t)p.n_chunks * p.colgroups * 64 * sizeof(uint32_t);
+  p.total = p.off_prog + align_up(p.prog_bytes, 256);
   return p;
 }
 
@@ -577,7 +611,7 @@ struct I8Plan {
   size_t off_pivot, off_px, off_pu, off_wt, total;
   // precision-guard fallback: window flags, run list, and the FP64 kernel's plan / partial sums for one column group
   int sub_tiles;
-  size_t off_flag, off_list, off_nlist, off_fbx, off_fbu;
+  size_t off_flag, off_list, off_nlist, off_fbx, off_fbu, off_prog, prog_bytes;
   ResamplePlan fb;
 };
 
@@ -589,10 +623,12 @@ static I8Plan plan_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   // one workgroup per CU: chunks x replicate groups should fill the CUs once, not 1.1 times
   int64_t nc = (int64_t)num_cus() / p.n_rbg / 8 * 8;
   if (nc < 8) nc = 8;
-  // scaling window: 64 tiles, shorter when a chunk would hold fewer than two of them (chunks are
-  // whole windows, so short windows keep the workgroups balanced on small N x many chunks)
+  // scaling window: 256 tiles (one flush of the int32 accumulators into the FP64 partial sums per window: the
+  // read-modify-write of the partials is 7 GB instead of 29 GB per launch at the north-star size), shorter
+  // while a chunk would hold fewer than eight of them (chunks are whole windows: that keeps the workgroups
+  // balanced to 1/8 on small N x many chunks)
   p.win_tiles = I8_WIN_TILES;
-  while (p.win_tiles > 4 && p.ntiles < 2 * p.win_tiles * nc) p.win_tiles /= 4;
+  while (p.win_tiles > 4 && cdiv(p.ntiles, p.win_tiles) < 8 * nc) p.win_tiles /= 4;
   p.nwin = cdiv(p.ntiles, p.win_tiles);
   p.tiles_per_chunk = cdiv(p.nwin, nc) * p.win_tiles;
   p.n_chunks = (int)(cdiv(cdiv(p.ntiles, p.tiles_per_chunk), 8) * 8);
@@ -607,7 +643,9 @@ static I8Plan plan_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   p.fb = plan_resample(N, C < I8_CPAD ? C : I8_CPAD, nrep, K);
   p.off_fbx = p.off_nlist + 256;
   p.off_fbu = p.off_fbx + align_up((size_t)p.fb.n_chunks * p.fb.nrep_pad * p.fb.C_pad * K * sizeof(double), 256);
-  p.total = p.off_fbu + align_up((size_t)p.fb.n_chunks * p.fb.nrep_pad * K * sizeof(double), 256);
+  p.off_prog = p.off_fbu + align_up((size_t)p.fb.n_chunks * p.fb.nrep_pad * K * sizeof(double), 256);
+  p.prog_bytes = (size_t)p.n_chunks * 64 * sizeof(uint32_t);
+  p.total = p.off_prog + align_up(p.prog_bytes, 256);
   return p;
 }
 
@@ -624,6 +662,16 @@ static int path_override() {
   return g_path_override;
 }
 
+// TXM_THROTTLE=0 switches the L2-sharing hint of the bootstrap kernels off (A/B measurements)
+static bool throttle_on() {
+  static int on = -1;
+  if (on < 0) {
+    const char *e = getenv("TXM_THROTTLE");
+    on = (e && e[0] == '0') ? 0 : 1;
+  }
+  return on != 0;
+}
+
 static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   if (!i8_supported(N, C, nrep, K)) return false;
   const int ov = path_override();
@@ -635,7 +683,7 @@ static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   // last column group must also hold more than 16 columns.
   const int64_t ctail = C % I8_CPAD;
   const int64_t min_rep = K >= 4 ? 64 : 384;
-  return K >= 3 && C > 16 && (ctail == 0 || ctail > 16) && nrep >= min_rep && N >= 4 * I8_WIN_TILES * SM_T;
+  return K >= 3 && C > 16 && (ctail == 0 || ctail > 16) && nrep >= min_rep && N >= 262144;
 }
 
 }  // namespace txm
@@ -799,6 +847,7 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
     b.n_list = (uint32_t *)((char *)ws + q.off_nlist);
     b.sub_tiles = q.sub_tiles;
     TXM_HIP(hipMemsetAsync(b.n_list, 0, 256, st));
+    b.progress = (throttle_on() && q.n_rbg > 1) ? (uint32_t *)((char *)ws + q.off_prog) : nullptr;
     // the FP64 kernel in listed mode: contracts the windows the precision guard flags (none on ordinary data)
     ResampleArgs f;
     f.ldx_s = ldx_s; f.u = u; f.w = w; f.N = N; f.nrep = nrep;
@@ -810,14 +859,14 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
     f.part_u = (double *)((char *)ws + q.off_fbu);
     f.n_chunks = q.fb.n_chunks; f.n_rbg = q.fb.n_rbg; f.tiles_per_chunk = q.fb.tiles_per_chunk;
     f.nrep_pad = q.fb.nrep_pad; f.C_pad = q.fb.C_pad;
-    f.list = b.list; f.n_list = b.n_list; f.sub_tiles = q.sub_tiles; f.batch = nullptr;
+    f.list = b.list; f.n_list = b.n_list; f.sub_tiles = q.sub_tiles; f.batch = nullptr; f.progress = nullptr;
     TXM_REQUIRE(q.fb.nrep_pad == q.nrep_pad, "resample_vals: replicate padding of the two kernels differs");
     // one launch (or two, orders 5-7) per group of 32 columns; the groups reuse the partial buffers
     for (int64_t col0 = 0; col0 < C; col0 += I8_CPAD) {
       b.col0 = col0;
       b.C = C - col0 < I8_CPAD ? C - col0 : I8_CPAD;
       TXM_HIP(hipMemsetAsync(b.part_x, 0, q.off_wt - q.off_px, st));
-      const int rc = launch_resample_i8(b, K, w != nullptr, st);
+      const int rc = launch_resample_i8(b, K, w != nullptr, q.prog_bytes, st);
       if (rc != TXM_OK) return rc;
       f.x = x + col0; f.C = b.C; f.col_off = col0;
       {
@@ -875,6 +924,11 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
   a.n_chunks = p.n_chunks; a.n_rbg = p.n_rbg; a.tiles_per_chunk = p.tiles_per_chunk;
   a.nrep_pad = p.nrep_pad; a.C_pad = p.C_pad;
   a.list = nullptr; a.n_list = nullptr; a.sub_tiles = 0; a.col_off = 0; a.batch = nullptr;
+  a.progress = nullptr;
+  if (throttle_on() && p.n_rbg > 1 && a.N >= SM_T) {
+    a.progress = (uint32_t *)((char *)ws + p.off_prog);
+    TXM_HIP(hipMemsetAsync(a.progress, 0, p.prog_bytes, st));
+  }
   TXM_K_SWITCH(K, return run_resample<KK>(a, p, w != nullptr, explicit_, out, st));
   return TXM_OK;
 }
@@ -958,6 +1012,7 @@ extern "C" int txm_resample_vals_batched(const txm_state_ptrs *states_host, int6
   a.nrep_pad = p.nrep_pad; a.C_pad = p.C_pad;
   a.list = nullptr; a.n_list = nullptr; a.sub_tiles = 0; a.col_off = 0;
   a.batch = tab;
+  a.progress = nullptr;
   TXM_K_SWITCH(K, return run_resample<KK>(a, p, weighted, explicit_, out, st, S));
   return TXM_OK;
 }

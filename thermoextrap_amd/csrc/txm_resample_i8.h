@@ -7,7 +7,7 @@ namespace txm {
 
 constexpr int I8_REPS = 64;        // replicates per workgroup (2 MFMA row blocks of 32)
 constexpr int I8_NSL = 7;          // signed 8-bit slices of the 51-bit fixed-point operand
-constexpr int I8_WIN_TILES = 64;   // sampler tiles per scaling window (65536 samples); short chunks use 16 or 4
+constexpr int I8_WIN_TILES = 256;  // sampler tiles per scaling window (262144 samples); short chunks use 64, 16 or 4
 constexpr int I8_CPAD = 32;        // columns of one MFMA column block
 constexpr int I8_WT_STRIDE = 80;   // doubles per window-table entry
 constexpr int I8_SUB_TILES = 8;    // tiles per entry of the FP64 fallback list (a flagged window = win_tiles / 8 runs)
@@ -43,18 +43,23 @@ struct I8Args {
   double *part_u;          // [n_chunks][7 digits][nrep_pad][K]
   int n_chunks, n_rbg;
   int64_t tiles_per_chunk; // multiple of win_tiles
-  int64_t win_tiles;       // sampler tiles per scaling window: 64, 16 or 4
+  int64_t win_tiles;       // sampler tiles per scaling window: 256, 64, 16 or 4
   int64_t nrep_pad;
   // precision guard: flag[w] != 0 -> window w is left to the FP64 kernel (run list built by i8_list_kernel)
   uint32_t *wflag;         // [nwin]
   uint32_t *list;          // [nwin * (win_tiles / sub_tiles)] first tile of every run; n_list[0] = runs, n_list[1] += flagged windows
   uint32_t *n_list;
   int sub_tiles;           // tiles per run: min(I8_SUB_TILES, win_tiles)
+  // L2-sharing hint (see ResampleArgs::progress in txm_resample.hip): the replicate groups of a chunk publish the
+  // tiles they have finished and stay within I8_LEAD tiles of each other, so that the chunk is streamed from HBM once
+  uint32_t *progress;      // [n_chunks][64], zeroed by the launcher; nullptr: off
 };
+constexpr uint32_t I8_LEAD = 2;
+constexpr int I8_THROTTLE_SPINS = 48;
 
 // true when the int8 path can take this problem (device-sampler mode only)
 bool i8_supported(int64_t N, int64_t C, int64_t nrep, int K);
 // launches the window-scale pass and the bootstrap kernel; partial sums land in part_x/part_u
-int launch_resample_i8(const I8Args &a, int K, bool weighted, hipStream_t st);
+int launch_resample_i8(const I8Args &a, int K, bool weighted, size_t prog_bytes, hipStream_t st);
 
 }  // namespace txm

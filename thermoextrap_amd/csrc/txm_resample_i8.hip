@@ -51,11 +51,12 @@ constexpr int I8_STEPS = SM_T / 32;               // k-steps per tile
 
 // ---------------------------------------------------------------------------
 // pre-pass: per-window maxima -> scale / descale table, and the precision guard (txm_resample_i8.h):
-// next to the maxima every thread keeps the mean of |w du^J dx_c| (J = the top power) over 8 consecutive
-// eighths of its rows; the smallest of a column's 64 group means (8 threads x 8 eighths) is the window's
+// next to the maxima every thread keeps the mean of |w du^J dx_c| (J = the top power) over 4 consecutive
+// quarters of its rows; the smallest of a column's 64 group means (16 threads x 4 quarters) is the window's
 // typical monomial.  typ must not be the plain mean: ONE 1e4-sigma sample owns the mean of du^4 over its
 // window, and the replicates that do not draw it (37 %) see only the other samples -- which the window's
 // scale would have rounded away.
+template <bool VEC2>
 __global__ __launch_bounds__(256) void i8_window_kernel(const double *__restrict__ x, int64_t ldx,
                                                         const double *__restrict__ u,
                                                         const double *__restrict__ w, int64_t N,
@@ -63,11 +64,13 @@ __global__ __launch_bounds__(256) void i8_window_kernel(const double *__restrict
                                                         const double *__restrict__ pivot, int J,
                                                         double *__restrict__ wtab,
                                                         uint32_t *__restrict__ wflag) {
+  // thread = (column pair cp, row phase r): 16 lanes read one 256-byte row with 16-byte loads
+  // (VEC2: the column group is 16-byte aligned and the row pitch even), 16 rows per block step
   const int64_t win = blockIdx.x;
   const int64_t i0 = win * win_samples;
   const int64_t i1 = (i0 + win_samples < N) ? i0 + win_samples : N;
-  const int tid = threadIdx.x, c = tid & 31, r = tid >> 5;
-  __shared__ double shx[256], shu[256], shw[256], shg[256], shs[256];
+  const int tid = threadIdx.x, cp = tid & 15, r = tid >> 4;
+  __shared__ double shx[2][256], shg[2][256], shu[256], shw[256], shs[256];
   __shared__ int shn[256];
   // non-finite samples: fmax drops NaN, so track them separately and poison the window's descale
   // factors -- the sums then come out NaN, as they do from the FP64 kernel (0 * NaN in the MFMA)
@@ -77,27 +80,48 @@ __global__ __launch_bounds__(256) void i8_window_kernel(const double *__restrict
   __syncthreads();
   const double pu = pivot[0];
   const double kInf = __longlong_as_double(0x7ff0000000000000ll);
-  double mx = 0.0, mu = 0.0, mw = 0.0, gmin = kInf;
-  bool bx = false, bu = false;
-  if (c < C) {
-    const double px = pivot[1 + col0 + c];
-    const int64_t gs = win_samples / 8;  // rows per eighth (win_samples is a multiple of 4096)
-    for (int g = 0; g < 8; ++g) {
+  double mx[2] = {0.0, 0.0}, gmin[2] = {kInf, kInf}, mu = 0.0, mw = 0.0;
+  bool bx[2] = {false, false}, bu = false;
+  const int c0 = 2 * cp;
+  if (c0 < C) {
+    const bool two = c0 + 1 < C;
+    const double px0 = pivot[1 + col0 + c0], px1 = two ? pivot[1 + col0 + c0 + 1] : 0.0;
+    const int64_t gs = win_samples / 4;  // rows per quarter (win_samples is a multiple of 4096)
+    for (int g = 0; g < 4; ++g) {
       const int64_t ia = i0 + g * gs;
       const int64_t ib = (ia + gs < i1) ? ia + gs : i1;
-      double s = 0.0;
+      double s0 = 0.0, s1 = 0.0;
       int n = 0;
-      for (int64_t i = ia + r; i < ib; i += 8) {
+      for (int64_t i = ia + r; i < ib; i += 16) {
         double a = w ? fabs(w[i]) : 1.0;
         const double du = fabs(u[i] - pu);
         for (int q = 0; q < J; ++q) a *= du;
-        const double v = fabs(x[i * ldx + col0 + c] - px);
-        bx |= !(v <= 1.7976931348623157e308);
-        mx = fmax(mx, v);
-        s += a * v;
+        double x0, x1 = px1;
+        if constexpr (VEC2) {
+          if (two) {
+            const double2 t2 = *reinterpret_cast<const double2 *>(x + i * ldx + col0 + c0);
+            x0 = t2.x;
+            x1 = t2.y;
+          } else {
+            x0 = x[i * ldx + col0 + c0];
+          }
+        } else {
+          x0 = x[i * ldx + col0 + c0];
+          if (two) x1 = x[i * ldx + col0 + c0 + 1];
+        }
+        const double v0 = fabs(x0 - px0), v1 = fabs(x1 - px1);
+        bx[0] |= !(v0 <= 1.7976931348623157e308);
+        bx[1] |= !(v1 <= 1.7976931348623157e308);
+        mx[0] = fmax(mx[0], v0);
+        mx[1] = fmax(mx[1], v1);
+        s0 += a * v0;
+        s1 += a * v1;
         ++n;
       }
-      if (n > 0) gmin = fmin(gmin, s / (double)n);
+      if (n > 0) {
+        gmin[0] = fmin(gmin[0], s0 / (double)n);
+        gmin[1] = fmin(gmin[1], s1 / (double)n);
+      }
     }
   }
   double su = 0.0;
@@ -117,12 +141,16 @@ __global__ __launch_bounds__(256) void i8_window_kernel(const double *__restrict
     su += a;
     ++nu;
   }
-  if (bx) atomicOr(&badx[c], 1);
+  if (bx[0]) atomicOr(&badx[c0], 1);
+  if (bx[1]) atomicOr(&badx[c0 + 1], 1);
   if (bu) atomicOr(&badu, 1);
-  shx[tid] = mx;
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    shx[v][tid] = mx[v];
+    shg[v][tid] = gmin[v];
+  }
   shu[tid] = mu;
   shw[tid] = mw;
-  shg[tid] = gmin;
   shs[tid] = su;
   shn[tid] = nu;
   __syncthreads();
@@ -141,9 +169,12 @@ __global__ __launch_bounds__(256) void i8_window_kernel(const double *__restrict
       shu[tid] = fmax(shu[tid], shu[tid + off]);
       shw[tid] = fmax(shw[tid], shw[tid + off]);
       shs[tid] = fmin(shs[tid], shs[tid + off]);
-      if (off >= 32) {  // keeps the column = tid & 31
-        shx[tid] = fmax(shx[tid], shx[tid + off]);
-        shg[tid] = fmin(shg[tid], shg[tid + off]);
+      if (off >= 16) {  // keeps the column pair = tid & 15
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          shx[v][tid] = fmax(shx[v][tid], shx[v][tid + off]);
+          shg[v][tid] = fmin(shg[v][tid], shg[v][tid + off]);
+        }
       }
     }
     __syncthreads();
@@ -166,10 +197,10 @@ __global__ __launch_bounds__(256) void i8_window_kernel(const double *__restrict
     if (mtop > theta * shs[0]) atomicOr(&flagged, 1);
   }
   if (tid < 32) {
-    const double m = shx[tid];
+    const double m = shx[tid & 1][tid >> 1], typ = shg[tid & 1][tid >> 1];  // column tid = 2 * (tid >> 1) + (tid & 1)
     wt[I8_WT_SC + tid] = m > 0.0 ? 0x1p50 / m : 0.0;
     wt[I8_WT_DSC + tid] = badx[tid] ? __longlong_as_double(0x7ff8000000000000ll) : m * 0x1p-50;
-    if (tid < C && mtop * m > theta * shg[tid]) atomicOr(&flagged, 1);
+    if (tid < C && mtop * m > theta * typ) atomicOr(&flagged, 1);
   }
   __syncthreads();
   if (tid == 0) wflag[win] = (uint32_t)flagged;
@@ -570,6 +601,8 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
     }
   };
 
+  uint32_t *pg = a.progress != nullptr ? a.progress + (size_t)chunk * 64 : nullptr;
+  uint32_t tiles_done = 1;  // published value = tiles finished + 1 (0 means "not started")
   // chunks are made of whole windows (tiles_per_chunk is a multiple of win_tiles)
   const int64_t WT = a.win_tiles;
   for (int64_t win = t_begin / WT; win * WT < t_end; ++win) {
@@ -590,6 +623,22 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
       if (wbase > a.N - SM_T) wbase = a.N - SM_T;  // the last tile slides its window back
       const uint32_t shift = (uint32_t)(i_tile - wbase);
 
+      if (pg != nullptr && wave == 0) {  // wave-uniform; the other waves are held by the next barrier
+        if (lane == 0) __hip_atomic_store(&pg[rbg & 63], tiles_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll 1
+        for (int spin = 0; spin < I8_THROTTLE_SPINS; ++spin) {
+          uint32_t v = __hip_atomic_load(&pg[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (v == 0u) v = 0xffffffffu;  // unused slot or a group that has not started
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t w2 = (uint32_t)__shfl_xor((int)v, o);
+            v = w2 < v ? w2 : v;
+          }
+          if (tiles_done <= v + I8_LEAD) break;
+          __builtin_amdgcn_s_sleep(32);
+        }
+      }
+      ++tiles_done;
       TXM_TICK(7);
       I8Chunk r0;
       load_chunk(wbase, 0, r0);
@@ -661,6 +710,8 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
     flush(win);
     TXM_TICK(6);
   }
+  if (pg != nullptr && threadIdx.x == 0)  // finished: never hold the others back
+    __hip_atomic_store(&pg[rbg & 63], 0xfffffff0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef TXM_I8_TIMING
   if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 133))
     for (int k = 0; k < 8; ++k) a.wtab[a.nwin * I8_WT_STRIDE + ((blockIdx.x ? 1 : 0) * 8 + wave) * 8 + k] = (double)tm[k];
@@ -674,7 +725,8 @@ bool i8_supported(int64_t N, int64_t C, int64_t nrep, int K) {
 }
 
 template <int K, int J0, int JN>
-static int launch_pass(const I8Args &a, bool weighted, hipStream_t st) {
+static int launch_pass(const I8Args &a, bool weighted, size_t prog_bytes, hipStream_t st) {
+  if (a.progress != nullptr) TXM_HIP(hipMemsetAsync(a.progress, 0, prog_bytes, st));  // every pass starts from "not started"
   const dim3 grid((unsigned)(a.n_chunks * a.n_rbg)), block(I8_BLOCK);
   constexpr int buf = 3 * JN * 2048 + (JN + (8 * JN + 31) / 32) * I8_FRAG;  // pair rows + plain fragments
   const size_t lds = (size_t)I8_CNT_BYTES + 2u * (size_t)buf + I8_REPS * sizeof(uint32_t) +
@@ -696,23 +748,28 @@ static int launch_pass(const I8Args &a, bool weighted, hipStream_t st) {
   return TXM_OK;
 }
 
-int launch_resample_i8(const I8Args &a, int K, bool weighted, hipStream_t st) {
-  hipLaunchKernelGGL(i8_window_kernel, dim3((unsigned)a.nwin), dim3(256), 0, st, a.x, a.ldx_s, a.u, a.w,
-                     a.N, a.C, a.col0, a.win_tiles * SM_T, a.pivot, K - 1, a.wtab, a.wflag);
+int launch_resample_i8(const I8Args &a, int K, bool weighted, size_t prog_bytes, hipStream_t st) {
+  const bool vec2 = ((reinterpret_cast<uintptr_t>(a.x + a.col0) & 15) == 0) && (a.ldx_s % 2 == 0);
+  if (vec2)
+    hipLaunchKernelGGL(i8_window_kernel<true>, dim3((unsigned)a.nwin), dim3(256), 0, st, a.x, a.ldx_s, a.u, a.w,
+                       a.N, a.C, a.col0, a.win_tiles * SM_T, a.pivot, K - 1, a.wtab, a.wflag);
+  else
+    hipLaunchKernelGGL(i8_window_kernel<false>, dim3((unsigned)a.nwin), dim3(256), 0, st, a.x, a.ldx_s, a.u, a.w,
+                       a.N, a.C, a.col0, a.win_tiles * SM_T, a.pivot, K - 1, a.wtab, a.wflag);
   TXM_LAUNCH_CHECK();
   hipLaunchKernelGGL(i8_list_kernel, dim3(1), dim3(256), 0, st, a.wflag, a.nwin, a.win_tiles, a.sub_tiles, a.list,
                      a.n_list);
   TXM_LAUNCH_CHECK();
   int rc = TXM_OK;
   switch (K) {
-    case 2: rc = launch_pass<2, 0, 2>(a, weighted, st); break;
-    case 3: rc = launch_pass<3, 0, 3>(a, weighted, st); break;
-    case 4: rc = launch_pass<4, 0, 4>(a, weighted, st); break;
-    case 5: rc = launch_pass<5, 0, 5>(a, weighted, st); break;
+    case 2: rc = launch_pass<2, 0, 2>(a, weighted, prog_bytes, st); break;
+    case 3: rc = launch_pass<3, 0, 3>(a, weighted, prog_bytes, st); break;
+    case 4: rc = launch_pass<4, 0, 4>(a, weighted, prog_bytes, st); break;
+    case 5: rc = launch_pass<5, 0, 5>(a, weighted, prog_bytes, st); break;
     // orders 5..7: two passes over the sampler stream, each with its own powers
-    case 6: rc = launch_pass<6, 0, 3>(a, weighted, st); if (rc == TXM_OK) rc = launch_pass<6, 3, 3>(a, weighted, st); break;
-    case 7: rc = launch_pass<7, 0, 4>(a, weighted, st); if (rc == TXM_OK) rc = launch_pass<7, 4, 3>(a, weighted, st); break;
-    case 8: rc = launch_pass<8, 0, 4>(a, weighted, st); if (rc == TXM_OK) rc = launch_pass<8, 4, 4>(a, weighted, st); break;
+    case 6: rc = launch_pass<6, 0, 3>(a, weighted, prog_bytes, st); if (rc == TXM_OK) rc = launch_pass<6, 3, 3>(a, weighted, prog_bytes, st); break;
+    case 7: rc = launch_pass<7, 0, 4>(a, weighted, prog_bytes, st); if (rc == TXM_OK) rc = launch_pass<7, 4, 3>(a, weighted, prog_bytes, st); break;
+    case 8: rc = launch_pass<8, 0, 4>(a, weighted, prog_bytes, st); if (rc == TXM_OK) rc = launch_pass<8, 4, 4>(a, weighted, prog_bytes, st); break;
     default: set_error("resample_i8: order out of range"); return TXM_ERR_INVALID;
   }
   return rc;

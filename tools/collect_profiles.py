@@ -60,7 +60,13 @@ for k, d in traffic.items():
     d["read_bytes_corrected_x2"] = 2 * f
     d["write_bytes"] = w
     d["hbm_bytes_per_launch"] = 2 * f + w
-json.dump({"tag": tag, "note": "FETCH_SIZE x2 correction per MI355X_MICROARCH.md (calibrated for 16 B/lane streams; "
+workload = {"n_samp": 100_000_000, "n_obs": 32, "order": 4, "nrep": 1000}
+for a in sys.argv[2:]:  # e.g. n_samp=1e8 order=6
+    k, v = a.split("=")
+    workload[k] = int(float(v))
+json.dump({"tag": tag, "workload": workload,
+           "command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline (one rocprofv3 --pmc pass per counter)",
+           "note": "FETCH_SIZE x2 correction per MI355X_MICROARCH.md (calibrated for 16 B/lane streams; "
            "the bootstrap kernel's 8 B/lane x loads are uncalibrated, so its figure is an upper bound)",
            "kernels": traffic}, open(out / f"{tag}_traffic.json", "w"), indent=1)
 print(open(out / f"{tag}_kernel_stats.csv").read() if rows else "no trace")
