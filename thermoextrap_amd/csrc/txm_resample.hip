@@ -171,7 +171,12 @@ __device__ __forceinline__ void fill_tile_full(const ResampleArgs &a, const uint
 // that belong to the previous tile a zero count, so the hot loop has no
 // bounds handling at all.  Only data sets shorter than one tile (SMALLN) use
 // clamped addresses, in a separate instantiation.
-template <int K, int NBLK, bool WEIGHTED, bool EXPLICIT, bool SMALLN>
+// MODE: RS_PLAIN = one state point, contiguous chunk of tiles; RS_LISTED = the runs of the fallback list;
+// RS_BATCHED = state blockIdx.z of a batch.  Compile-time so that the plain kernel carries none of the other modes'
+// loop state (scalar registers are what this kernel runs out of first: spilled SGPRs cost vector instructions,
+// and every vector instruction here costs FP64-MFMA time).
+constexpr int RS_PLAIN = 0, RS_LISTED = 1, RS_BATCHED = 2;
+template <int K, int NBLK, bool WEIGHTED, bool EXPLICIT, bool SMALLN, int MODE = RS_PLAIN>
 __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   // readfirstlane: tell the compiler the wave index is wave-uniform, so everything
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
   const int64_t *FREQ = a.freq;
   double *PX = a.part_x, *PU = a.part_u;
   uint32_t rid0 = 0;
-  if (a.batch != nullptr) {
+  if constexpr (MODE == RS_BATCHED) {
     const int64_t sidx = blockIdx.z;
     const txm_state_ptrs bs = a.batch[sidx];
     X = bs.x;
@@ -213,9 +218,9 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
     PU += (size_t)sidx * a.n_chunks * a.nrep_pad * K;
     rid0 = (uint32_t)(sidx * a.nrep);
   }
-  const bool listed = a.list != nullptr;  // kernel argument: uniform
+  constexpr bool listed = MODE == RS_LISTED;
   int64_t nruns = 1;
-  if (listed) {
+  if constexpr (listed) {
     nruns = (int64_t)*a.n_list;
     if (nruns == 0) return;  // nothing flagged: the finalize kernel does not read this launch's partial sums
   }
@@ -260,12 +265,12 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
   uint32_t *pg = nullptr;
   uint32_t tiles_done = 0;
   const int pslot = (rbg * RS_WAVES + wave) & 63;
-  if (a.progress != nullptr)
-    pg = a.progress + ((size_t)((blockIdx.z * gridDim.y + colgrp) * a.n_chunks + chunk)) * 64;
+  if constexpr (MODE == RS_PLAIN && !SMALLN)
+    if (a.progress != nullptr) pg = a.progress + ((size_t)(colgrp * a.n_chunks + chunk)) * 64;
   double cnt = 0.0;  // lanes kk == 0, unweighted: the replicate's draws in the contracted tiles (exact integers)
   for (int64_t run = listed ? chunk : 0; run < nruns; run += listed ? a.n_chunks : 1) {
   int64_t tb = t_begin, te = t_end;
-  if (listed) {
+  if constexpr (listed) {
     tb = (int64_t)a.list[run];
     te = tb + a.sub_tiles;
     if (te > a.ntiles) te = a.ntiles;
@@ -611,7 +616,7 @@ struct I8Plan {
   size_t off_pivot, off_px, off_pu, off_wt, total;
   // precision-guard fallback: window flags, run list, and the FP64 kernel's plan / partial sums for one column group
   int sub_tiles;
-  size_t off_flag, off_list, off_nlist, off_fbx, off_fbu, off_prog, prog_bytes;
+  size_t off_flag, off_list, off_nlist, off_fbx, off_fbu, off_prog, prog_bytes, off_stats;
   ResamplePlan fb;
 };
 
@@ -645,7 +650,8 @@ static I8Plan plan_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   p.off_fbu = p.off_fbx + align_up((size_t)p.fb.n_chunks * p.fb.nrep_pad * p.fb.C_pad * K * sizeof(double), 256);
   p.off_prog = p.off_fbu + align_up((size_t)p.fb.n_chunks * p.fb.nrep_pad * K * sizeof(double), 256);
   p.prog_bytes = (size_t)p.n_chunks * 64 * sizeof(uint32_t);
-  p.total = p.off_prog + align_up(p.prog_bytes, 256);
+  p.off_stats = p.off_prog + align_up(p.prog_bytes, 256);
+  p.total = p.off_stats + align_up((size_t)cdiv(p.ntiles, p.win_tiles < 16 ? p.win_tiles : 16) * 100 * sizeof(double), 256);
   return p;
 }
 
@@ -748,12 +754,17 @@ static int run_resample(ResampleArgs a, const ResamplePlan &p, bool weighted, bo
                         double *out, hipStream_t st, int64_t S = 1) {
   dim3 grid((unsigned)(p.n_chunks * p.n_rbg), (unsigned)p.colgroups, (unsigned)S), block(RS_BLOCK);
   const size_t lds = explicit_ ? 0 : (size_t)RS_WAVES * RS_TILE_BYTES;
-#define TXM_RS_LAUNCH(NB, WT, EX)                                                          \
-  do {                                                                                    \
-    if (a.N < SM_T)                                                                       \
-      hipLaunchKernelGGL((resample_kernel<K, NB, WT, EX, true>), grid, block, lds, st, a);  \
-    else                                                                                  \
-      hipLaunchKernelGGL((resample_kernel<K, NB, WT, EX, false>), grid, block, lds, st, a); \
+#define TXM_RS_LAUNCH(NB, WT, EX)                                                                       \
+  do {                                                                                                 \
+    if (S > 1 || a.batch != nullptr) {                                                                 \
+      if (a.N < SM_T)                                                                                  \
+        hipLaunchKernelGGL((resample_kernel<K, NB, WT, EX, true, RS_BATCHED>), grid, block, lds, st, a);  \
+      else                                                                                             \
+        hipLaunchKernelGGL((resample_kernel<K, NB, WT, EX, false, RS_BATCHED>), grid, block, lds, st, a); \
+    } else if (a.N < SM_T)                                                                             \
+      hipLaunchKernelGGL((resample_kernel<K, NB, WT, EX, true>), grid, block, lds, st, a);             \
+    else                                                                                               \
+      hipLaunchKernelGGL((resample_kernel<K, NB, WT, EX, false>), grid, block, lds, st, a);            \
   } while (0)
   if (p.nblk == 1) {
     if (weighted) { if (explicit_) TXM_RS_LAUNCH(1, true, true); else TXM_RS_LAUNCH(1, true, false); }
@@ -777,11 +788,11 @@ static int run_listed_k(const ResampleArgs &a, const ResamplePlan &p, bool weigh
   dim3 grid((unsigned)(p.n_chunks * p.n_rbg), (unsigned)p.colgroups), block(RS_BLOCK);
   const size_t lds = (size_t)RS_WAVES * RS_TILE_BYTES;
   if (p.nblk == 1) {
-    if (weighted) hipLaunchKernelGGL((resample_kernel<K, 1, true, false, false>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((resample_kernel<K, 1, false, false, false>), grid, block, lds, st, a);
+    if (weighted) hipLaunchKernelGGL((resample_kernel<K, 1, true, false, false, RS_LISTED>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((resample_kernel<K, 1, false, false, false, RS_LISTED>), grid, block, lds, st, a);
   } else {
-    if (weighted) hipLaunchKernelGGL((resample_kernel<K, 2, true, false, false>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((resample_kernel<K, 2, false, false, false>), grid, block, lds, st, a);
+    if (weighted) hipLaunchKernelGGL((resample_kernel<K, 2, true, false, false, RS_LISTED>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((resample_kernel<K, 2, false, false, false, RS_LISTED>), grid, block, lds, st, a);
   }
   TXM_LAUNCH_CHECK();
   return TXM_OK;
@@ -836,6 +847,7 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
     b.last_tile_size = (uint32_t)(N - (q.ntiles - 1) * SM_T);
     b.pivot = piv;
     b.wtab = (double *)((char *)ws + q.off_wt);
+    b.stats = (double *)((char *)ws + q.off_stats);
     b.nwin = q.nwin;
     b.part_x = (double *)((char *)ws + q.off_px);
     b.part_u = (double *)((char *)ws + q.off_pu);

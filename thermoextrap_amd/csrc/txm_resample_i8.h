@@ -38,6 +38,7 @@ struct I8Args {
   uint32_t last_tile_size;
   const double *pivot;     // [1 + all columns]: {pivot_u, pivot_x[...]}, indexed with col0
   double *wtab;            // [nwin][I8_WT_STRIDE]
+  double *stats;           // [ceil(ntiles / min(16, win_tiles))][100] per-sub-block statistics of the pre-pass
   int64_t nwin;
   double *part_x;          // [n_chunks][7 digits][K][nrep_pad][32]   (zeroed by the launcher)
   double *part_u;          // [n_chunks][7 digits][nrep_pad][K]

@@ -50,53 +50,73 @@ constexpr int I8_FRAG = 1024;                     // one 32 x 32 int8 MFMA opera
 constexpr int I8_STEPS = SM_T / 32;               // k-steps per tile
 
 // ---------------------------------------------------------------------------
-// pre-pass: per-window maxima -> scale / descale table, and the precision guard (txm_resample_i8.h):
-// next to the maxima every thread keeps the mean of |w du^J dx_c| (J = the top power) over 4 consecutive
-// quarters of its rows; the smallest of a column's 64 group means (16 threads x 4 quarters) is the window's
-// typical monomial.  typ must not be the plain mean: ONE 1e4-sigma sample owns the mean of du^4 over its
-// window, and the replicates that do not draw it (37 %) see only the other samples -- which the window's
-// scale would have rounded away.
+// pre-pass: per-window maxima -> scale / descale table, and the precision guard (txm_resample_i8.h).
+//
+// i8_stats_kernel: one block per SUB-BLOCK of <= 16 tiles (a 256-tile window alone would give the chip 1.5 blocks
+// per CU).  Next to the maxima it takes the mean of |w du^J dx_c| (J = the top power) over groups of samples and
+// keeps the smallest group mean: a robust "typical monomial".  typ must not be the plain mean: ONE 1e4-sigma sample
+// owns the mean of du^4 over its window, and the replicates that do not draw it (37 %) see only the other samples --
+// which the window's scale would have rounded away.  Groups: a window of several sub-blocks uses 4 groups per
+// sub-block and column (quarters of its rows); a window that is one sub-block uses 64 (quarter x row phase).
+// i8_table_kernel: one block per window: combines its sub-blocks, writes the window table entry and the flag.
+constexpr int I8_ST_MAXDU = 0, I8_ST_MAXW = 1, I8_ST_UMIN = 2, I8_ST_BADU = 3, I8_ST_MAXX = 4, I8_ST_GMIN = 36,
+              I8_ST_BADX = 68, I8_ST_STRIDE = 100;
+constexpr int I8_STAT_TILES = 16;  // tiles per sub-block
+
 template <bool VEC2>
-__global__ __launch_bounds__(256) void i8_window_kernel(const double *__restrict__ x, int64_t ldx,
-                                                        const double *__restrict__ u,
-                                                        const double *__restrict__ w, int64_t N,
-                                                        int64_t C, int64_t col0, int64_t win_samples,
-                                                        const double *__restrict__ pivot, int J,
-                                                        double *__restrict__ wtab,
-                                                        uint32_t *__restrict__ wflag) {
+__global__ __launch_bounds__(256) void i8_stats_kernel(const double *__restrict__ x, int64_t ldx,
+                                                       const double *__restrict__ u,
+                                                       const double *__restrict__ w, int64_t N, int64_t C,
+                                                       int64_t col0, int64_t sub_samples, int fine_groups,
+                                                       const double *__restrict__ pivot, int J,
+                                                       double *__restrict__ stats) {
   // thread = (column pair cp, row phase r): 16 lanes read one 256-byte row with 16-byte loads
-  // (VEC2: the column group is 16-byte aligned and the row pitch even), 16 rows per block step
-  const int64_t win = blockIdx.x;
-  const int64_t i0 = win * win_samples;
-  const int64_t i1 = (i0 + win_samples < N) ? i0 + win_samples : N;
+  const int64_t sb = blockIdx.x;
+  const int64_t i0 = sb * sub_samples;
+  const int64_t i1 = (i0 + sub_samples < N) ? i0 + sub_samples : N;
   const int tid = threadIdx.x, cp = tid & 15, r = tid >> 4;
+  __shared__ double shq[4][2][256];  // per-thread quarter sums of the two columns
+  __shared__ int shqn[4][256];
   __shared__ double shx[2][256], shg[2][256], shu[256], shw[256], shs[256];
   __shared__ int shn[256];
-  // non-finite samples: fmax drops NaN, so track them separately and poison the window's descale
-  // factors -- the sums then come out NaN, as they do from the FP64 kernel (0 * NaN in the MFMA)
-  __shared__ int badx[32], badu, flagged;
+  __shared__ int badx[32], badu;
   if (tid < 32) badx[tid] = 0;
-  if (tid == 0) badu = flagged = 0;
+  if (tid == 0) badu = 0;
   __syncthreads();
   const double pu = pivot[0];
   const double kInf = __longlong_as_double(0x7ff0000000000000ll);
   double mx[2] = {0.0, 0.0}, gmin[2] = {kInf, kInf}, mu = 0.0, mw = 0.0;
   bool bx[2] = {false, false}, bu = false;
   const int c0 = 2 * cp;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    shq[g][0][tid] = shq[g][1][tid] = 0.0;
+    shqn[g][tid] = 0;
+  }
   if (c0 < C) {
     const bool two = c0 + 1 < C;
     const double px0 = pivot[1 + col0 + c0], px1 = two ? pivot[1 + col0 + c0 + 1] : 0.0;
-    const int64_t gs = win_samples / 4;  // rows per quarter (win_samples is a multiple of 4096)
+    const int64_t gs = sub_samples / 4;  // rows per quarter (sub_samples is a multiple of 4096)
     for (int g = 0; g < 4; ++g) {
       const int64_t ia = i0 + g * gs;
       const int64_t ib = (ia + gs < i1) ? ia + gs : i1;
       double s0 = 0.0, s1 = 0.0;
       int n = 0;
-      for (int64_t i = ia + r; i < ib; i += 16) {
-        double a = w ? fabs(w[i]) : 1.0;
-        const double du = fabs(u[i] - pu);
+      auto body = [&](double x0, double x1, double ui, double wi) {
+        double a = fabs(wi);
+        const double du = fabs(ui - pu);
         for (int q = 0; q < J; ++q) a *= du;
-        double x0, x1 = px1;
+        const double v0 = fabs(x0 - px0), v1 = fabs(x1 - px1);
+        bx[0] |= !(v0 <= 1.7976931348623157e308);
+        bx[1] |= !(v1 <= 1.7976931348623157e308);
+        mx[0] = fmax(mx[0], v0);
+        mx[1] = fmax(mx[1], v1);
+        s0 += a * v0;
+        s1 += a * v1;
+        ++n;
+      };
+      auto load = [&](int64_t i, double &x0, double &x1, double &ui, double &wi) {
+        x1 = px1;
         if constexpr (VEC2) {
           if (two) {
             const double2 t2 = *reinterpret_cast<const double2 *>(x + i * ldx + col0 + c0);
@@ -109,15 +129,26 @@ __global__ __launch_bounds__(256) void i8_window_kernel(const double *__restrict
           x0 = x[i * ldx + col0 + c0];
           if (two) x1 = x[i * ldx + col0 + c0 + 1];
         }
-        const double v0 = fabs(x0 - px0), v1 = fabs(x1 - px1);
-        bx[0] |= !(v0 <= 1.7976931348623157e308);
-        bx[1] |= !(v1 <= 1.7976931348623157e308);
-        mx[0] = fmax(mx[0], v0);
-        mx[1] = fmax(mx[1], v1);
-        s0 += a * v0;
-        s1 += a * v1;
-        ++n;
+        ui = u[i];
+        wi = w ? w[i] : 1.0;
+      };
+      int64_t i = ia + r;
+      constexpr int UNR = 4;  // rows in flight per lane
+      for (; i + (UNR - 1) * 16 < ib; i += UNR * 16) {
+        double x0[UNR], x1[UNR], ui[UNR], wi[UNR];
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) load(i + q * 16, x0[q], x1[q], ui[q], wi[q]);
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) body(x0[q], x1[q], ui[q], wi[q]);
       }
+      for (; i < ib; i += 16) {
+        double x0, x1, ui, wi;
+        load(i, x0, x1, ui, wi);
+        body(x0, x1, ui, wi);
+      }
+      shq[g][0][tid] = s0;
+      shq[g][1][tid] = s1;
+      shqn[g][tid] = n;
       if (n > 0) {
         gmin[0] = fmin(gmin[0], s0 / (double)n);
         gmin[1] = fmin(gmin[1], s1 / (double)n);
@@ -154,11 +185,34 @@ __global__ __launch_bounds__(256) void i8_window_kernel(const double *__restrict
   shs[tid] = su;
   shn[tid] = nu;
   __syncthreads();
-  // u row: 64 groups of 4 adjacent threads (samples = 4g .. 4g+3 mod 256) -> group means -> their minimum
+  if (!fine_groups) {
+    // coarse groups: the 16 row phases of a quarter together (fixed order) -> 4 group means per column
+#pragma unroll
+    for (int v = 0; v < 2; ++v) shg[v][tid] = kInf;
+    __syncthreads();
+    if (tid < 128) {
+      const int g = tid >> 5, col = tid & 31, ccp = col >> 1, v = col & 1;
+      double sg = 0.0;
+      int ng = 0;
+      for (int rr = 0; rr < 16; ++rr) {
+        sg += shq[g][v][rr * 16 + ccp];
+        ng += shqn[g][rr * 16 + ccp];
+      }
+      // park the group mean where the tree below (which keeps tid & 15 = column pair) finds it: row phase g
+      if (ng > 0) shg[v][g * 16 + ccp] = sg / (double)ng;
+    }
+    __syncthreads();
+  }
+  // u row: groups of 4 adjacent threads (fine: 64 groups) or of 64 (coarse: 4 groups) -> group means -> their minimum
   double umin = kInf;
-  if (tid < 64) {
-    const double sg = shs[4 * tid] + shs[4 * tid + 1] + shs[4 * tid + 2] + shs[4 * tid + 3];
-    const int ng = shn[4 * tid] + shn[4 * tid + 1] + shn[4 * tid + 2] + shn[4 * tid + 3];
+  const int gw = fine_groups ? 4 : 64;
+  if (tid < 256 / gw) {
+    double sg = 0.0;
+    int ng = 0;
+    for (int k = 0; k < gw; ++k) {
+      sg += shs[gw * tid + k];
+      ng += shn[gw * tid + k];
+    }
     if (ng > 0) umin = sg / (double)ng;
   }
   __syncthreads();
@@ -179,8 +233,50 @@ __global__ __launch_bounds__(256) void i8_window_kernel(const double *__restrict
     }
     __syncthreads();
   }
+  double *st = stats + sb * I8_ST_STRIDE;
+  if (tid == 0) {
+    st[I8_ST_MAXDU] = shu[0];
+    st[I8_ST_MAXW] = shw[0];
+    st[I8_ST_UMIN] = shs[0];
+    st[I8_ST_BADU] = (double)badu;
+  }
+  if (tid < 32) {  // column tid = 2 * (tid >> 1) + (tid & 1)
+    st[I8_ST_MAXX + tid] = shx[tid & 1][tid >> 1];
+    st[I8_ST_GMIN + tid] = shg[tid & 1][tid >> 1];
+    st[I8_ST_BADX + tid] = (double)badx[tid];
+  }
+}
+
+__global__ __launch_bounds__(64) void i8_table_kernel(const double *__restrict__ stats, int nsub, int64_t nsub_total,
+                                                      int64_t N, int64_t C, int64_t win_samples, bool weighted,
+                                                      int J, double *__restrict__ wtab,
+                                                      uint32_t *__restrict__ wflag) {
+  const int64_t win = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int64_t i0 = win * win_samples;
+  const int64_t i1 = (i0 + win_samples < N) ? i0 + win_samples : N;
+  const double kInf = __longlong_as_double(0x7ff0000000000000ll);
+  __shared__ int flagged;
+  if (tid == 0) flagged = 0;
+  __syncthreads();
+  double dumax = 0.0, wmaxv = 0.0, umin = kInf, mx = 0.0, gmin = kInf;
+  bool badu = false, badx = false;
+  for (int k = 0; k < nsub; ++k) {
+    const int64_t sb = win * nsub + k;
+    if (sb >= nsub_total) break;
+    const double *st = stats + sb * I8_ST_STRIDE;
+    dumax = fmax(dumax, st[I8_ST_MAXDU]);
+    wmaxv = fmax(wmaxv, st[I8_ST_MAXW]);
+    umin = fmin(umin, st[I8_ST_UMIN]);
+    badu |= st[I8_ST_BADU] != 0.0;
+    if (tid < 32) {
+      mx = fmax(mx, st[I8_ST_MAXX + tid]);
+      gmin = fmin(gmin, st[I8_ST_GMIN + tid]);
+      badx |= st[I8_ST_BADX + tid] != 0.0;
+    }
+  }
+  const double wmax = weighted ? wmaxv : 1.0;
   double *wt = wtab + win * I8_WT_STRIDE;
-  const double dumax = shu[0], wmax = w ? shw[0] : 1.0;
   // guard: scale of the top power against the typical monomial (NaN / inf compare false: those windows keep
   // the int8 path, whose poisoned descale reproduces the FP64 kernel's non-finite output)
   double mtop = wmax;
@@ -194,13 +290,12 @@ __global__ __launch_bounds__(256) void i8_window_kernel(const double *__restrict
       wt[I8_WT_DSP + j] = d;
       d *= dumax;
     }
-    if (mtop > theta * shs[0]) atomicOr(&flagged, 1);
+    if (mtop > theta * umin) atomicOr(&flagged, 1);
   }
   if (tid < 32) {
-    const double m = shx[tid & 1][tid >> 1], typ = shg[tid & 1][tid >> 1];  // column tid = 2 * (tid >> 1) + (tid & 1)
-    wt[I8_WT_SC + tid] = m > 0.0 ? 0x1p50 / m : 0.0;
-    wt[I8_WT_DSC + tid] = badx[tid] ? __longlong_as_double(0x7ff8000000000000ll) : m * 0x1p-50;
-    if (tid < C && mtop * m > theta * typ) atomicOr(&flagged, 1);
+    wt[I8_WT_SC + tid] = mx > 0.0 ? 0x1p50 / mx : 0.0;
+    wt[I8_WT_DSC + tid] = badx ? __longlong_as_double(0x7ff8000000000000ll) : mx * 0x1p-50;
+    if (tid < C && mtop * mx > theta * gmin) atomicOr(&flagged, 1);
   }
   __syncthreads();
   if (tid == 0) wflag[win] = (uint32_t)flagged;
@@ -749,14 +844,23 @@ static int launch_pass(const I8Args &a, bool weighted, size_t prog_bytes, hipStr
 }
 
 int launch_resample_i8(const I8Args &a, int K, bool weighted, size_t prog_bytes, hipStream_t st) {
-  const bool vec2 = ((reinterpret_cast<uintptr_t>(a.x + a.col0) & 15) == 0) && (a.ldx_s % 2 == 0);
-  if (vec2)
-    hipLaunchKernelGGL(i8_window_kernel<true>, dim3((unsigned)a.nwin), dim3(256), 0, st, a.x, a.ldx_s, a.u, a.w,
-                       a.N, a.C, a.col0, a.win_tiles * SM_T, a.pivot, K - 1, a.wtab, a.wflag);
-  else
-    hipLaunchKernelGGL(i8_window_kernel<false>, dim3((unsigned)a.nwin), dim3(256), 0, st, a.x, a.ldx_s, a.u, a.w,
-                       a.N, a.C, a.col0, a.win_tiles * SM_T, a.pivot, K - 1, a.wtab, a.wflag);
-  TXM_LAUNCH_CHECK();
+  {
+    // sub-blocks of <= 16 tiles; a window is 1 sub-block (4- and 16-tile windows) or win_tiles / 16 of them
+    const int64_t sub_tiles = a.win_tiles < I8_STAT_TILES ? a.win_tiles : I8_STAT_TILES;
+    const int nsub = (int)(a.win_tiles / sub_tiles);
+    const int64_t nsub_total = cdiv(a.ntiles, sub_tiles);
+    const bool vec2 = ((reinterpret_cast<uintptr_t>(a.x + a.col0) & 15) == 0) && (a.ldx_s % 2 == 0);
+    if (vec2)
+      hipLaunchKernelGGL(i8_stats_kernel<true>, dim3((unsigned)nsub_total), dim3(256), 0, st, a.x, a.ldx_s, a.u, a.w,
+                         a.N, a.C, a.col0, sub_tiles * SM_T, nsub == 1 ? 1 : 0, a.pivot, K - 1, a.stats);
+    else
+      hipLaunchKernelGGL(i8_stats_kernel<false>, dim3((unsigned)nsub_total), dim3(256), 0, st, a.x, a.ldx_s, a.u, a.w,
+                         a.N, a.C, a.col0, sub_tiles * SM_T, nsub == 1 ? 1 : 0, a.pivot, K - 1, a.stats);
+    TXM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(i8_table_kernel, dim3((unsigned)a.nwin), dim3(64), 0, st, a.stats, nsub, nsub_total, a.N, a.C,
+                       a.win_tiles * SM_T, a.w != nullptr, K - 1, a.wtab, a.wflag);
+    TXM_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(i8_list_kernel, dim3(1), dim3(256), 0, st, a.wflag, a.nwin, a.win_tiles, a.sub_tiles, a.list,
                      a.n_list);
   TXM_LAUNCH_CHECK();
