@@ -191,9 +191,12 @@ def pmc_traffic(kernel_prefix, shape):
         got = (wl.get("n_samp", 100_000_000), wl.get("n_obs", 32), wl.get("order", 4), wl.get("nrep", 1000))
         if tuple(int(v) for v in got) != tuple(shape):
             continue
-        for k, v in d.get("kernels", {}).items():
-            if k.startswith(kernel_prefix):
-                return v.get("hbm_bytes_per_launch"), "profiles/" + Path(f).name
+        # several instantiations can share the prefix (e.g. the FP64 kernel's empty listed-mode launches): the
+        # one that moved the most bytes is the kernel of this workload
+        hits = [v.get("hbm_bytes_per_launch") for k, v in d.get("kernels", {}).items() if k.startswith(kernel_prefix)]
+        hits = [h for h in hits if h is not None]
+        if hits:
+            return max(hits), "profiles/" + Path(f).name
     return None, None
 
 
