@@ -221,9 +221,19 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # one rank per GPU over RCCL.  TXM_BENCH_BACKEND=gloo is a rehearsal switch for a box with fewer GPUs than
+        # ranks (the ranks then share cards and the final gather goes through host memory): plumbing test only
+        backend = os.environ.get("TXM_BENCH_BACKEND", "nccl")
+        ngpu = torch.cuda.device_count()
+        if backend == "nccl" and local >= ngpu:
+            raise SystemExit(f"rank {rank}: local rank {local} but only {ngpu} GPU(s) visible")
+        local = local % max(ngpu, 1)
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        world = dist.get_world_size()  # the rank count RCCL saw
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+        world = dist.get_world_size()  # the rank count the process group reports
     else:
         torch.cuda.set_device(0)
 
@@ -308,7 +318,7 @@ def main():
     dt = time.perf_counter() - t0
     recording["on"] = False
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = 1e3 * dt / args.steps

@@ -44,6 +44,9 @@ def all_gather_slabs(local: torch.Tensor, counts: Sequence[int] | None = None, g
     rank, w = world()
     if w == 1:
         return local
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal on a box without RCCL peers: gather through host memory
+        return all_gather_slabs(local.cpu(), counts, group).to(local.device)
     if counts is None:
         n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
         ns = [torch.zeros_like(n) for _ in range(w)]
