@@ -402,14 +402,6 @@ __device__ __forceinline__ void i8_slice2(double r0, double r1, uint32_t (&T)[4]
   T[3] = __builtin_amdgcn_perm(h1, h0, 0x07030602u);
 }
 
-__device__ __forceinline__ void i8_store7(unsigned char *base, const uint32_t (&T)[4], int stride) {
-#pragma unroll
-  for (int i = 0; i < I8_NSL; ++i) {
-    const uint32_t v = (i & 1) ? (T[i >> 1] >> 16) : T[i >> 1];
-    *reinterpret_cast<uint16_t *>(base + i * stride) = (uint16_t)v;
-  }
-}
-
 // 1.5 * 2^52 + 0x80 in each of the six low mantissa bytes
 constexpr double I8_MAGIC = 6755399441055744.0 + 141289400074368.0;
 
@@ -452,16 +444,22 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
   const int n32 = lane & 31, half = lane >> 5;
   // slicing role: column c, sample pair g2 of every chunk (a half-wave = 16 pairs x 2 columns = 32
   // consecutive dwords of a pair row)
-  const int g2 = lane & 15, cslot = lane >> 4;
+  const int cslot = lane >> 4;
   const int c = wave * 4 + cslot;
+  // the lane at position (lane & 15) of its column's 16-dword run slices the pair that the rotation puts there, so
+  // that a wave's 64 dwords of a pair row are simply base + 4 * lane: ds_write_addtid_b32
+  const int g2 = ((lane & 15) - 4 * ((c >> 1) & 3)) & 15;
   const int64_t cc = c < a.C ? c : 0;  // columns >= C re-read column 0: their sums are never flushed
   const uint32_t poff = (uint32_t)(c * 64 + ((g2 + 4 * ((c >> 1) & 3)) & 15) * 4);
   const uint32_t foff = (uint32_t)(FRAG0 + c * 32 + g2 * 2);
   // u-row role (lanes of column slot 0): wave jj < 4 slices the power J0 + jj; a fifth power goes to
   // wave 7 (fewest MFMAs), not to wave 4, which shares its SIMD with wave 0
   const int jr = wave < 4 ? wave : 4;
-  const bool urow = cslot == 0 && jr < JN && (wave < 4 || wave == I8_WAVES - 1);
-  const uint32_t uoff = (uint32_t)(FRAG0 + (JN + (jr >> 2)) * I8_FRAG + (jr & 3) * 8 * 32 + g2 * 2);
+  const bool urow = jr < JN && (wave < 4 || wave == I8_WAVES - 1);  // wave-uniform
+  // column slot k of the wave stores the digits 2k, 2k+1 of the u-row monomial (columns 8 jr + 2k, + 1)
+  const uint32_t uoff = (uint32_t)(FRAG0 + (JN + (jr >> 2)) * I8_FRAG + ((jr & 3) * 8 + 2 * cslot) * 32 + g2 * 2);
+  const uint32_t usel = (cslot & 1) ? 0x07030602u : 0x05010400u;   // which byte pair of the two source dwords
+  const uint32_t uxor = cslot == 3 ? 0u : 0x80808080u;             // digit 6 keeps its bias (removed at flush time)
   // MFMA role, the same shape for every wave (no per-wave code paths): the pair rows 2 wave and
   // 2 wave + 1 (4 tiles each: two digits x two replicate halves) and the plain fragment `wave`
   // (2 tiles).  Indices past the end are clamped: those tiles compute a duplicate that is never flushed.
@@ -620,10 +618,11 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
       Rb = *reinterpret_cast<const v4i *>(bcur + p0 * PAIR_B + pr1);
     }
 #endif
-    uint32_t wp = (uint32_t)(bnxt - lds) + poff, wf = (uint32_t)(bnxt - lds) + foff;
-    // opaque per-lane bases + immediate offsets: the B buffers sit above 64 KiB, so constant-folded
+    uint32_t wf = (uint32_t)(bnxt - lds) + foff;  // (pair rows go through M0 + immediates: no per-lane base)
+    (void)poff;
+    // opaque per-lane base + immediate offsets: the B buffers sit above 64 KiB, so constant-folded
     // absolute LDS addresses would take a register each
-    asm volatile("" : "+v"(wp), "+v"(wf));
+    asm volatile("" : "+v"(wf));
     double du[2], dx[2], p[2];
     {
 #pragma unroll
@@ -641,8 +640,18 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
       p[1] *= du[1];
     }
     constexpr int NIT = JN > 3 ? JN : 3;
+    // M0 = LDS byte address of this wave's 256-byte run in pair row 0 of the buffer being filled (ds_write_addtid_b32:
+    // address = M0 + offset + 4 * lane, no address register, half the LDS-path cycles of ds_write_b32)
+    const uint32_t m0base = __builtin_amdgcn_readfirstlane((uint32_t)(bnxt - lds) + (uint32_t)(wave * 256));
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
+#ifdef TXM_I8_NO_PRODUCE
+      const bool do_slice = false;
+#else
+      const bool do_slice = slice && it < JN;
+#endif
+      const int jj = it;
+      uint32_t T[4] = {0, 0, 0, 0};
 #ifndef TXM_I8_NO_MFMA
       if (mf) {
         if (it == 0) {
@@ -666,30 +675,36 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);
-#ifdef TXM_I8_NO_PRODUCE
-      if (false) {
-#else
-      if (slice && it < JN) {
-#endif
-        const int jj = it;
+      if (do_slice) {
         if (jj > 0) {
           p[0] *= du[0];
           p[1] *= du[1];
         }
-        uint32_t T[4];
         i8_slice2(fma(p[0], dx[0], I8_MAGIC), fma(p[1], dx[1], I8_MAGIC), T);
-        *reinterpret_cast<uint32_t *>(lds + wp + (jj * 3 + 0) * PAIR_B) = T[0];
-        *reinterpret_cast<uint32_t *>(lds + wp + (jj * 3 + 1) * PAIR_B) = T[1];
-        *reinterpret_cast<uint32_t *>(lds + wp + (jj * 3 + 2) * PAIR_B) = T[2];
+        // (s_nop: one wait state between an SALU write of M0 and an add-TID LDS instruction; the assembler pads
+        // nothing inside an asm statement)
+        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "ds_write_addtid_b32 %0 offset:%4\n\t"
+                     "ds_write_addtid_b32 %1 offset:%5\n\t"
+                     "ds_write_addtid_b32 %2 offset:%6"
+                     :
+                     : "v"(T[0]), "v"(T[1]), "v"(T[2]), "s"(m0base), "n"((jj * 3 + 0) * PAIR_B),
+                       "n"((jj * 3 + 1) * PAIR_B), "n"((jj * 3 + 2) * PAIR_B)
+                     : "memory");
         *reinterpret_cast<uint16_t *>(lds + wf + jj * I8_FRAG) = (uint16_t)T[3];
         // u-row: p is w * du^(J0 + jj) right now; the wave that owns this power slices it (dx = 1)
         // into the columns 8 jj + i of the packed u-row fragments
-        if (jj == jr) {  // wave-uniform
-          if (urow) {
-            uint32_t U[4];
-            i8_slice2(fma(p[0], 0x1p50, I8_MAGIC), fma(p[1], 0x1p50, I8_MAGIC), U);
-            i8_store7(bnxt + uoff, U, 32);
-          }
+        if (jj == jr && urow) {  // wave-uniform
+          // all four column slots of the wave hold this sample pair's p (it does not depend on the column), so
+          // slot k cuts and stores the digits 2k and 2k+1 only: 2 stores per wave instead of 7 by a quarter of it.
+          // (slot 3's second halfword is the exponent byte pair: it lands in the unused column 8 jj + 7.)
+          const uint64_t b0 = (uint64_t)__double_as_longlong(fma(p[0], 0x1p50, I8_MAGIC));
+          const uint64_t b1 = (uint64_t)__double_as_longlong(fma(p[1], 0x1p50, I8_MAGIC));
+          const uint32_t s0 = cslot < 2 ? (uint32_t)b0 : (uint32_t)(b0 >> 32);
+          const uint32_t s1 = cslot < 2 ? (uint32_t)b1 : (uint32_t)(b1 >> 32);
+          const uint32_t t = __builtin_amdgcn_perm(s1, s0, usel) ^ uxor;
+          *reinterpret_cast<uint16_t *>(bnxt + uoff) = (uint16_t)t;
+          *reinterpret_cast<uint16_t *>(bnxt + uoff + 32) = (uint16_t)(t >> 16);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
