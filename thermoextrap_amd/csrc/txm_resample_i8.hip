@@ -362,14 +362,15 @@ __device__ __forceinline__ void i8_tile_calls(uint32_t *cnt, uint32_t k0, uint32
   }
 }
 
+// `wcnt`: lane i < I8_REPS_WAVE holds counts[rep0w + i][t] (0 past the last replicate), fetched one tile ahead
 __device__ __forceinline__ void i8_fill_full(const I8Args &a, uint32_t *cnt, int64_t rep0w, uint32_t rl0,
-                                             int64_t t, int lane) {
+                                             int64_t t, int lane, uint32_t wcnt) {
 #pragma unroll 1
   for (int p = 0; p < I8_REPS_WAVE / 2; ++p) {
     const int64_t ra = rep0w + 2 * p, rb = ra + 1;
     if (ra >= a.nrep) break;  // wave-uniform
-    const uint32_t na = a.counts[(size_t)ra * a.ntiles + t];
-    const uint32_t nb = rb < a.nrep ? a.counts[(size_t)rb * a.ntiles + t] : 0u;
+    const uint32_t na = (uint32_t)__builtin_amdgcn_readlane((int)wcnt, 2 * p);
+    const uint32_t nb = (uint32_t)__builtin_amdgcn_readlane((int)wcnt, 2 * p + 1);
     const uint32_t la = rl0 + 2u * p, lb = la + 1u;
     if (na >= 768u) i8_tile_calls<true>(cnt, a.k0, a.k1, (uint32_t)ra, (uint32_t)t, (uint32_t)lane, na, la);
     else i8_tile_calls<false>(cnt, a.k0, a.k1, (uint32_t)ra, (uint32_t)t, (uint32_t)lane, na, la);
@@ -393,6 +394,13 @@ __device__ __forceinline__ void i8_fill_full(const I8Args &a, uint32_t *cnt, int
 // constant).  Digit 6 is left as the raw exponent-adjacent byte 0x38 + d6: the constant 56
 // is taken out at flush time as 56 * (sum of counts), which the sampler knows exactly.
 constexpr int I8_D6_BIAS = 0x38;
+// a wave-uniform double, moved to scalar registers (a uniform value loaded through the vector path would otherwise
+// occupy -- or be spilled from -- two vector registers)
+__device__ __forceinline__ double i8_uniform(double v) {
+  const uint64_t b = (uint64_t)__double_as_longlong(v);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+  return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
 __device__ __forceinline__ void i8_slice2(double r0, double r1, uint32_t (&T)[4]) {
   const uint64_t b0 = (uint64_t)__double_as_longlong(r0), b1 = (uint64_t)__double_as_longlong(r1);
   const uint32_t l0 = (uint32_t)b0, l1 = (uint32_t)b1, h0 = (uint32_t)(b0 >> 32), h1 = (uint32_t)(b1 >> 32);
@@ -437,7 +445,10 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
   uint32_t *fsum = reinterpret_cast<uint32_t *>(bb1 + BUF);  // [64] draws per replicate in the window
   // the tile's scaled u deviations (u - pu) / max|u - pu| and weights w / max|w|: loaded once per tile by the
   // whole workgroup instead of once per k-step by every lane
-  double *utile = reinterpret_cast<double *>(fsum + I8_REPS);
+  uint32_t *cntlds = fsum + I8_REPS;  // [64] the next tile's draw counts, parked here while the k-steps run
+  // unweighted: two u tiles (the next tile's u is staged while this one is contracted); weighted: one u + one w tile
+  double *utile = reinterpret_cast<double *>(cntlds + I8_REPS);
+  double *utile_nxt = utile + SM_T;
   double *wtile = utile + SM_T;
 
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -505,6 +516,11 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
   // D layout of v_mfma_i32_32x32x32_i8: column = lane & 31, row = 8 * (reg / 4) + 4 * (lane >> 5) + reg % 4
   uint32_t fdraws = 0;  // lane rr < 8: draws of replicate rep0 + 8 wave + rr in the current window
   const double *wt = a.wtab;
+  // `opq` is an opaque zero that `flush` re-creates for every window (asm volatile).  The flush addresses are built on
+  // it so that they are computed where they are used: left to itself the compiler hoists all 160 of them out of the
+  // window loop and spills them (227 VGPRs in round 1), and every scratch RELOAD in the per-tile code is a vector-memory
+  // wait that also waits for whatever global loads are in flight (s_waitcnt vmcnt is in order) -- the prefetches.
+  int64_t opq = 0;
   // one tile: digit i of power J0 + jj; observable columns (urow_f < 0) or the packed u-row fragment urow_f
   auto flush_tile = [&](v16i &T, int h, int jj, int i, int urow_f) {
     bool valid;
@@ -524,10 +540,10 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
     int64_t stride;
     if (urow_f < 0) {
       // [chunk][digit][power][replicate][32 columns]: the lanes of a row write 256 contiguous bytes
-      base = a.part_x + ((part * K + j) * a.nrep_pad + rep0 + 32 * h + 4 * half) * I8_CPAD + n32;
+      base = a.part_x + ((part * K + j) * a.nrep_pad + rep0 + 32 * h + 4 * half) * I8_CPAD + n32 + opq;
       stride = I8_CPAD;
     } else {
-      base = a.part_u + (part * a.nrep_pad + rep0 + 32 * h + 4 * half) * K + j;
+      base = a.part_u + (part * a.nrep_pad + rep0 + 32 * h + 4 * half) * K + j + opq;
       stride = K;
     }
     double old[16];
@@ -543,6 +559,11 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
     T = (v16i)(0);
   };
   auto flush = [&](int64_t win) {
+    {
+      uint32_t z = 0;
+      asm volatile("" : "+v"(z));
+      opq = (int64_t)z;
+    }
     wt = a.wtab + win * I8_WT_STRIDE;
     if (lane < I8_REPS_WAVE) fsum[wave * I8_REPS_WAVE + lane] = fdraws;
     fdraws = 0;
@@ -719,19 +740,35 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
     if (a.wflag[win] != 0u) continue;  // precision guard: this window goes to the FP64 kernel (wave-uniform)
     {
       const double *wt = a.wtab + win * I8_WT_STRIDE;
-      inv_du = wt[I8_WT_INVDU];
-      if constexpr (WEIGHTED) inv_w = wt[I8_WT_INVW];
+      inv_du = i8_uniform(wt[I8_WT_INVDU]);
+      if constexpr (WEIGHTED) inv_w = i8_uniform(wt[I8_WT_INVW]);
       sc = wt[I8_WT_SC + cc];
     }
     int64_t tt_end = (win + 1) * WT;
     if (tt_end > t_end) tt_end = t_end;
+    // What a tile needs that does not depend on the previous tile is fetched ONE TILE AHEAD: in-order waves park on a
+    // load until it is back, and at the top of a tile every wave of the workgroup would (~7k cycles of HBM latency per
+    // 89k-cycle tile in round 1).  The next tile's u samples and the wave's 8 tile counts are requested at the top of
+    // this tile, are back by the end of the stage-3 fill and are parked in LDS there (second u tile, cntlds) -- not
+    // kept in registers across the k-steps, which have none to spare; the next tile's first x chunk rides in the
+    // load slot of this tile's last slicing call.  (Weighted launches have no LDS left for second u and w tiles:
+    // they prefetch the counts and the x chunk only.)  Nothing is requested across windows.
+    bool have_pref = false;  // uniform
+    I8Chunk r0;
+    const int64_t rep0w = rep0 + wave * I8_REPS_WAVE;
+    const uint32_t rl0 = (uint32_t)(wave * I8_REPS_WAVE);
+    auto tile_base = [&](int64_t tt) {
+      const int64_t b0 = tt * SM_T;
+      return b0 > a.N - SM_T ? a.N - SM_T : b0;  // the last tile slides its window back
+    };
 #pragma unroll 1
     for (int64_t t = win * WT; t < tt_end; ++t) {
       const int64_t i_tile = t * SM_T;
       const uint32_t tsize = (t == a.ntiles - 1) ? a.last_tile_size : (uint32_t)SM_T;
-      int64_t wbase = i_tile;
-      if (wbase > a.N - SM_T) wbase = a.N - SM_T;  // the last tile slides its window back
+      const int64_t wbase = tile_base(t);
       const uint32_t shift = (uint32_t)(i_tile - wbase);
+      const bool has_next = t + 1 < tt_end;
+      const int64_t wnext = has_next ? tile_base(t + 1) : wbase;
 
       if (pg != nullptr && wave == 0) {  // wave-uniform; the other waves are held by the next barrier
         if (lane == 0) __hip_atomic_store(&pg[rbg & 63], tiles_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -750,10 +787,22 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
       }
       ++tiles_done;
       TXM_TICK(7);
-      I8Chunk r0;
-      load_chunk(wbase, 0, r0);
-      {
-        const int i2 = 2 * (int)threadIdx.x;  // 512 threads x 2 samples
+      // The lane id is re-read from the hardware here (opaque to the compiler) and every per-thread address of this
+      // per-tile code is built on it.  Otherwise those addresses are loop invariants that the register allocator keeps
+      // in scratch, and each reload is a vector-memory wait that also waits for the global loads issued just before it
+      // (vmcnt is in order): the requests below would be waited for one after the other, right here.
+      uint32_t lane_f;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_f));
+      const int i2 = 2 * (int)((uint32_t)wave * 64u + lane_f);  // 512 threads x 2 samples
+      const bool cnt_lane = lane_f < (uint32_t)I8_REPS_WAVE && rep0w + (int64_t)lane_f < a.nrep;
+      uint32_t wcnt;  // lane i < 8: draws of replicate rep0w + i in this tile
+      if (!have_pref) {  // first tile of a window: nothing was requested ahead
+        load_chunk(wbase, 0, r0);
+        wcnt = cnt_lane ? a.counts[(size_t)(rep0w + lane_f) * a.ntiles + t] : 0u;
+      } else {
+        wcnt = lane_f < (uint32_t)I8_REPS_WAVE ? cntlds[rl0 + lane_f] : 0u;
+      }
+      if (WEIGHTED || !have_pref) {
         const double u0 = a.u[wbase + i2], u1 = a.u[wbase + i2 + 1];
         utile[i2] = (u0 - pu) * inv_du;
         utile[i2 + 1] = (u1 - pu) * inv_du;
@@ -762,27 +811,35 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
           wtile[i2 + 1] = a.w[wbase + i2 + 1] * inv_w;
         }
       }
+      // requests for the next tile: in flight during the zeroing and the fill below
+      double nu0 = 0.0, nu1 = 0.0;
+      uint32_t ncnt = 0;
+      if (has_next) {
+        if constexpr (!WEIGHTED) {
+          nu0 = a.u[wnext + i2];
+          nu1 = a.u[wnext + i2 + 1];
+        }
+        if (cnt_lane) ncnt = a.counts[(size_t)(rep0w + lane_f) * a.ntiles + t + 1];
+      }
 
       // ---- stage 3 of the sampler: the workgroup's 64 x 1024 count tile -------
-      for (int e = threadIdx.x; e < I8_CNT_BYTES / 16; e += I8_BLOCK)
+      for (int e = i2 / 2; e < I8_CNT_BYTES / 16; e += I8_BLOCK)
         reinterpret_cast<uint4 *>(cnt)[e] = make_uint4(0, 0, 0, 0);
       TXM_TICK(0);
       __syncthreads();
       TXM_TICK(1);
       {
-        const int64_t rep0w = rep0 + wave * I8_REPS_WAVE;
-        const uint32_t rl0 = (uint32_t)(wave * I8_REPS_WAVE);
 #ifdef TXM_I8_NO_FILL
         if (rep0w < 0) {
 #else
         if (tsize == (uint32_t)SM_T) {
 #endif
-          i8_fill_full(a, cnt, rep0w, rl0, t, lane);
+          i8_fill_full(a, cnt, rep0w, rl0, t, lane, wcnt);
         } else if (tsize != (uint32_t)SM_T) {
           for (int rr = 0; rr < I8_REPS_WAVE; ++rr) {
             const int64_t r = rep0w + rr;
             if (r >= a.nrep) break;  // wave-uniform
-            const uint32_t n = a.counts[(size_t)r * a.ntiles + t];
+            const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)wcnt, rr);
             sampler_fine_tile(a.k0, a.k1, (uint32_t)r, (uint32_t)t, n, tsize, lane, [&](uint32_t off0) {
               const uint32_t off = off0 + shift;
               atomicAdd(&cnt[(rl0 + (uint32_t)rr) * I8_CNT_ROW + (off >> 2)], 1u << ((off & 3u) << 3));
@@ -790,8 +847,14 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
           }
         }
       }
-      if (lane < I8_REPS_WAVE && rep0 + wave * I8_REPS_WAVE + lane < a.nrep)
-        fdraws += a.counts[(size_t)(rep0 + wave * I8_REPS_WAVE + lane) * a.ntiles + t];
+      if (cnt_lane) fdraws += wcnt;
+      if (has_next) {  // park what was requested above (same window: same scale factors)
+        if constexpr (!WEIGHTED) {
+          utile_nxt[i2] = (nu0 - pu) * inv_du;
+          utile_nxt[i2 + 1] = (nu1 - pu) * inv_du;
+        }
+        if (lane_f < (uint32_t)I8_REPS_WAVE) cntlds[rl0 + lane_f] = ncnt;
+      }
       TXM_TICK(2);
       __syncthreads();
       TXM_TICK(1);
@@ -812,10 +875,19 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
         __syncthreads();
         TXM_TICK(5);
       }
-      step(bb0, I8_STEPS - 2, bb1, r0, wbase, I8_STEPS - 1, I8_STEPS - 1, true);
+      // the last slicing call has no chunk of this tile left to load: it fetches the next tile's first chunk instead
+      step(bb0, I8_STEPS - 2, bb1, r0, wnext, I8_STEPS - 1, has_next ? 0 : I8_STEPS - 1, true);
       __syncthreads();
       step(bb1, I8_STEPS - 1, bb0, r0, wbase, I8_STEPS - 1, I8_STEPS - 1, false);
       __syncthreads();
+      have_pref = has_next;
+      if constexpr (!WEIGHTED) {
+        if (has_next) {  // the parked u tile becomes the current one
+          double *tmp = utile;
+          utile = utile_nxt;
+          utile_nxt = tmp;
+        }
+      }
     }
     flush(win);
     TXM_TICK(6);
@@ -839,8 +911,8 @@ static int launch_pass(const I8Args &a, bool weighted, size_t prog_bytes, hipStr
   if (a.progress != nullptr) TXM_HIP(hipMemsetAsync(a.progress, 0, prog_bytes, st));  // every pass starts from "not started"
   const dim3 grid((unsigned)(a.n_chunks * a.n_rbg)), block(I8_BLOCK);
   constexpr int buf = 3 * JN * 2048 + (JN + (8 * JN + 31) / 32) * I8_FRAG;  // pair rows + plain fragments
-  const size_t lds = (size_t)I8_CNT_BYTES + 2u * (size_t)buf + I8_REPS * sizeof(uint32_t) +
-                     (weighted ? 2u : 1u) * SM_T * sizeof(double);  // + the tile's u (and w)
+  const size_t lds = (size_t)I8_CNT_BYTES + 2u * (size_t)buf + 2u * I8_REPS * sizeof(uint32_t) +
+                     2u * SM_T * sizeof(double);  // + window draws, parked counts; two u tiles, or one u + one w
   // the dynamic-LDS limit is a property of the function: set it once per instantiation (one device per process)
   static bool lds_set[2] = {false, false};
   if (!lds_set[weighted ? 1 : 0]) {

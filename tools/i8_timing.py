@@ -4,6 +4,7 @@ import os, sys, ctypes as ct
 import torch
 sys.path.insert(0, ".")
 os.environ["TXM_I8"] = "1"
+os.environ["TXM_THROTTLE"] = os.environ.get("TXM_THROTTLE", "1")
 from thermoextrap_amd import engine as eng, _lib
 from bench import make_data
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20_000_000
@@ -18,8 +19,8 @@ ws = eng.workspace(nbytes)
 ntiles = -(-N // 1024); K = order + 1
 n_rbg = -(-nrep // 64); nrep_pad = n_rbg * 64
 nc = max(8, 256 // n_rbg // 8 * 8)
-win = 64
-while win > 4 and ntiles < 2 * win * nc: win //= 4
+win = 256
+while win > 4 and -(-ntiles // win) < 8 * nc: win //= 4
 nwin = -(-ntiles // win)
 tpc = -(-nwin // nc) * win
 n_chunks = -(-(-(-ntiles // tpc)) // 8) * 8
