@@ -68,6 +68,8 @@ def truth_err(orc, got, x, u, order, freq, reps, w=None, sc=None):
     (40000, 32, 4, 130, False),     # several tiles, three replicate groups
     (200000, 32, 4, 64, False),     # four scaling windows in four chunks
     (150000, 9, 1, 64, True),       # order 1
+    (30000, 32, 0, 64, False),      # order 0: means only (the volume callback's <dx/dq> bootstrap)
+    (9000, 20, 0, 70, True),        # order 0, weighted
     (30000, 32, 5, 64, False),      # order 5: powers 0-2 and 3-5 in two passes
     (30000, 20, 6, 70, True),       # order 6: 0-3 and 4-6
     (9000, 32, 7, 64, False),       # order 7: 0-3 and 4-7
@@ -268,8 +270,10 @@ def test_dispatch_thresholds(eng):
         assert eng.resample_path(big, 32, 1000, 4) == "int8"
         assert eng.resample_path(big, 32, 64, 4) == "int8"
         assert eng.resample_path(big, 32, 48, 4) == "fp64"        # less than one replicate group
-        assert eng.resample_path(big, 32, 300, 2) == "fp64"       # order 2 needs >= 384
+        assert eng.resample_path(big, 32, 300, 2) == "fp64"       # orders 1 and 2 need >= 384
         assert eng.resample_path(big, 32, 400, 2) == "int8"
+        assert eng.resample_path(big, 32, 400, 1) == "int8"
+        assert eng.resample_path(big, 32, 1000, 0) == "fp64"      # order 0: the two kernels are within 5 %
         assert eng.resample_path(big, 8, 1000, 4) == "fp64"       # one 16-column FP64 block is cheaper
         assert eng.resample_path(big, 64, 1000, 4) == "int8"      # two column groups
         assert eng.resample_path(big, 40, 1000, 4) == "fp64"      # 8-column tail group

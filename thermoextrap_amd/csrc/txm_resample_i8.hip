@@ -599,7 +599,11 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
     const int64_t i = wbase + s * 32 + g2 * 2;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
+#ifdef TXM_I8_NO_XLOAD
+      r.x[e] = (double)(i + e) * 1e-9 + px;  // ablation: no memory access
+#else
       r.x[e] = a.x[(i + e) * a.ldx_s + a.col0 + cc];
+#endif
     }
   };
 
@@ -903,7 +907,7 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
 // ---------------------------------------------------------------------------
 bool i8_supported(int64_t N, int64_t C, int64_t nrep, int K) {
   (void)nrep;
-  return N >= SM_T && C >= 1 && C <= 64 * I8_CPAD && K >= 2 && K <= 8;  // C > 32: one launch per 32 columns
+  return N >= SM_T && C >= 1 && C <= 64 * I8_CPAD && K >= 1 && K <= 8;  // C > 32: one launch per 32 columns
 }
 
 template <int K, int J0, int JN>
@@ -953,6 +957,7 @@ int launch_resample_i8(const I8Args &a, int K, bool weighted, size_t prog_bytes,
   TXM_LAUNCH_CHECK();
   int rc = TXM_OK;
   switch (K) {
+    case 1: rc = launch_pass<1, 0, 1>(a, weighted, prog_bytes, st); break;
     case 2: rc = launch_pass<2, 0, 2>(a, weighted, prog_bytes, st); break;
     case 3: rc = launch_pass<3, 0, 3>(a, weighted, prog_bytes, st); break;
     case 4: rc = launch_pass<4, 0, 4>(a, weighted, prog_bytes, st); break;
