@@ -55,7 +55,10 @@ struct I8Args {
   // tiles they have finished and stay within I8_LEAD tiles of each other, so that the chunk is streamed from HBM once
   uint32_t *progress;      // [n_chunks][64], zeroed by the launcher; nullptr: off
 };
-constexpr uint32_t I8_LEAD = 2;
+#ifndef TXM_I8_LEAD
+#define TXM_I8_LEAD 2
+#endif
+constexpr uint32_t I8_LEAD = TXM_I8_LEAD;
 constexpr int I8_THROTTLE_SPINS = 48;
 
 // true when the int8 path can take this problem (device-sampler mode only)

@@ -394,13 +394,6 @@ __device__ __forceinline__ void i8_fill_full(const I8Args &a, uint32_t *cnt, int
 // constant).  Digit 6 is left as the raw exponent-adjacent byte 0x38 + d6: the constant 56
 // is taken out at flush time as 56 * (sum of counts), which the sampler knows exactly.
 constexpr int I8_D6_BIAS = 0x38;
-// a wave-uniform double, moved to scalar registers (a uniform value loaded through the vector path would otherwise
-// occupy -- or be spilled from -- two vector registers)
-__device__ __forceinline__ double i8_uniform(double v) {
-  const uint64_t b = (uint64_t)__double_as_longlong(v);
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
-  return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
-}
 __device__ __forceinline__ void i8_slice2(double r0, double r1, uint32_t (&T)[4]) {
   const uint64_t b0 = (uint64_t)__double_as_longlong(r0), b1 = (uint64_t)__double_as_longlong(r1);
   const uint32_t l0 = (uint32_t)b0, l1 = (uint32_t)b1, h0 = (uint32_t)(b0 >> 32), h1 = (uint32_t)(b1 >> 32);
@@ -744,8 +737,10 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
     if (a.wflag[win] != 0u) continue;  // precision guard: this window goes to the FP64 kernel (wave-uniform)
     {
       const double *wt = a.wtab + win * I8_WT_STRIDE;
-      inv_du = i8_uniform(wt[I8_WT_INVDU]);
-      if constexpr (WEIGHTED) inv_w = i8_uniform(wt[I8_WT_INVW]);
+      // (kept in vector registers on purpose: moving these two uniform factors to scalar registers changed the
+      // register allocation so that the kernel fetched 37 instead of 15 GiB per launch -- measured, tools/ab_fetch.sh)
+      inv_du = wt[I8_WT_INVDU];
+      if constexpr (WEIGHTED) inv_w = wt[I8_WT_INVW];
       sc = wt[I8_WT_SC + cc];
     }
     int64_t tt_end = (win + 1) * WT;

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 N=${1:-2e7}; NREP=${2:-1000}
 mkdir -p /tmp/i8ab
 CS=thermoextrap_amd/csrc
-for v in base NO_MFMA NO_PRODUCE NO_FILL "NO_MFMA -DTXM_I8_NO_PRODUCE" "NO_MFMA -DTXM_I8_NO_FILL" "NO_PRODUCE -DTXM_I8_NO_FILL"; do
+for v in base NO_MFMA NO_PRODUCE NO_FILL NO_XLOAD "NO_MFMA -DTXM_I8_NO_PRODUCE" "NO_MFMA -DTXM_I8_NO_FILL" "NO_PRODUCE -DTXM_I8_NO_FILL" "NO_MFMA -DTXM_I8_NO_PRODUCE -DTXM_I8_NO_FILL"; do
   tag=$(echo "$v" | tr -d ' ' | tr -c 'A-Za-z0-9_\n' '_')
   def=""; [ "$v" != base ] && def="-DTXM_I8_$v"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-pass-failed $def -c $CS/txm_resample_i8.hip -o /tmp/i8ab/i8_$tag.o
