@@ -273,6 +273,28 @@ def test_resample_vals_device_sampler(eng, orc, N, C, order, nrep):
     assert_states_close(got, got2, moment_scale(x, u, order)[None], rtol=1e-13, what="fused vs explicit")
 
 
+@pytest.mark.parametrize("C", [1, 2, 3, 4, 5, 7, 8])
+@pytest.mark.parametrize("order", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_resample_vals_narrow_states_packed_powers(eng, orc, C, order, weighted):
+    """C <= 8 with the device sampler runs the power-packed contraction (2 or 4 powers of du per
+    B-operand column); the states must be those of the oracle on the same frequency table, and equal
+    the one-power-per-column kernel (explicit-freq path) up to summation order.  N has a ragged tail."""
+    N, nrep = 4099 + 1024 * C, 35
+    rng = np.random.default_rng(100 * C + order)
+    x, u = make_data(rng, N, C)
+    w = rng.uniform(0.2, 3.0, N) if weighted else None
+    s = eng.DeviceSampler(77 + C, nrep, N)
+    got = eng.resample_vals(dev(x), dev(u), order, sampler=s, w=None if w is None else dev(w)).cpu().numpy()
+    freq = s.freq().cpu().numpy()
+    scale = moment_scale(x, u, order, w)[None]
+    truth = np.stack([orc.truth_cov(x, u, order, w=w, freq_row=freq[r]) for r in range(nrep)])
+    assert_states_close(got, truth, scale, what="packed powers vs oracle")
+    got2 = eng.resample_vals(dev(x), dev(u), order, freq=dev(freq, torch.int64),
+                             w=None if w is None else dev(w)).cpu().numpy()
+    assert_states_close(got, got2, scale, rtol=1e-13, what="packed vs one power per column")
+
+
 def test_resample_user_pivot(eng, orc):
     rng = np.random.default_rng(2)
     x, u = make_data(rng, 2000, 4)

@@ -48,13 +48,13 @@ constexpr int RS_QUARTER = SM_T / 4;                  // 256 samples per lane-gr
 constexpr int RS_TILE_BYTES = SM_T * RS_REPS;         // 16384 bytes per wave
 // steps per register-prefetch group: as many as the VGPR budget (2 waves/SIMD,
 // 256 VGPRs) allows next to the K*NBLK accumulator tiles.
-constexpr int rs_group(int K, int NBLK, bool weighted, bool explicit_) {
+constexpr int rs_group(int K, int NBLK, bool weighted, bool explicit_, int pack = 1) {
   const int per_step = 2 + 2 * NBLK + (weighted ? 2 : 0) + (explicit_ ? 10 : 0);
   for (int g = 8; g > 2; g >>= 1)
 #ifndef TXM_EXP_BUDGET
 #define TXM_EXP_BUDGET 160
 #endif
-    if (K * NBLK * 8 + 2 * g * per_step <= TXM_EXP_BUDGET) return g;
+    if ((K + pack - 1) / pack * NBLK * 8 + 2 * g * per_step <= TXM_EXP_BUDGET) return g;
   return 2;
 }
 
@@ -176,14 +176,23 @@ __device__ __forceinline__ void fill_tile_full(const ResampleArgs &a, const uint
 // loop state (scalar registers are what this kernel runs out of first: spilled SGPRs cost vector instructions,
 // and every vector instruction here costs FP64-MFMA time).
 constexpr int RS_PLAIN = 0, RS_LISTED = 1, RS_BATCHED = 2;
-template <int K, int NBLK, bool WEIGHTED, bool EXPLICIT, bool SMALLN, int MODE = RS_PLAIN>
+//
+// PACK (1, 2 or 4; NBLK == 1): with C <= 16 / PACK value columns the 16 B-operand columns carry PACK powers of du
+// per column, B[k][jp * CPK + c] = dx_c * du^jp, and the A operands step by du^PACK: ceil(K / PACK) MFMAs per
+// k-step instead of K, so a narrow state does not pay for 16 columns it does not have.
+template <int K, int NBLK, bool WEIGHTED, bool EXPLICIT, bool SMALLN, int MODE = RS_PLAIN, int PACK = 1>
 __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArgs a) {
+  static_assert(PACK == 1 || (NBLK == 1 && (PACK == 2 || PACK == 4)), "power packing needs a single column block");
+  constexpr int CPK = 16 / PACK;            // value columns per power slot
+  constexpr int KJ = (K + PACK - 1) / PACK;  // accumulator tiles (MFMAs per k-step and column block)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   // readfirstlane: tell the compiler the wave index is wave-uniform, so everything
   // derived from it (replicate base, LDS tile base, loop bounds) lives in SGPRs
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int row = lane & 15;   // A: replicate within block;  B: column within block
   const int kk = lane >> 4;    // which quarter of the tile this lane group walks
+  const int crow = PACK == 1 ? row : row % CPK;  // B: value column within the block
+  const int jp = PACK == 1 ? 0 : row / CPK;      // B: power of du folded into this lane's column
 
   // XCD-aware task map: workgroups that share a sample chunk sit on one XCD
   // (blocks b and b+8 share an XCD) and are dispatched back to back, so the
@@ -233,19 +242,19 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
   int64_t ccol[NBLK];
 #pragma unroll
   for (int bl = 0; bl < NBLK; ++bl) {
-    const int64_t c = col0 + bl * 16 + row;
+    const int64_t c = col0 + bl * 16 + crow;
     ccol[bl] = c < a.C ? c : 0;
     px[bl] = PIV[1 + a.col_off + ccol[bl]];
   }
 
-  v4f64 acc[K][NBLK];
+  v4f64 acc[KJ][NBLK];
   double usum[K];
 #pragma unroll
-  for (int j = 0; j < K; ++j) {
-    usum[j] = 0.0;
+  for (int j = 0; j < K; ++j) usum[j] = 0.0;
+#pragma unroll
+  for (int j = 0; j < KJ; ++j)
 #pragma unroll
     for (int bl = 0; bl < NBLK; ++bl) acc[j][bl] = (v4f64){0.0, 0.0, 0.0, 0.0};
-  }
 
   unsigned char *tile = lds_raw + (size_t)wave * RS_TILE_BYTES;
   const int64_t my_rep = rep0 + row;
@@ -253,7 +262,7 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
   const int64_t last = a.N - 1;
 
   // register double buffer for one group of RS_GROUP steps
-  constexpr int RS_GROUP = SMALLN ? 2 : rs_group(K, NBLK, WEIGHTED, EXPLICIT);
+  constexpr int RS_GROUP = SMALLN ? 2 : rs_group(K, NBLK, WEIGHTED, EXPLICIT, PACK);
   struct Grp {
     double u[RS_GROUP];
     double w[RS_GROUP];
@@ -331,7 +340,7 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
     // K*NBLK MFMAs of step e are issued, so the MFMAs of a step go out back to back
     // and no VALU write targets a register an in-flight MFMA still reads.
     struct Ops {
-      double a[K];
+      double a[KJ];
       double b[NBLK];
     };
     auto prep_step = [&](const Grp &G, int e, Ops &o) {
@@ -342,9 +351,14 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
       const double du = G.u[e] - pu;
 #pragma unroll
       for (int bl = 0; bl < NBLK; ++bl) o.b[bl] = G.x[e][bl] - px[bl];
+      if constexpr (PACK > 1) {
+        double f = (jp & 1) ? du : 1.0;
+        if constexpr (PACK == 4) f *= (jp & 2) ? du * du : 1.0;
+        o.b[0] *= f;
+      }
 #pragma unroll
       for (int j = 0; j < K; ++j) {
-        o.a[j] = av;
+        if (j % PACK == 0) o.a[j / PACK] = av;
         // S0[0] = sum of counts: accumulated only when weights make it non-trivial
         // (unweighted it is the replicate's draw count, summed from `counts` below)
         if (j > 0 || WEIGHTED || EXPLICIT) usum[j] += av;
@@ -353,7 +367,7 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
     };
     auto mfma_step = [&](const Ops &o) {
 #pragma unroll
-      for (int j = 0; j < K; ++j)
+      for (int j = 0; j < KJ; ++j)
 #pragma unroll
         for (int bl = 0; bl < NBLK; ++bl)
           acc[j][bl] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a[j], o.b[bl], acc[j][bl], 0, 0, 0);
@@ -478,14 +492,15 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
   // D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
   double *px_out = PX + ((size_t)chunk * a.nrep_pad + rep0) * a.C_pad * K;
 #pragma unroll
-  for (int j = 0; j < K; ++j)
+  for (int jj = 0; jj < KJ; ++jj)
 #pragma unroll
     for (int bl = 0; bl < NBLK; ++bl)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int rrow = kk + 4 * rg;
-        const int64_t c = col0 + bl * 16 + row;
-        px_out[((size_t)rrow * a.C_pad + c) * K + j] = acc[j][bl][rg];
+        const int64_t c = col0 + bl * 16 + crow;
+        const int j = jj * PACK + jp;
+        if (PACK == 1 || j < K) px_out[((size_t)rrow * a.C_pad + c) * K + j] = acc[jj][bl][rg];
       }
   if (colgrp == 0) {
     if constexpr (!WEIGHTED && !EXPLICIT) usum[0] = cnt;  // other lane groups contribute 0
@@ -751,6 +766,14 @@ extern "C" size_t txm_resample_vals_ws_bytes(int64_t N, int64_t C, int64_t nrep,
   }
 
 namespace txm {
+// TXM_PACK=0 keeps the one-power-per-column kernel for narrow states too (A/B measurements)
+static bool pack_on() {
+  static const bool on = [] {
+    const char *e = getenv("TXM_PACK");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
 template <int K>
 static int run_resample(ResampleArgs a, const ResamplePlan &p, bool weighted, bool explicit_,
                         double *out, hipStream_t st, int64_t S = 1) {
@@ -768,7 +791,29 @@ static int run_resample(ResampleArgs a, const ResamplePlan &p, bool weighted, bo
     else                                                                                               \
       hipLaunchKernelGGL((resample_kernel<K, NB, WT, EX, false>), grid, block, lds, st, a);            \
   } while (0)
-  if (p.nblk == 1) {
+  // narrow states (C <= 8, device sampler, full tiles): PACK powers per B column -> ceil(K / PACK) MFMAs per k-step
+  bool packed = false;
+  if constexpr (K >= 2 && K <= 6) {
+    if (p.nblk == 1 && p.colgroups == 1 && !explicit_ && a.N >= SM_T && a.C <= 8 && pack_on()) {
+      packed = true;
+      const bool bat = S > 1 || a.batch != nullptr;
+#define TXM_RS_PACKED(PK)                                                                                      \
+  do {                                                                                                         \
+    if (bat) {                                                                                                 \
+      if (weighted) hipLaunchKernelGGL((resample_kernel<K, 1, true, false, false, RS_BATCHED, PK>), grid, block, lds, st, a); \
+      else hipLaunchKernelGGL((resample_kernel<K, 1, false, false, false, RS_BATCHED, PK>), grid, block, lds, st, a);         \
+    } else {                                                                                                   \
+      if (weighted) hipLaunchKernelGGL((resample_kernel<K, 1, true, false, false, RS_PLAIN, PK>), grid, block, lds, st, a);   \
+      else hipLaunchKernelGGL((resample_kernel<K, 1, false, false, false, RS_PLAIN, PK>), grid, block, lds, st, a);           \
+    }                                                                                                          \
+  } while (0)
+      if (a.C <= 4 && K >= 3) TXM_RS_PACKED(4);
+      else TXM_RS_PACKED(2);
+#undef TXM_RS_PACKED
+    }
+  }
+  if (packed) {
+  } else if (p.nblk == 1) {
     if (weighted) { if (explicit_) TXM_RS_LAUNCH(1, true, true); else TXM_RS_LAUNCH(1, true, false); }
     else          { if (explicit_) TXM_RS_LAUNCH(1, false, true); else TXM_RS_LAUNCH(1, false, false); }
   } else {

@@ -118,7 +118,9 @@ def main(args):
     K = order + 1
     flops = 2.0 * S * N * nrep * K * (C + 1)
     # the FP64 kernel pads the observables to one 16-column MFMA block and the replicates to 64 per workgroup
-    exec_flops = 2.0 * S * N * (-(-nrep // 64) * 64) * K * 16
+    import os
+    pack = 1 if os.environ.get("TXM_PACK", "1").startswith("0") or not (2 <= K <= 6 and C <= 8) else (4 if C <= 4 and K >= 3 else 2)
+    exec_flops = 2.0 * S * N * (-(-nrep // 128) * 128) * -(-K // pack) * 16
     rec = {
         "metric": "samples/s for 64-state GP input (order-3 derivatives + covariance over 100 bootstrap replicates)",
         "value": S * N / dt, "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -133,7 +135,7 @@ def main(args):
                      "frac": flops / (t_k * 1e-3) / 1e12 / 78.6, "executed_tflops": exec_flops / (t_k * 1e-3) / 1e12,
                      "traffic": None, "ms": t_k, "algorithmic_flops": flops,
                      "measured": "HIP events around 5 txm_resample_vals_batched calls",
-                     "note": "achieved = algorithmic flops 2*S*N*nrep*K*(N_obs+1); the kernel executes 16 columns x 128 replicates per state "
-                             "(executed_tflops)"},
+                     "note": "achieved = algorithmic flops 2*S*N*nrep*K*(N_obs+1); the kernel executes ceil(K / pack) MFMAs of 16 columns "
+                             f"(pack = {pack} powers of du per column) x 128 replicates per state and k-step (executed_tflops)"},
     }
     print(json.dumps(rec), flush=True)
