@@ -2,7 +2,7 @@
 """bench.py -- samples/s of the central-comoment bootstrap hot path (BASELINE.json metric) on MI355X.
 
 One "step" = `ExtrapModel.resample({"nrep": nrep}).derivs()` through the drop-in API on a state
-point whose samples are already resident in HBM: draw the sampler (device multinomial: stage-1/2
+point whose samples are already resident in HBM: draw the sampler (device multinomial: tile-count
 kernels), run the bootstrap (txm_resample_vals: window pre-pass with the precision guard, Philox
 stage 3 fused into the contraction, finalize), evaluate the derivative table on the replicate states
 (txm_eval_poly) and copy the (order+1, nrep, N_obs) derivatives to the host.
@@ -289,7 +289,7 @@ def main():
     from thermoextrap_amd import moments as cm
 
     def one_bootstrap(n_rep, seed):
-        # one sampler object per step (stage-1/2 kernels run here), shared by the moments and the callback's <dx/dq>
+        # one sampler object per step (the tile-count kernel runs here), shared by the moments and the callback's <dx/dq>
         smp = cm.factory_sampler({"nrep": n_rep, "device": True, "seed": seed}, data=xv, dim="rec")
         boot = xem.resample(sampler=smp)
         results["derivs"] = boot.derivs(norm=False)  # host labelled array (order+1, rep, val)

@@ -108,6 +108,12 @@ int txm_indices_to_freq(const int64_t *indices, int64_t nrep, int64_t nsamp, int
  * counter-based Philox4x32-10 stream keyed by (seed, stage, replicate, tile)
  * without ever materialising indices; oracle/philox_oracle.c restates the
  * stream bit for bit.  The sampler object is a plain struct (no hidden state).
+ * Stream version 2: the per-tile draw counts come from recursive binomial
+ * splitting over a binary tree of tile ranges (one random bit per draw and
+ * level, counted with popcounts; splits that are not 1/2 compare all draws
+ * with the size ratio bit by bit), the per-sample counts inside a tile from
+ * 10-bit fields.  Tables of a given seed differ from version 1 (round 1 of
+ * this library); their distribution is the same exact multinomial.
  */
 typedef struct txm_sampler_spec {
   uint64_t seed;
@@ -117,7 +123,9 @@ typedef struct txm_sampler_spec {
 } txm_sampler_spec;
 
 /* Per-(replicate, tile) draw counts, tile = 1024 consecutive samples.
- * counts: [nrep][txm_sampler_ntiles(ndat)] uint32. */
+ * counts: [nrep][txm_sampler_ntiles(ndat)] uint32.  ndat <= 2^30; the workspace
+ * is no longer used (the tile tree lives in LDS) but the query still returns a
+ * valid size and the arguments are accepted. */
 int64_t txm_sampler_ntiles(int64_t ndat);
 size_t txm_sampler_counts_ws_bytes(const txm_sampler_spec *spec_host);
 int txm_sampler_tile_counts(const txm_sampler_spec *spec_host, uint32_t *counts, void *ws,

@@ -12,36 +12,40 @@
  * normative statement of that stream; tests compare the GPU's tables with it
  * bit for bit.
  *
- * Spec (all integers):
- *   T = 1024 samples per tile;  ntiles = ceil(ndat / T)
- *   s = smallest shift with ceil(ntiles / 2^s) <= 16384   (requires s <= 6)
- *   nb1 = ceil(ntiles / 2^s) coarse bins of BS = T * 2^s samples
- *   Stage 1 (per replicate r): 16384 virtual lanes v, quota q_v = nsamp/16384
- *     (+1 for v < nsamp % 16384).  Lane v reads Philox(key=seed,
- *     ctr=(j, v, r, 1)), j = 0,1,...; each call yields 8 16-bit slots (word e>>1,
- *     half e&1).  Slot value z: c = z & (2^k1 - 1), k1 = bits(nb1 - 1).
- *     Reject if c >= nb1.  If c is the last bin and that bin is partial, draw
- *     off = Philox(ctr=(m, v, r, 4)).w0 & (BS-1) with m = running count of such
- *     events on this lane, and reject unless off < size(last bin).  Accepted
- *     draws increment n1[r][c] until the quota is met.
- *   Stage 2 (per replicate r, coarse bin b; only when s > 0), n = n1[r][b]:
- *     full bin (covers 2^s whole tiles): draw d in [0, n) uses field d % F of
- *     Philox call c = d / F, F = 4 * floor(32 / s); field k of word w is bits
- *     [k*s, (k+1)*s) (k < floor(32/s)), fields ordered word-major;
- *     ctr = (c, b, r, 2).  The field value is the tile inside the bin.
- *     last bin when partial: 64 lanes, quota split of n; ctr = (j, b*64 + lane,
- *     r, 5); 16-bit slot z: off = z & (BS-1), reject unless off < size(bin b);
- *     tile inside the bin = off >> 10.
- *   Stage 3 (per replicate r, tile t), n = n2[r][t]:
+ * Spec (all integers), stream version 2:
+ *   T = 1024 samples per tile;  ntiles = ceil(ndat / T);  k = smallest integer with 2^k >= ntiles.
+ *   Tile counts (per replicate r) by recursive binomial splitting over a binary tree of tile ranges:
+ *     node (l, i), l = 0..k, i in [0, 2^l), covers tiles [i * 2^(k-l), (i+1) * 2^(k-l));
+ *     size(l, i) = number of samples of [0, ndat) inside that tile range;  heap index h = 2^l + i.
+ *     n(0, 0) = nsamp.  A node with l < k and n = n(l, i) > 0 sends `left` of its draws to child
+ *     (l+1, 2i) and n - left to (l+1, 2i+1), where left ~ Binomial(n, A / (A + B)) exactly,
+ *     A = size(l+1, 2i), B = size(l+1, 2i+1):
+ *       B == 0: left = n (no random bits).
+ *       otherwise every draw compares a uniform binary fraction U = 0.b1 b2 ... with p = A / (A + B) =
+ *       0.p1 p2 ... bit by bit (left iff U < p), all draws of the node at once:
+ *         rem = A, den = A + B, tie = n, left = 0;  for j = 0, 1, ...:
+ *           rem = 2 * rem;  pj = (rem >= den);  if pj: rem -= den
+ *           K = number of 1 bits among the first `tie` bits of bit stream (h, j)
+ *           if pj: left += tie - K, tie = K      (b = 0 < pj = 1: decided left;  b = 1: still tied)
+ *           else : tie = tie - K                 (b = 1 > pj = 0: decided right; b = 0: still tied)
+ *           stop when tie == 0, or rem == 0 (p exhausted: the ties have U >= p, right), or j == 254.
+ *       (A == B is the one-step case p = 1/2: left = number of 0 bits among n.)  A >= B always, because
+ *       only the last real node of a level can be partial.
+ *     bit stream (h, j): bit q is bit (q & 31) of word ((q >> 5) & 3) of Philox(key = seed,
+ *     ctr = (h, q >> 7, r, 1 + 256 * j)).  (The call index sits in the second counter word so that the
+ *     first Philox rounds are partly the same for all calls of a node.)
+ *     counts[r][t] = n(k, t).
+ *   Per-sample counts (per replicate r, tile t), n = counts[r][t]:
  *     full tile: draw d uses field d % 12 of call c = d / 12 (three 10-bit
  *     fields per word: bits 0-9, 10-19, 20-29); ctr = (c, t, r, 3); the field
  *     value is the sample inside the tile.
  *     last tile when partial: 64 lanes, quota split of n; ctr = (j, t*64 + lane,
  *     r, 6); 16-bit slot z: off = z & 1023, reject unless off < size(tile t).
- *   freq[r][t*1024 + off] += 1 for every stage-3 draw.
- * Acceptance regions are exactly proportional to the number of samples a bin
- * covers, so every draw is uniform over [0, ndat) and the tables are exactly
- * multinomial.
+ *   freq[r][t*1024 + off] += 1 for every such draw.
+ * Every binomial split is exact for its ratio of sample counts, so the tile counts are exactly
+ * multinomial(nsamp; size(t) / ndat) and, with the uniform draws inside a tile, the tables are exactly
+ * multinomial(nsamp; 1/ndat ...).  Cost: one random bit per draw and level (two on the k nodes whose split
+ * is not 1/2) instead of a 16-bit slot per draw -- version 1 of the stream binned every draw separately.
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -71,21 +75,16 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 }
 
 typedef struct {
-  int64_t ntiles, nb1, BS, last_bin_size, last_tile_size;
-  int s, k1;
+  int64_t ntiles, last_tile_size;
+  int k;
 } sm_geom;
 
 static int sm_geometry(int64_t ndat, sm_geom *g) {
+  if (ndat > ((int64_t)1 << 30)) return -1;
   g->ntiles = (ndat + SM_T - 1) / SM_T;
-  g->s = 0;
-  while (((g->ntiles + ((int64_t)1 << g->s) - 1) >> g->s) > SM_NB1_MAX) g->s++;
-  if (g->s > 6) return -1;
-  g->nb1 = (g->ntiles + ((int64_t)1 << g->s) - 1) >> g->s;
-  g->BS = (int64_t)SM_T << g->s;
-  g->last_bin_size = ndat - (g->nb1 - 1) * g->BS;
   g->last_tile_size = ndat - (g->ntiles - 1) * SM_T;
-  g->k1 = 0;
-  while (((int64_t)1 << g->k1) < g->nb1) g->k1++;
+  g->k = 0;
+  while (((int64_t)1 << g->k) < g->ntiles) g->k++;
   return 0;
 }
 
@@ -94,81 +93,88 @@ int64_t orc_sampler_ntiles(int64_t ndat) { return (ndat + SM_T - 1) / SM_T; }
 /* slot e of a 4-word Philox output */
 static inline uint32_t slot16(const uint32_t o[4], int e) { return (o[e >> 1] >> (16 * (e & 1))) & 0xffffu; }
 
-/* counts [nrep][ntiles] uint32 (stage 1 + stage 2) */
+/* samples of [0, ndat) under node (l, i) of the tile tree */
+static int64_t node_size(int64_t ndat, int k, int l, int64_t i) {
+  const int64_t span = (int64_t)SM_T << (k - l);
+  const int64_t lo = i * span;
+  if (lo >= ndat) return 0;
+  return (ndat - lo < span) ? ndat - lo : span;
+}
+
+static int popc32(uint32_t v) {
+  int c = 0;
+  while (v) { v &= v - 1; ++c; }
+  return c;
+}
+
+/* number of 1 bits among the first nbits bits of bit stream (h, j) of replicate r */
+static uint32_t stream_ones(uint32_t k0, uint32_t k1, uint32_t h, uint32_t r, uint32_t j, uint32_t nbits) {
+  uint32_t ones = 0;
+  const uint32_t full = nbits >> 7, tail = nbits & 127u;
+  for (uint32_t c = 0; c < full; ++c) {
+    uint32_t o[4];
+    philox4x32_10(h, c, r, 1u + 256u * j, k0, k1, o);
+    ones += (uint32_t)(popc32(o[0]) + popc32(o[1]) + popc32(o[2]) + popc32(o[3]));
+  }
+  if (tail) {
+    uint32_t o[4];
+    philox4x32_10(h, full, r, 1u + 256u * j, k0, k1, o);
+    for (int w = 0; w < 4; ++w) {
+      const int nb = (int)tail - 32 * w;
+      if (nb <= 0) break;
+      ones += (uint32_t)popc32(nb >= 32 ? o[w] : (o[w] & (((uint32_t)1 << nb) - 1u)));
+    }
+  }
+  return ones;
+}
+
+/* left ~ Binomial(n, A / (A + B)), bitwise comparison of all n uniforms with p at once */
+static uint32_t split_left(uint32_t k0, uint32_t k1, uint32_t h, uint32_t r, uint32_t n, int64_t A, int64_t B) {
+  if (B == 0) return n;
+  uint64_t rem = (uint64_t)A;
+  const uint64_t den = (uint64_t)A + (uint64_t)B;
+  uint32_t tie = n, left = 0;
+  for (uint32_t j = 0; tie > 0 && j < 255u; ++j) {
+    rem <<= 1;
+    const int pj = rem >= den;
+    if (pj) rem -= den;
+    const uint32_t K = stream_ones(k0, k1, h, r, j, tie);
+    if (pj) { left += tie - K; tie = K; }
+    else tie -= K;
+    if (rem == 0) break;
+  }
+  return left;
+}
+
+/* counts [nrep][ntiles] uint32 */
 int orc_sampler_tile_counts(uint64_t seed, int64_t nrep, int64_t ndat, int64_t nsamp,
                             uint32_t *counts) {
   sm_geom g;
   if (ndat < 1 || nrep < 1 || sm_geometry(ndat, &g)) return -1;
   if (nsamp <= 0) nsamp = ndat;
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-  uint32_t *n1 = (uint32_t *)calloc((size_t)g.nb1, sizeof(uint32_t));
-  if (!n1) return -2;
+  const size_t P = (size_t)1 << g.k;
+  uint32_t *cur = (uint32_t *)calloc(P, sizeof(uint32_t)), *nxt = (uint32_t *)calloc(P, sizeof(uint32_t));
+  if (!cur || !nxt) { free(cur); free(nxt); return -2; }
   for (int64_t r = 0; r < nrep; ++r) {
-    memset(n1, 0, sizeof(uint32_t) * (size_t)g.nb1);
-    uint32_t *n2 = counts + r * g.ntiles;
-    memset(n2, 0, sizeof(uint32_t) * (size_t)g.ntiles);
-    /* ---- stage 1 ---- */
-    if (g.nb1 == 1) {
-      n1[0] = (uint32_t)nsamp;
-    } else {
-      const uint32_t mask = ((uint32_t)1 << g.k1) - 1;
-      for (int64_t v = 0; v < SM_V1; ++v) {
-        int64_t quota = nsamp / SM_V1 + (v < nsamp % SM_V1 ? 1 : 0);
-        uint32_t j = 0, m = 0;
-        while (quota > 0) {
-          uint32_t o[4];
-          philox4x32_10(j++, (uint32_t)v, (uint32_t)r, 1u, k0, k1, o);
-          for (int e = 0; e < 8 && quota > 0; ++e) {
-            const uint32_t c = slot16(o, e) & mask;
-            if (c >= (uint32_t)g.nb1) continue;
-            if (c == (uint32_t)(g.nb1 - 1) && g.last_bin_size < g.BS) {
-              uint32_t o2[4];
-              philox4x32_10(m++, (uint32_t)v, (uint32_t)r, 4u, k0, k1, o2);
-              if ((int64_t)(o2[0] & (uint32_t)(g.BS - 1)) >= g.last_bin_size) continue;
-            }
-            n1[c]++;
-            quota--;
-          }
-        }
+    cur[0] = (uint32_t)nsamp;
+    for (int l = 0; l < g.k; ++l) {
+      const int64_t nn = (int64_t)1 << l;
+      for (int64_t i = 0; i < nn; ++i) {
+        const uint32_t n = cur[i];
+        uint32_t left = 0;
+        if (n > 0)
+          left = split_left(k0, k1, (uint32_t)(nn + i), (uint32_t)r, n, node_size(ndat, g.k, l + 1, 2 * i),
+                            node_size(ndat, g.k, l + 1, 2 * i + 1));
+        nxt[2 * i] = left;
+        nxt[2 * i + 1] = n - left;
       }
+      uint32_t *t = cur; cur = nxt; nxt = t;
     }
-    /* ---- stage 2 ---- */
-    if (g.s == 0) {
-      for (int64_t b = 0; b < g.nb1; ++b) n2[b] = n1[b];
-    } else {
-      const int fpw = 32 / g.s, F = 4 * fpw; /* fields per word / per call */
-      const uint32_t fmask = ((uint32_t)1 << g.s) - 1;
-      for (int64_t b = 0; b < g.nb1; ++b) {
-        const int64_t n = n1[b];
-        const int64_t size_b = (b == g.nb1 - 1) ? g.last_bin_size : g.BS;
-        if (size_b == g.BS) {
-          for (int64_t c = 0; c * F < n; ++c) {
-            uint32_t o[4];
-            philox4x32_10((uint32_t)c, (uint32_t)b, (uint32_t)r, 2u, k0, k1, o);
-            const int64_t nd = (n - c * F < F) ? n - c * F : F;
-            for (int64_t q = 0; q < nd; ++q)
-              n2[(b << g.s) + ((o[q / fpw] >> (g.s * (int)(q % fpw))) & fmask)]++;
-          }
-        } else {
-          for (int lane = 0; lane < 64; ++lane) {
-            int64_t quota = n / 64 + (lane < n % 64 ? 1 : 0);
-            uint32_t j = 0;
-            while (quota > 0) {
-              uint32_t o[4];
-              philox4x32_10(j++, (uint32_t)(b * 64 + lane), (uint32_t)r, 5u, k0, k1, o);
-              for (int e = 0; e < 8 && quota > 0; ++e) {
-                const int64_t off = slot16(o, e) & (uint32_t)(g.BS - 1);
-                if (off >= size_b) continue;
-                n2[(b << g.s) + (off >> SM_LT)]++;
-                quota--;
-              }
-            }
-          }
-        }
-      }
-    }
+    for (int64_t t = 0; t < g.ntiles; ++t) counts[r * g.ntiles + t] = cur[t];
   }
-  free(n1);
+  free(cur);
+  free(nxt);
   return 0;
 }
 

@@ -200,13 +200,31 @@ def test_device_sampler_bit_exact_vs_cpu_restatement(eng, orc, ndat):
 
 
 def test_device_sampler_large_geometry_bit_exact(eng, orc):
-    """ndat large enough that stage 2 (s > 0) and a partial last coarse bin are exercised."""
+    """ndat large enough for a 15-level tile tree with workgroup, wave and sub-wave splits and a partial last tile."""
     ndat, nrep, seed = 16384 * 1024 + 3 * 1024 + 17, 1, 99
     s = eng.DeviceSampler(seed, nrep, ndat)
     counts = s.counts.cpu().numpy().view(np.uint32)
     ref_counts = orc.sampler_tile_counts(seed, nrep, ndat)
     assert np.array_equal(counts, ref_counts)
     assert counts.sum() == ndat
+
+
+@pytest.mark.parametrize("ndat,nrep,nsamp", [
+    (100_000_000, 2, 0),            # the north-star geometry: 17 levels, 16 waves per replicate, every regime
+    ((1 << 27) + 1, 1, 0),          # one sample beyond a power of two: a 18-level tree whose right half holds 1 sample
+    (1 << 24, 1, 0),                # exactly dyadic: no spine node at all
+    (3_000_000, 3, 40_000_000),     # nsamp >> ndat (16-wave launch on a 12-level tree)
+    (50_000_000, 2, 1000),          # nsamp << ndat: almost every node is empty
+])
+def test_device_sampler_tile_counts_bit_exact_at_size(eng, orc, ndat, nrep, nsamp):
+    """Tile counts of the binomial-splitting tree vs the CPU restatement, bit for bit, at full size (the oracle
+    needs ~1 s per replicate at 1e8: it counts bits, it does not bin draws)."""
+    seed = 0xABCDEF12345 + ndat
+    s = eng.DeviceSampler(seed, nrep, ndat, nsamp=nsamp) if nsamp else eng.DeviceSampler(seed, nrep, ndat)
+    counts = s.counts.cpu().numpy().view(np.uint32)
+    ref = orc.sampler_tile_counts(seed, nrep, ndat, nsamp)
+    assert counts.shape == ref.shape and np.array_equal(counts, ref)
+    assert (counts.sum(axis=1, dtype=np.int64) == (nsamp or ndat)).all()
 
 
 def test_device_sampler_nsamp(eng, orc):

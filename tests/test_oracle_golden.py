@@ -172,7 +172,7 @@ def test_device_sampler_spec_is_exact_multinomial_shape(orc, ndat):
     assert (counts.sum(axis=1) == ndat).all()
     freq = orc.sampler_freq(11, nrep, ndat, counts=counts)
     assert (freq >= 0).all() and (freq.sum(axis=1) == ndat).all()
-    # tile sums agree with the stage-2 counts
+    # tile sums agree with the tile counts
     pad = (-ndat) % 1024
     tiles = np.pad(freq, ((0, 0), (0, pad))).reshape(nrep, -1, 1024).sum(axis=2)
     assert (tiles == counts).all()
@@ -200,3 +200,31 @@ def test_device_sampler_statistics(orc):
 
     pois = np.array([math.exp(-1) / math.factorial(k) for k in range(8)])
     assert np.max(np.abs(hist - pois)) < 2e-3
+
+
+@pytest.mark.parametrize("ndat", [5 * 1024 + 300, 11 * 1024, 3 * 1024 + 1])
+def test_device_sampler_tile_counts_are_multinomial(orc, ndat):
+    """Stream v2 draws the tile counts by recursive binomial splitting (bitwise comparison with the size
+    ratio): per-tile mean n*p, variance n*p*(1-p) and pair covariance -n*p_i*p_j over many replicates, the
+    partial last tile and the non-dyadic splits included."""
+    nrep = 3000
+    c = orc.sampler_tile_counts(77, nrep, ndat).astype(float)
+    nt = c.shape[1]
+    size = np.full(nt, 1024.0)
+    size[-1] = ndat - 1024 * (nt - 1)
+    p = size / ndat
+    mean = c.mean(axis=0)
+    sd_mean = np.sqrt(ndat * p * (1 - p) / nrep)
+    assert np.all(np.abs(mean - ndat * p) < 5 * sd_mean)
+    var = c.var(axis=0, ddof=1)
+    assert np.all(np.abs(var / (ndat * p * (1 - p)) - 1) < 6 * np.sqrt(2 / nrep))
+    cov = np.cov(c.T)
+    want = -ndat * np.outer(p, p)
+    off = ~np.eye(nt, dtype=bool)
+    # sd of a sample covariance ~ sqrt(var_i var_j / nrep)
+    sd_cov = np.sqrt(np.outer(var, var) / nrep)
+    assert np.all(np.abs(cov - want)[off] < 6 * sd_cov[off])
+    # chi-square of the pooled tile totals
+    tot = c.sum(axis=0)
+    chi2 = ((tot - nrep * ndat * p) ** 2 / (nrep * ndat * p)).sum()
+    assert chi2 < (nt - 1) + 6 * np.sqrt(2 * (nt - 1))

@@ -7,25 +7,19 @@ namespace txm {
 
 constexpr int SM_LT = 10;
 constexpr int SM_T = 1 << SM_LT;  // samples per tile
-constexpr int SM_V1 = 16384;      // stage-1 virtual lanes per replicate
-constexpr int SM_NB1_MAX = 16384; // coarse bins (u32 in 64 KiB of LDS)
 
 struct SamplerGeom {
-  int64_t ntiles, nb1, BS, last_bin_size, last_tile_size;
-  int s, k1;
+  int64_t ndat, ntiles, last_tile_size;
+  int k;  // 2^k >= ntiles: depth of the tile tree
 };
 
 static inline int sampler_geometry(int64_t ndat, SamplerGeom *g) {
+  if (ndat > ((int64_t)1 << 30)) return -1;
+  g->ndat = ndat;
   g->ntiles = (ndat + SM_T - 1) / SM_T;
-  g->s = 0;
-  while (((g->ntiles + ((int64_t)1 << g->s) - 1) >> g->s) > SM_NB1_MAX) g->s++;
-  if (g->s > 6) return -1;
-  g->nb1 = (g->ntiles + ((int64_t)1 << g->s) - 1) >> g->s;
-  g->BS = (int64_t)SM_T << g->s;
-  g->last_bin_size = ndat - (g->nb1 - 1) * g->BS;
   g->last_tile_size = ndat - (g->ntiles - 1) * SM_T;
-  g->k1 = 0;
-  while (((int64_t)1 << g->k1) < g->nb1) g->k1++;
+  g->k = 0;
+  while (((int64_t)1 << g->k) < g->ntiles) g->k++;
   return 0;
 }
 
@@ -34,7 +28,7 @@ struct Philox4 {
 };
 
 // XOR3: fold the two XORs of a round into one v_bitop3_b32.  Measured on gfx950: the standalone sampler
-// kernels gain 9 % (58.8 -> 53.9 ms for stages 1+2 at N=1e8, nrep=1000), the fill phases fused into the
+// kernels gain 9 % (round-1 tile-count kernels: 58.8 -> 53.9 ms at N=1e8, nrep=1000), the fill phases fused into the
 // bootstrap kernels lose (int8 kernel 262 -> 271 ms), so only the former ask for it.
 template <bool XOR3 = false>
 __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
@@ -74,7 +68,7 @@ __device__ __forceinline__ uint32_t slot16(const Philox4 &o, int e) {
   return (o.w[e >> 1] >> (16 * (e & 1))) & 0xffffu;
 }
 
-// Stage 3 for one (replicate r, tile t) executed by one wave: every draw calls
+// Per-sample counts ("stage 3") for one (replicate r, tile t) executed by one wave: every draw calls
 // hit(off) with off in [0, tile_size).  `n` = counts[r][t].
 //   full tile   : draw d = field d % 12 of Philox call d / 12 (three 10-bit
 //                 fields per word), call c handled by lane c % 64 -- no random

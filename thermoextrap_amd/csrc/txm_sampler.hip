@@ -4,13 +4,10 @@
 // (cmomy factory_sampler as reached from data.py:1782-1789) without ever
 // materialising the (nrep, ndat) index/freq tables.
 //
-// Stage 1: per replicate, nsamp draws of a coarse bin id into LDS bins (u32),
-//          16 workgroups of 1024 threads per replicate, flushed with one global
-//          atomic per non-empty bin.
-// Stage 2: one wave per (replicate, coarse bin) splits its count over the 2^s
-//          tiles of the bin.
-// Stage 3: lives in txm_sampler.h and is executed inside the bootstrap kernel
-//          (txm_resample.hip), tile by tile, straight into LDS.
+// Tile counts: recursive binomial splitting over the tree of tile ranges, one
+//          workgroup per replicate (sampler_tree_kernel).
+// Per-sample counts inside a tile ("stage 3"): txm_sampler.h, executed inside the
+//          bootstrap kernels (txm_resample*.hip), tile by tile, straight into LDS.
 #include "txm_sampler.h"
 
 namespace txm {
@@ -36,252 +33,176 @@ __global__ __launch_bounds__(256) void indices_to_freq_kernel(const int64_t *__r
   (void)nrep;
 }
 
-// ---- stage 1 ---------------------------------------------------------------
-// grid (SM_V1 / 1024, nrep), block 1024, dynamic LDS = nb1 * 4 bytes.
-__global__ __launch_bounds__(1024) void sampler_stage1_kernel(uint32_t k0, uint32_t k1key,
-                                                              int64_t nsamp, SamplerGeom g,
-                                                              uint32_t *__restrict__ n1) {
-  extern __shared__ uint32_t bins[];
-  const uint32_t r = blockIdx.y;
-  const uint32_t v = blockIdx.x * 1024u + threadIdx.x;
-  const uint32_t nb1 = (uint32_t)g.nb1;
-  for (uint32_t b = threadIdx.x; b < nb1; b += 1024u) bins[b] = 0u;
-  __syncthreads();
-  // nsamp <= 16 * 2^30 (check_spec), so a lane's share of SM_V1 = 16384 lanes fits 32 bits
-  uint32_t quota = (uint32_t)(nsamp / SM_V1) + ((int64_t)v < (nsamp % SM_V1) ? 1u : 0u);
-  const uint32_t mask = (1u << g.k1) - 1u;
-  const bool last_partial = g.last_bin_size < g.BS;
-  const uint32_t bsmask = (uint32_t)(g.BS - 1);
-  const uint32_t last_size = (uint32_t)g.last_bin_size;
-  uint32_t j = 0, m = 0;
-  while (quota) {
-    const Philox4 o = philox4x32_10<true>(j++, v, r, 1u, k0, k1key);
+// ---- tile counts: recursive binomial splitting (stream v2, oracle/philox_oracle.c) -------------------
+// One workgroup per replicate walks the binary tree of tile ranges.  A node's n draws are split between its
+// children by counting 1 bits in n bits of the node's Philox bit stream: one v_bcnt per 32 draws and level,
+// no histogram, no atomics, no rejection.  Levels with few nodes are split by the whole workgroup (block
+// reduction per node), levels with >= 4 nodes per wave by one wave per node, and the subtrees below level
+// ka = k - ST_DEPTH by one wave each in wave-private LDS with g <= 64 lanes per node, g chosen so that every
+// lane has a few Philox calls per node.
+constexpr int ST_DEPTH = 7;        // levels of a wave-private subtree (2^7 leaves)
+constexpr int ST_BLOCK_NODES = 4;  // nodes per wave below which a level is split by the whole workgroup
+
+__device__ __forceinline__ uint32_t popc4(const Philox4 &o) {
+  return (uint32_t)(__popc(o.w[0]) + __popc(o.w[1]) + __popc(o.w[2]) + __popc(o.w[3]));
+}
+
+// this lane's share of the 1 bits among the first `nbits` bits of stream (h, tagj): calls sub, sub + g, ...
+// The call index is the SECOND counter word: rounds 1-3 then need 2 instead of 6 multiplies per call (the rest is
+// the same for all calls of a node and hoisted out of the loop).
+// (g a power of two); the partial last call belongs to the lane whose turn it is.
+__device__ __forceinline__ uint32_t stream_ones_partial(uint32_t k0, uint32_t k1, uint32_t h, uint32_t r,
+                                                        uint32_t tagj, uint32_t nbits, uint32_t sub, uint32_t g) {
+  const uint32_t full = nbits >> 7, tail = nbits & 127u;
+  uint32_t acc = 0;
+  for (uint32_t c = sub; c < full; c += g) acc += popc4(philox4x32_10<true>(h, c, r, tagj, k0, k1));
+  if (tail != 0u && (full & (g - 1u)) == sub) {
+    const Philox4 o = philox4x32_10<true>(h, full, r, tagj, k0, k1);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const uint32_t c = slot16(o, e) & mask;
-      bool ok = quota && (c < nb1);
-      if (ok && last_partial && c == nb1 - 1u) {
-        const Philox4 o2 = philox4x32_10<true>(m++, v, r, 4u, k0, k1key);
-        ok = (o2.w[0] & bsmask) < last_size;
-      }
-      if (ok) {
-        atomicAdd(&bins[c], 1u);
-        --quota;
-      }
+    for (int w = 0; w < 4; ++w) {
+      const int nb = (int)tail - 32 * w;
+      const uint32_t m = nb >= 32 ? 0xffffffffu : (nb <= 0 ? 0u : ((1u << nb) - 1u));
+      acc += (uint32_t)__popc(o.w[w] & m);
     }
   }
-  __syncthreads();
-  for (uint32_t b = threadIdx.x; b < nb1; b += 1024u) {
-    const uint32_t cnt = bins[b];
-    if (cnt) atomicAdd(&n1[(size_t)r * nb1 + b], cnt);
+  return acc;
+}
+
+__device__ __forceinline__ int64_t tree_node_size(int64_t ndat, int k, int l, int64_t i) {
+  const int64_t span = (int64_t)SM_T << (k - l);
+  const int64_t lo = i * span;
+  if (lo >= ndat) return 0;
+  return (ndat - lo < span) ? ndat - lo : span;
+}
+
+// left ~ Binomial(n, A / (A + B)): all n uniforms are compared with p bit by bit at once.  SUM(v) adds v over the
+// lanes that share the node (and returns the total on each of them).
+template <class Sum>
+__device__ __forceinline__ uint32_t split_left(uint32_t k0, uint32_t k1, uint32_t h, uint32_t r, uint32_t n,
+                                               int64_t A, int64_t B, uint32_t sub, uint32_t g, Sum sum) {
+  if (B == 0) return n;
+  uint64_t rem = (uint64_t)A;
+  const uint64_t den = (uint64_t)A + (uint64_t)B;
+  uint32_t tie = n, left = 0;
+  for (uint32_t j = 0; tie > 0u && j < 255u; ++j) {
+    rem <<= 1;
+    const bool pj = rem >= den;
+    if (pj) rem -= den;
+    const uint32_t K = sum(stream_ones_partial(k0, k1, h, r, 1u + 256u * j, tie, sub, g));
+    if (pj) {
+      left += tie - K;
+      tie = K;
+    } else {
+      tie -= K;
+    }
+    if (rem == 0) break;
   }
+  return left;
 }
 
-__global__ void sampler_fill_single_bin_kernel(uint32_t *__restrict__ counts, int64_t nrep,
-                                               uint32_t nsamp) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < nrep) counts[r] = nsamp;
-}
+// grid nrep, block 64 * nwaves (a power of two), dynamic LDS: heap[2^(ka+1)] + nwaves * sub[2^(depth+1)] + red[nwaves]
+__global__ __launch_bounds__(1024) void sampler_tree_kernel(uint32_t k0, uint32_t k1key, uint32_t nsamp,
+                                                            SamplerGeom g, uint32_t *__restrict__ counts) {
+  extern __shared__ uint32_t tree_lds[];
+  const int k = g.k;
+  const int depth = k < ST_DEPTH ? k : ST_DEPTH;
+  const int ka = k - depth;
+  const int nwaves = (int)(blockDim.x >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  uint32_t *heap = tree_lds;                                   // levels 0 .. ka, heap indexed
+  uint32_t *sub_all = heap + ((size_t)2 << ka);                // per wave: subtree levels 0 .. depth
+  uint32_t *red = sub_all + (size_t)nwaves * ((size_t)2 << depth);
+  const uint32_t r = blockIdx.x;
 
-// ---- stage 2 ---------------------------------------------------------------
-// One wave per run of S2_BINS consecutive coarse bins of one replicate; the
-// wave's 64-entry LDS table is private, so no workgroup barrier is needed.
-// Full bins use s-bit fields (F = 4 * floor(32/s) draws per Philox call, call c
-// on lane c % 64); only the last, partial bin needs rejection.
-constexpr int S2_BINS = 8;
+  for (uint32_t q = threadIdx.x; q < ((uint32_t)2 << ka); q += blockDim.x) heap[q] = 0u;
+  __syncthreads();
+  if (threadIdx.x == 0) heap[1] = nsamp;
+  __syncthreads();
 
-// Fast path for s <= 3 (ndat <= 1.3e8).  Per-tile counts come from popcounts of
-// bit-plane products: with B_b = bit b of every field, P(m) = popc(AND_{b in m} B_b)
-// for the 2^S - 1 non-empty bit subsets m, and the number of fields equal to v is
-// the Moebius sum  c(v) = sum_{m >= v} (-1)^{|m|-|v|} P(m)  (P(0) = #fields).
-// 16 ALU ops per 32-bit word for S = 3 instead of one match-and-count per value.
-template <int S>
-__global__ __launch_bounds__(256) void sampler_stage2_popc_kernel(
-    uint32_t k0, uint32_t k1key, int64_t nrep, SamplerGeom g, const uint32_t *__restrict__ n1,
-    uint32_t *__restrict__ counts) {
-  constexpr int NS = 1 << S;
-  constexpr int FPW = 32 / S;
-  constexpr uint32_t F = 4u * FPW;
-  uint32_t lsb = 0;  // LSB of every field of a word
+  auto block_sum = [&](uint32_t v) {
 #pragma unroll
-  for (int k = 0; k < FPW; ++k) lsb |= 1u << (k * S);
-  const int lane = threadIdx.x & 63;
-  const int64_t runs_per_rep = (g.nb1 + S2_BINS - 1) / S2_BINS;
-  const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (task >= nrep * runs_per_rep) return;
-  const uint32_t r = (uint32_t)(task / runs_per_rep);
-  const int64_t b_begin = (task % runs_per_rep) * S2_BINS;
-  const int64_t b_end = (b_begin + S2_BINS < g.nb1) ? b_begin + S2_BINS : g.nb1;
-  // all counts of the run are loaded up front (one latency, not one per bin)
-  uint32_t nb[S2_BINS];
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    uint32_t s = 0;
+    for (int w = 0; w < nwaves; ++w) s += red[w];
+    return s;
+  };
+  auto wave_sum = [&](uint32_t v) {
 #pragma unroll
-  for (int i = 0; i < S2_BINS; ++i)
-    nb[i] = (b_begin + i < b_end) ? n1[(size_t)r * g.nb1 + b_begin + i] : 0u;
-#pragma unroll
-  for (int i = 0; i < S2_BINS; ++i) {
-    const int64_t bb = b_begin + i;
-    if (bb >= b_end) break;
-    const uint32_t b = (uint32_t)bb;
-    const uint32_t n = nb[i];
-    uint32_t pc[NS];   // pc[m] = P(m); pc[0] = number of fields seen by this lane
-    uint32_t cnt[NS];  // exact per-value counts of the (rare) rejection path
-#pragma unroll
-    for (int v = 0; v < NS; ++v) pc[v] = cnt[v] = 0u;
-    const bool full_bin = !(bb == g.nb1 - 1 && g.last_bin_size < g.BS);
-    if (full_bin) {
-      for (uint32_t c0 = 0; (uint64_t)c0 * F < n; c0 += 64u) {
-        const uint32_t c = c0 + (uint32_t)lane;
-        const uint64_t first = (uint64_t)c * F;
-        if (first < n) {
-          const Philox4 o = philox4x32_10<true>(c, b, r, 2u, k0, k1key);
-          const uint32_t nd = (n - first < F) ? (uint32_t)(n - first) : F;
-#pragma unroll
-          for (int wi = 0; wi < 4; ++wi) {
-            const int nv = (int)nd - wi * FPW;  // fields of this word that are real draws
-            uint32_t valid = lsb;
-            if (nv <= 0) valid = 0u;
-            else if (nv < FPW) valid = lsb & ((1u << (nv * S)) - 1u);
-            const uint32_t word = o.w[wi];
-            uint32_t B[S];
-#pragma unroll
-            for (int bit = 0; bit < S; ++bit) B[bit] = (word >> bit) & valid;
-            pc[0] += __popc(valid);
-#pragma unroll
-            for (int m = 1; m < NS; ++m) {
-              uint32_t t = 0xffffffffu;
-#pragma unroll
-              for (int bit = 0; bit < S; ++bit)
-                if (m & (1 << bit)) t &= B[bit];
-              pc[m] += __popc(t);
-            }
-          }
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+    return v;
+  };
+
+  // ---- levels 0 .. ka-1: counts in the workgroup's heap ----
+  for (int l = 0; l < ka; ++l) {
+    const uint32_t nn = 1u << l;
+    const int64_t span = (int64_t)1 << (k - l);                      // tiles per node
+    const uint32_t nreal = (uint32_t)((g.ntiles + span - 1) / span);  // nodes that cover samples
+    if (nreal < (uint32_t)(ST_BLOCK_NODES * nwaves)) {
+      for (uint32_t i = 0; i < nreal; ++i) {
+        const uint32_t n = heap[nn + i];
+        const uint32_t left = split_left(k0, k1key, nn + i, r, n, tree_node_size(g.ndat, k, l + 1, 2 * (int64_t)i),
+                                         tree_node_size(g.ndat, k, l + 1, 2 * (int64_t)i + 1), threadIdx.x,
+                                         blockDim.x, block_sum);
+        if (threadIdx.x == 0) {
+          heap[2 * nn + 2 * i] = left;
+          heap[2 * nn + 2 * i + 1] = n - left;
         }
       }
     } else {
-      const uint32_t size_b = (uint32_t)g.last_bin_size;
-      const uint32_t bsmask = (uint32_t)(g.BS - 1);
-      uint32_t quota = n / 64u + ((uint32_t)lane < (n % 64u) ? 1u : 0u);
-      uint32_t j = 0;
-      const uint32_t c1 = b * 64u + (uint32_t)lane;
-      while (quota) {
-        const Philox4 o = philox4x32_10<true>(j++, c1, r, 5u, k0, k1key);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const uint32_t off = slot16(o, e) & bsmask;
-          if (quota && off < size_b) {
-            const uint32_t sub = off >> SM_LT;
-#pragma unroll
-            for (int v = 0; v < NS; ++v) cnt[v] += (sub == (uint32_t)v) ? 1u : 0u;
-            --quota;
-          }
+      for (uint32_t i = (uint32_t)wave; i < nreal; i += (uint32_t)nwaves) {
+        const uint32_t n = heap[nn + i];
+        const uint32_t left = split_left(k0, k1key, nn + i, r, n, tree_node_size(g.ndat, k, l + 1, 2 * (int64_t)i),
+                                         tree_node_size(g.ndat, k, l + 1, 2 * (int64_t)i + 1), (uint32_t)lane, 64u,
+                                         wave_sum);
+        if (lane == 0) {
+          heap[2 * nn + 2 * i] = left;
+          heap[2 * nn + 2 * i + 1] = n - left;
         }
       }
     }
-    // wave reduction of the subset popcounts, Moebius inversion, lane v stores tile v
-#pragma unroll
-    for (int m = 0; m < NS; ++m) {
-      uint32_t x = pc[m];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-      pc[m] = x;
-      uint32_t y = cnt[m];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) y += __shfl_xor(y, off);
-      cnt[m] = y;
-    }
-    uint32_t mine = 0;
-#pragma unroll
-    for (int v = 0; v < NS; ++v) {
-      int32_t c = 0;
-#pragma unroll
-      for (int m = 0; m < NS; ++m) {
-        if ((m & v) == v) {  // m is a superset of v
-          const int extra = __builtin_popcount(m ^ v);
-          c += (extra & 1) ? -(int32_t)pc[m] : (int32_t)pc[m];
-        }
-      }
-      const uint32_t tot = (uint32_t)c + cnt[v];
-      if (lane == v) mine = tot;
-    }
-    if (lane < NS) {
-      const int64_t t = (bb << S) + lane;
-      if (t < g.ntiles) counts[(size_t)r * g.ntiles + t] = mine;
-    }
+    __syncthreads();
   }
-}
 
-constexpr int S2_WAVES = 2;  // waves per workgroup
-
-// Every lane keeps PRIVATE counters in LDS (row pitch 2^s + 1 words, so lanes
-// sit on different banks): a shared 2^s-entry table would make all 64 lanes of
-// a ds_add hit the same few addresses and serialise.
-__global__ __launch_bounds__(64 * S2_WAVES) void sampler_stage2_kernel(
-    uint32_t k0, uint32_t k1key, int64_t nrep, SamplerGeom g, const uint32_t *__restrict__ n1,
-    uint32_t *__restrict__ counts) {
-  extern __shared__ uint32_t sub_all[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int s = g.s;
-  const int nsub = 1 << s, pitch = nsub + 1;
-  uint32_t *sub = sub_all + (size_t)wave * 64 * pitch;
-  uint32_t *mine = sub + lane * pitch;
-  const int64_t runs_per_rep = (g.nb1 + S2_BINS - 1) / S2_BINS;
-  const int64_t task = (int64_t)blockIdx.x * S2_WAVES + wave;
-  if (task >= nrep * runs_per_rep) return;  // whole wave exits together
-  const uint32_t r = (uint32_t)(task / runs_per_rep);
-  const int64_t b_begin = (task % runs_per_rep) * S2_BINS;
-  const int64_t b_end = (b_begin + S2_BINS < g.nb1) ? b_begin + S2_BINS : g.nb1;
-  const int fpw = 32 / s;
-  const uint32_t F = 4u * (uint32_t)fpw;
-  const uint32_t fmask = (1u << s) - 1u;
-  for (int64_t bb = b_begin; bb < b_end; ++bb) {
-    const uint32_t b = (uint32_t)bb;
-    for (int v = 0; v < nsub; ++v) mine[v] = 0u;
-    const uint32_t n = n1[(size_t)r * g.nb1 + b];
-    const bool full_bin = !(bb == g.nb1 - 1 && g.last_bin_size < g.BS);
-    if (full_bin) {
-      for (uint32_t c0 = 0; (uint64_t)c0 * F < n; c0 += 64u) {
-        const uint32_t c = c0 + (uint32_t)lane;
-        const uint64_t first = (uint64_t)c * F;
-        if (first < n) {
-          const Philox4 o = philox4x32_10<true>(c, b, r, 2u, k0, k1key);
-          const uint32_t nd = (n - first < F) ? (uint32_t)(n - first) : F;
-          uint32_t q = 0;
-#pragma unroll
-          for (int wi = 0; wi < 4; ++wi) {  // static word index: keeps `o` in registers
-            uint32_t word = o.w[wi];
-            for (int k = 0; k < fpw; ++k, ++q) {
-              if (q < nd) mine[word & fmask] += 1u;
-              word >>= s;
-            }
-          }
-        }
-      }
-    } else {
-      const uint32_t size_b = (uint32_t)g.last_bin_size;
-      const uint32_t bsmask = (uint32_t)(g.BS - 1);
-      uint32_t quota = n / 64u + ((uint32_t)lane < (n % 64u) ? 1u : 0u);
-      uint32_t j = 0;
-      const uint32_t c1 = b * 64u + (uint32_t)lane;
-      while (quota) {
-        const Philox4 o = philox4x32_10<true>(j++, c1, r, 5u, k0, k1key);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const uint32_t off = slot16(o, e) & bsmask;
-          if (quota && off < size_b) {
-            mine[off >> SM_LT] += 1u;
-            --quota;
-          }
-        }
-      }
-    }
-    // wave-private region: DS ops of one wave execute in order; fence the compiler
+  // ---- subtrees rooted at level ka: one wave each, counts in wave-private LDS ----
+  uint32_t *sh = sub_all + (size_t)wave * ((size_t)2 << depth);
+  const uint32_t nroots = (uint32_t)((g.ntiles + ((int64_t)1 << depth) - 1) >> depth);
+  for (uint32_t s = (uint32_t)wave; s < nroots; s += (uint32_t)nwaves) {
+    if (lane == 0) sh[1] = heap[((uint32_t)1 << ka) + s];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    if (lane < nsub) {
-      uint32_t tot = 0;
-      for (int l = 0; l < 64; ++l) tot += sub[l * pitch + lane];
-      const int64_t t = (bb << s) + lane;
-      if (t < g.ntiles) counts[(size_t)r * g.ntiles + t] = tot;
+    for (int d = 0; d < depth; ++d) {
+      const int l = ka + d;
+      const uint32_t nn = 1u << d;
+      // lanes per node: the largest power of two <= (expected Philox calls per node) / 3, within [1, 64]
+      const uint32_t ecalls = (uint32_t)(((uint64_t)nsamp >> l) >> 7);
+      uint32_t gsz = 64u;
+      while (gsz > 1u && gsz * 3u > ecalls) gsz >>= 1;
+      const uint32_t per = 64u / gsz;  // nodes per pass of the wave
+      const uint32_t sub = (uint32_t)lane & (gsz - 1u);
+      for (uint32_t base = 0; base < nn; base += per) {
+        const uint32_t jn = base + (uint32_t)lane / gsz;
+        const bool act = jn < nn;
+        const uint32_t n = act ? sh[nn + jn] : 0u;
+        const int64_t gi = ((int64_t)s << d) + jn;  // node index within level l
+        const int64_t A = tree_node_size(g.ndat, k, l + 1, 2 * gi), B = tree_node_size(g.ndat, k, l + 1, 2 * gi + 1);
+        const uint32_t left = split_left(k0, k1key, (1u << l) + (uint32_t)gi, r, n, A, B, sub, gsz, [&](uint32_t v) {
+          for (uint32_t o = gsz >> 1; o > 0u; o >>= 1) v += (uint32_t)__shfl_xor((int)v, (int)o);
+          return v;
+        });
+        if (act && sub == 0u) {
+          sh[2 * nn + 2 * jn] = left;
+          sh[2 * nn + 2 * jn + 1] = n - left;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
+    for (uint32_t j = (uint32_t)lane; j < (1u << depth); j += 64u) {
+      const int64_t t = ((int64_t)s << depth) + j;
+      if (t < g.ntiles) counts[(size_t)r * g.ntiles + t] = sh[(1u << depth) + j];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -367,7 +288,7 @@ extern "C" size_t txm_sampler_counts_ws_bytes(const txm_sampler_spec *sp) {
   SamplerGeom g;
   int64_t nsamp;
   if (check_spec(sp, &g, &nsamp) != TXM_OK) return 0;
-  return (size_t)sp->nrep * (size_t)g.nb1 * sizeof(uint32_t) + 256;
+  return 256;  // the tile tree lives in LDS; kept so that callers' workspace plumbing stays valid
 }
 
 extern "C" int txm_sampler_tile_counts(const txm_sampler_spec *sp, uint32_t *counts, void *ws,
@@ -377,43 +298,22 @@ extern "C" int txm_sampler_tile_counts(const txm_sampler_spec *sp, uint32_t *cou
   int rc = check_spec(sp, &g, &nsamp);
   if (rc != TXM_OK) return rc;
   TXM_REQUIRE(counts, "sampler: null counts");
+  (void)ws;
+  (void)ws_bytes;
   hipStream_t st = (hipStream_t)stream;
   const uint32_t k0 = (uint32_t)sp->seed, k1 = (uint32_t)(sp->seed >> 32);
-  if (g.nb1 == 1) {
-    hipLaunchKernelGGL(sampler_fill_single_bin_kernel, dim3((unsigned)cdiv(sp->nrep, 256)),
-                       dim3(256), 0, st, counts, sp->nrep, (uint32_t)nsamp);
-    TXM_LAUNCH_CHECK();
-    return TXM_OK;
+  // 16 waves per replicate when a replicate has enough draws to feed them, 4 otherwise
+  const int nwaves = nsamp >= ((int64_t)1 << 22) ? 16 : 4;
+  const int depth = g.k < ST_DEPTH ? g.k : ST_DEPTH, ka = g.k - depth;
+  const size_t lds = (((size_t)2 << ka) + (size_t)nwaves * ((size_t)2 << depth) + (size_t)nwaves) * sizeof(uint32_t);
+  static bool attr = false;
+  if (!attr) {
+    TXM_HIP(hipFuncSetAttribute((const void *)sampler_tree_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
   }
-  uint32_t *n1 = counts;
-  if (g.s > 0) {
-    if (!ws || ws_bytes < txm_sampler_counts_ws_bytes(sp)) {
-      set_error("sampler: workspace too small");
-      return TXM_ERR_WORKSPACE;
-    }
-    n1 = (uint32_t *)ws;
-  }
-  TXM_HIP(hipMemsetAsync(n1, 0, sizeof(uint32_t) * (size_t)sp->nrep * g.nb1, st));
-  hipLaunchKernelGGL(sampler_stage1_kernel, dim3(SM_V1 / 1024, (unsigned)sp->nrep), dim3(1024),
-                     (size_t)g.nb1 * sizeof(uint32_t), st, k0, k1, nsamp, g, n1);
+  hipLaunchKernelGGL(sampler_tree_kernel, dim3((unsigned)sp->nrep), dim3(64 * nwaves), lds, st, k0, k1,
+                     (uint32_t)nsamp, g, counts);
   TXM_LAUNCH_CHECK();
-  if (g.s > 0) {
-    const int64_t tasks = sp->nrep * cdiv(g.nb1, S2_BINS);
-    if (g.s <= 3) {
-      dim3 grid((unsigned)cdiv(tasks, 4)), block(256);
-      if (g.s == 1)
-        hipLaunchKernelGGL((sampler_stage2_popc_kernel<1>), grid, block, 0, st, k0, k1, sp->nrep, g, n1, counts);
-      else if (g.s == 2)
-        hipLaunchKernelGGL((sampler_stage2_popc_kernel<2>), grid, block, 0, st, k0, k1, sp->nrep, g, n1, counts);
-      else
-        hipLaunchKernelGGL((sampler_stage2_popc_kernel<3>), grid, block, 0, st, k0, k1, sp->nrep, g, n1, counts);
-    } else {
-      const size_t lds = (size_t)S2_WAVES * 64 * ((1 << g.s) + 1) * sizeof(uint32_t);
-      hipLaunchKernelGGL(sampler_stage2_kernel, dim3((unsigned)cdiv(tasks, S2_WAVES)),
-                         dim3(64 * S2_WAVES), lds, st, k0, k1, sp->nrep, g, n1, counts);
-    }
-    TXM_LAUNCH_CHECK();
-  }
   return TXM_OK;
 }
 
