@@ -37,7 +37,7 @@
  *     counts[r][t] = n(k, t).
  *   Per-sample counts (per replicate r, tile t), n = counts[r][t]:
  *     full tile: draw d uses field d % 12 of call c = d / 12 (three 10-bit
- *     fields per word: bits 0-9, 10-19, 20-29); ctr = (c, t, r, 3); the field
+ *     fields per word: bits 0-9, 10-19, 20-29); ctr = (t, c, r, 3); the field
  *     value is the sample inside the tile.
  *     last tile when partial: 64 lanes, quota split of n; ctr = (j, t*64 + lane,
  *     r, 6); 16-bit slot z: off = z & 1023, reject unless off < size(tile t).
@@ -192,7 +192,7 @@ int orc_sampler_freq(uint64_t seed, int64_t nrep, int64_t ndat, const uint32_t *
       if (size_t_ == SM_T) {
         for (int64_t c = 0; c * 12 < n; ++c) {
           uint32_t o[4];
-          philox4x32_10((uint32_t)c, (uint32_t)t, (uint32_t)r, 3u, k0, k1, o);
+          philox4x32_10((uint32_t)t, (uint32_t)c, (uint32_t)r, 3u, k0, k1, o);
           const int64_t nd = (n - c * 12 < 12) ? n - c * 12 : 12;
           for (int64_t q = 0; q < nd; ++q)
             freq[r * ndat + t * SM_T + ((o[q / 3] >> (10 * (int)(q % 3))) & 1023u)]++;

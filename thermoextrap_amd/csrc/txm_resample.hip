@@ -122,7 +122,8 @@ __device__ __forceinline__ void tile_calls(uint32_t *tw, uint32_t k0, uint32_t k
                                            uint32_t c, uint32_t n, uint32_t inc, uint32_t wsel) {
   const uint32_t first = c * 12u;
   if (!ALL_VALID && first >= n) return;  // ALL_VALID: 12 (c + 1) <= n by construction, no branch
-  const Philox4 o = philox4x32_10(c, t, r, 3u, k0, k1);
+  // call index in the second counter word: the tile's and the replicate's share of rounds 1-3 is wave-uniform
+  const Philox4 o = philox4x32_10(t, c, r, 3u, k0, k1);
   const uint32_t nd = n - first;
 #pragma unroll
   for (int wi = 0; wi < 4; ++wi) {

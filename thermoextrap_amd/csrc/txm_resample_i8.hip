@@ -347,7 +347,8 @@ __device__ __forceinline__ void i8_tile_calls(uint32_t *cnt, uint32_t k0, uint32
   // ALL_VALID: the caller guarantees 12 (c + 1) <= n, so there is no branch and the two
   // replicates of a pair share a basic block: their Philox chains interleave
   if (!ALL_VALID && first >= n) return;
-  const Philox4 o = philox4x32_10(c, t, r, 3u, k0, k1);
+  // call index in the second counter word: the tile's and the replicate's share of rounds 1-3 is wave-uniform
+  const Philox4 o = philox4x32_10(t, c, r, 3u, k0, k1);
   const uint32_t nd = n - first;
 #pragma unroll
   for (int wi = 0; wi < 4; ++wi) {

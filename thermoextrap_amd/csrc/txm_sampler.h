@@ -82,7 +82,7 @@ __device__ __forceinline__ void sampler_fine_tile(uint32_t k0, uint32_t k1, uint
       const uint32_t c = c0 + (uint32_t)lane;
       const uint32_t first = c * 12u;
       if (first < n) {
-        const Philox4 o = philox4x32_10(c, t, r, 3u, k0, k1);
+        const Philox4 o = philox4x32_10(t, c, r, 3u, k0, k1);
         const uint32_t nd = n - first;  // >= 1; fields beyond nd are unused
 #pragma unroll
         for (int q = 0; q < 12; ++q)
