@@ -271,6 +271,21 @@ typedef struct txm_poly_table {
 int txm_eval_poly(const txm_poly_table *table_host, const double *const *srcs, int32_t n_srcs,
                   int64_t nrep, int64_t nval, double *out, txm_stream stream);
 
+/* ---- (f-1) ExtrapModel.predict: Taylor series of the derivative table -------- */
+/* derivs [n_ord][M] (the output of txm_eval_poly, M = nrep * nval), dalpha [n_alpha] (device):
+ *   term[a][k][m] = dalpha[a]^k * (derivs[k][m] * (1 / k!))
+ *   mode TXM_TAYLOR_SUM    : out[a][m]    = sum_k term[a][k][m]           (k ascending)
+ *   mode TXM_TAYLOR_CUMSUM : out[a][k][m] = sum_{k' <= k} term[a][k'][m]
+ *   mode TXM_TAYLOR_TERMS  : out[a][k][m] = term[a][k][m]
+ *   replaces ExtrapModel.predict = coefs * dalpha**p summed / cumsummed over the order dim
+ *   reference: src/thermoextrap/models.py:479-565 (coefs: models.py:449-477, taylor_series_norm :55-70).
+ * One launch over (alpha, rep, val); n_ord <= 16. */
+#define TXM_TAYLOR_SUM 0
+#define TXM_TAYLOR_CUMSUM 1
+#define TXM_TAYLOR_TERMS 2
+int txm_predict_taylor(const double *derivs, int32_t n_ord, int64_t M, const double *dalpha,
+                       int64_t n_alpha, int32_t mode, double *out, txm_stream stream);
+
 /* ---- (f-2) covariance of the derivatives over bootstrap replicates --------- */
 /* vals [n_ord][nrep][nval] -> cov [nval][n_ord][n_ord] with ddof = 1 (numpy.cov),
  * the per-output covariance that gpr_active.input_GP_from_state feeds to the GP

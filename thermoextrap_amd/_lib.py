@@ -82,6 +82,7 @@ SIGNATURES = {
     "txm_convert_cov": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p]),
     "txm_convert_1d": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p]),
     "txm_eval_poly": (c_int, [ct.POINTER(PolyTable), c_void_p, ct.c_int32, c_i64, c_i64, c_void_p, c_void_p]),
+    "txm_predict_taylor": (c_int, [c_void_p, ct.c_int32, c_i64, c_void_p, c_i64, ct.c_int32, c_void_p, c_void_p]),
     "txm_cov_over_rep": (c_int, [c_void_p, ct.c_int32, c_i64, c_i64, c_void_p, c_void_p]),
     "txm_perturb_ws_bytes": (c_size, [c_i64, c_i64, ct.c_int32, c_i64]),
     "txm_perturb": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_i64, ct.POINTER(ct.c_double), ct.c_int32, c_void_p,

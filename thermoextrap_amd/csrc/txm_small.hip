@@ -339,6 +339,54 @@ extern "C" int txm_resample_data(const double *data, const int64_t *freq, int64_
   return TXM_OK;
 }
 
+namespace txm {
+// thread per (alpha a, element m): Horner is avoided on purpose -- the terms are formed exactly as the host
+// formula does (dalpha^k by repeated products, times the coefficient) so that cumsum / no_sum return them.
+template <int MODE>
+__global__ __launch_bounds__(256) void predict_taylor_kernel(const double *__restrict__ d, int n_ord, int64_t M,
+                                                             const double *__restrict__ dalpha, int64_t na,
+                                                             double *__restrict__ out) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t a = blockIdx.y;
+  if (m >= M) return;
+  const double da = dalpha[a];
+  double p = 1.0, s = 0.0, fact = 1.0;
+  for (int k = 0; k < n_ord; ++k) {
+    if (k > 1) fact *= (double)k;  // exact: 15! < 2^53
+    const double term = p * (d[(size_t)k * M + m] * (1.0 / fact));  // 1 / k! rounded once, as the host's taylor_series_norm
+    s += term;
+    if (MODE == TXM_TAYLOR_CUMSUM) out[((size_t)a * n_ord + k) * M + m] = s;
+    if (MODE == TXM_TAYLOR_TERMS) out[((size_t)a * n_ord + k) * M + m] = term;
+    p *= da;
+  }
+  if (MODE == TXM_TAYLOR_SUM) out[(size_t)a * M + m] = s;
+}
+}  // namespace txm
+
+extern "C" int txm_predict_taylor(const double *derivs, int32_t n_ord, int64_t M, const double *dalpha,
+                                  int64_t n_alpha, int32_t mode, double *out, txm_stream stream) {
+  TXM_REQUIRE(derivs && dalpha && out, "predict_taylor: null pointer");
+  TXM_REQUIRE(n_ord >= 1 && n_ord <= 16 && M >= 1 && n_alpha >= 1 && n_alpha <= 65535, "predict_taylor: bad sizes");
+  dim3 grid((unsigned)cdiv(M, 256), (unsigned)n_alpha), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (mode) {
+    case TXM_TAYLOR_SUM:
+      hipLaunchKernelGGL((predict_taylor_kernel<TXM_TAYLOR_SUM>), grid, block, 0, st, derivs, n_ord, M, dalpha, n_alpha, out);
+      break;
+    case TXM_TAYLOR_CUMSUM:
+      hipLaunchKernelGGL((predict_taylor_kernel<TXM_TAYLOR_CUMSUM>), grid, block, 0, st, derivs, n_ord, M, dalpha, n_alpha, out);
+      break;
+    case TXM_TAYLOR_TERMS:
+      hipLaunchKernelGGL((predict_taylor_kernel<TXM_TAYLOR_TERMS>), grid, block, 0, st, derivs, n_ord, M, dalpha, n_alpha, out);
+      break;
+    default:
+      set_error("predict_taylor: unknown mode %d", mode);
+      return TXM_ERR_INVALID;
+  }
+  TXM_LAUNCH_CHECK();
+  return TXM_OK;
+}
+
 extern "C" int txm_eval_poly(const txm_poly_table *tb, const double *const *srcs, int32_t n_srcs,
                              int64_t nrep, int64_t nval, double *out, txm_stream stream) {
   TXM_REQUIRE(tb && srcs && out, "eval_poly: null pointer");

@@ -420,6 +420,32 @@ def cov_over_rep(vals: torch.Tensor) -> torch.Tensor:
     return out
 
 
+TAYLOR_MODES = {"sum": 0, "cumsum": 1, "terms": 2}
+
+
+def predict_taylor(derivs: torch.Tensor, dalphas, mode: str = "sum") -> torch.Tensor:
+    """Taylor series of a derivative table (n_ord, ...) at every dalpha: (n_alpha, ...) for ``mode="sum"``,
+    (n_alpha, n_ord, ...) partial sums (``"cumsum"``) or terms (``"terms"``) -- ExtrapModel.predict in one launch."""
+    L = _L()
+    _check_f64_cuda(derivs, "derivs")
+    if mode not in TAYLOR_MODES:
+        raise ValueError(f"mode must be one of {sorted(TAYLOR_MODES)}")
+    d = derivs.contiguous()
+    n_ord = d.shape[0]
+    if not 1 <= n_ord <= 16:
+        raise ValueError("predict_taylor: 1 <= n_ord <= 16")
+    M = d[0].numel()
+    da = to_device(np.atleast_1d(np.asarray(dalphas, dtype=np.float64)).ravel())
+    na = da.numel()
+    if na < 1 or M < 1:
+        raise ValueError("predict_taylor: empty input")
+    shape = (na, *d.shape[1:]) if mode == "sum" else (na, n_ord, *d.shape[1:])
+    out = torch.empty(shape, dtype=F64, device="cuda")
+    check(L.txm_predict_taylor(_ptr(d), n_ord, M, _ptr(da), na, TAYLOR_MODES[mode], _ptr(out), _stream()),
+          "txm_predict_taylor")
+    return out
+
+
 def perturb(x: torch.Tensor, u: torch.Tensor, dalphas, freq: torch.Tensor | None = None) -> torch.Tensor:
     """Exponentially reweighted averages for each dalpha: (n_alpha, C), or
     (nrep, n_alpha, C) with bootstrap counts ``freq`` (nrep, N).  x: (N, C) row-major or (N,)."""
