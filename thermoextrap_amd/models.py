@@ -260,18 +260,40 @@ class ExtrapModel(_Params):
         return self.predict(*args, **kwargs)
 
     def predict(self, alpha, order=None, order_dim="order", cumsum=False, no_sum=False, minus_log=None,
-                alpha_name=None, dalpha_coords="dalpha", alpha0_coords=True):
-        """Taylor series at ``alpha``: sum_k coefs[k] * (alpha - alpha0)^k."""
+                alpha_name=None, dalpha_coords="dalpha", alpha0_coords=True, fused=True):
+        """Taylor series at ``alpha``: sum_k coefs[k] * (alpha - alpha0)^k  (reference models.py:479-565).
+
+        ``fused`` (default): derivative table -> 1/k! -> dalpha^k -> sum / cumsum over the order in ONE launch over
+        (alpha, rep, val) on the device table (txm_predict_taylor), one copy back.  ``fused=False`` forms the same
+        labelled expression on the host from ``coefs`` like the reference does."""
         if order is None:
             order = self.order
         if alpha_name is None:
             alpha_name = self.alpha_name
-        coefs = self.coefs(order=order, order_dim=order_dim, minus_log=minus_log)
+        if minus_log is None:
+            minus_log = self.minus_log
         alpha = xrwrap_alpha(alpha, name=alpha_name)
         dalpha = alpha - self.alpha0
-        p = DataArray(np.arange(order + 1), order_dim)
-        prefac = dalpha**p
-        out = prefac * coefs
+        if fused and order_dim is not None:
+            key = ("device", order, minus_log)
+            if key not in self._cache:
+                self._cache[key] = self.derivatives.derivs(data=self.data, order=order, norm=False,
+                                                           minus_log=minus_log, _device=True)
+            vals, src = self._cache[key]
+            mode = "terms" if no_sum else ("cumsum" if cumsum else "sum")
+            res = engine.predict_taylor(vals, dalpha.values, mode).cpu().numpy()
+            if mode == "sum":
+                out = DataArray(res.reshape((*dalpha.shape, *src.out_shape)), (*dalpha.dims, *src.out_dims))
+            else:
+                out = DataArray(res.reshape((*dalpha.shape, order + 1, *src.out_shape)),
+                                (*dalpha.dims, order_dim, *src.out_dims))
+            out._inherit(dalpha._coords)
+            out._inherit(src.coords)
+        else:
+            coefs = self.coefs(order=order, order_dim=order_dim, minus_log=minus_log)
+            p = DataArray(np.arange(order + 1), order_dim)
+            prefac = dalpha**p
+            out = prefac * coefs
         coords = {}
         if dalpha_coords is not None:
             coords[dalpha_coords] = dalpha
@@ -280,6 +302,8 @@ class ExtrapModel(_Params):
                 alpha0_coords = alpha_name + "0"
             coords[alpha0_coords] = self.alpha0
         out = out.assign_coords(coords)
+        if fused and order_dim is not None:
+            return out
         if no_sum:
             return out
         if cumsum:
