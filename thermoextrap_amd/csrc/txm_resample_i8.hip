@@ -350,15 +350,22 @@ __device__ __forceinline__ void i8_tile_calls(uint32_t *cnt, uint32_t k0, uint32
   // call index in the second counter word: the tile's and the replicate's share of rounds 1-3 is wave-uniform
   const Philox4 o = philox4x32_10(t, c, r, 3u, k0, k1);
   const uint32_t nd = n - first;
+  uint32_t *row = cnt + rl * I8_CNT_ROW;
 #pragma unroll
   for (int wi = 0; wi < 4; ++wi) {
     const uint32_t word = o.w[wi];
+    // byte lane of every field at once: keep bits {0,1} of the three fields, so that a plain shift leaves
+    // 8 * (f & 3) in the five bits the shifter reads and zeros below them.  The two opaque values keep this
+    // selection (mask once; bfe + lshl_add for the address): 4 instead of 6 vector instructions per draw.
+    uint32_t lo2 = word & 0x00300C03u;
+    asm volatile("" : "+v"(lo2));
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const uint32_t f = (word >> (10 * k)) & 1023u;
-      uint32_t inc = 1u << ((f & 3u) << 3);
+      uint32_t q = __builtin_amdgcn_ubfe(word, 10 * k + 2, 8);  // f >> 2: the word of the row
+      asm volatile("" : "+v"(q));
+      uint32_t inc = 1u << (((k == 0) ? (lo2 << 3) : (lo2 >> (10 * k - 3))) & 31u);
       if (!ALL_VALID) inc = ((uint32_t)(wi * 3 + k) < nd) ? inc : 0u;
-      atomicAdd(&cnt[rl * I8_CNT_ROW + (f >> 2)], inc);
+      atomicAdd(&row[q], inc);
     }
   }
 }
