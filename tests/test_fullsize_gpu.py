@@ -200,3 +200,39 @@ def test_c4_order6_bootstrap_and_dxdq_fullsize(eng):
     m2 = eng.resample_vals(dxdq, u, 0, sampler=s2)[:, :, 1, 0]
     want = (freq.to(torch.float64) @ dxdq) / float(N)               # the definition: freq-weighted mean
     np.testing.assert_allclose(m2.cpu().numpy(), want.cpu().numpy(), rtol=1e-12)
+
+
+def test_sampler_tile_counts_dispersion_at_every_tree_level_fullsize(eng):
+    """Statistical pin of the binomial-splitting sampler at the north-star size (1000 replicates x 97657 tiles):
+    the draws under EVERY node of the tile tree must be Binomial(N, size/N) across replicates -- mean N*p and
+    variance N*p*(1-p).  Averaged over the nodes of a level the variance ratio is known to 4.5 % / sqrt(nodes)
+    (0.015 % at the leaves), so a split that is off in its ratio or its dispersion anywhere in the tree shows.
+    (Bit-exactness against the CPU restatement is test_device_sampler_tile_counts_bit_exact_at_size.)"""
+    import torch
+
+    N, nrep = 100_000_000, 1000
+    s = eng.DeviceSampler(20260101, nrep, N)
+    c = s.counts.view(torch.int32).to(torch.float64)          # (nrep, ntiles)
+    nt = c.shape[1]
+    assert torch.all(c.sum(dim=1) == N)
+    k = (nt - 1).bit_length()
+    pad = torch.zeros((nrep, (1 << k) - nt), dtype=torch.float64, device=c.device)
+    leaves = torch.cat([c, pad], dim=1)
+    size = torch.full((1 << k,), 1024.0, dtype=torch.float64, device=c.device)
+    size[nt - 1] = N - 1024.0 * (nt - 1)
+    size[nt:] = 0.0
+    for lvl in range(k, 0, -1):
+        nodes = 1 << lvl
+        cn = leaves.reshape(nrep, nodes, -1).sum(dim=2)
+        p = size.reshape(nodes, -1).sum(dim=1) / N
+        real = p > 0
+        m = int(real.sum())
+        mean = cn.mean(dim=0)[real]
+        var = cn.var(dim=0, unbiased=True)[real]
+        pv = p[real]
+        want_var = N * pv * (1 - pv)
+        z_mean = (mean - N * pv) / torch.sqrt(want_var / nrep)
+        assert float(z_mean.abs().max()) < 5.5, (lvl, float(z_mean.abs().max()))      # max of <= 1e5 standard normals
+        ratio = float((var / want_var).mean())
+        tol = 6 * (2.0 / (nrep - 1)) ** 0.5 / m ** 0.5
+        assert abs(ratio - 1.0) < tol, (lvl, m, ratio, tol)
