@@ -227,6 +227,21 @@ def test_device_sampler_tile_counts_bit_exact_at_size(eng, orc, ndat, nrep, nsam
     assert (counts.sum(axis=1, dtype=np.int64) == (nsamp or ndat)).all()
 
 
+def test_device_sampler_matches_committed_stream_vectors(eng):
+    """GPU tables vs tests/golden/sampler_stream_v2.json (no oracle in between)."""
+    import json
+    from pathlib import Path
+
+    g = json.load(open(Path(__file__).parent / "golden" / "sampler_stream_v2.json"))
+    for c in g["cases"]:
+        s = eng.DeviceSampler(c["seed"], c["nrep"], c["ndat"], nsamp=c["nsamp"])
+        assert s.counts.cpu().numpy().view(np.uint32).tolist() == c["counts"]
+        f = s.freq().cpu().numpy()
+        assert f[:, :48].tolist() == c["freq_head"]
+        w = np.arange(1, c["ndat"] + 1)
+        assert [int((f[r] * w).sum()) for r in range(c["nrep"])] == c["freq_checksum"]
+
+
 def test_device_sampler_nsamp(eng, orc):
     s = eng.DeviceSampler(3, 4, 5000, nsamp=12345)
     f = s.freq().cpu().numpy()

@@ -228,3 +228,21 @@ def test_device_sampler_tile_counts_are_multinomial(orc, ndat):
     tot = c.sum(axis=0)
     chi2 = ((tot - nrep * ndat * p) ** 2 / (nrep * ndat * p)).sum()
     assert chi2 < (nt - 1) + 6 * np.sqrt(2 * (nt - 1))
+
+
+def test_sampler_stream_v2_golden(orc):
+    """The stream definition is pinned by committed vectors (tests/golden/sampler_stream_v2.json, generated by
+    make_sampler_golden.py): the CPU restatement must reproduce them; the GPU is held to the restatement bit for bit
+    in test_kernels_gpu.py."""
+    import json
+    from pathlib import Path
+
+    g = json.load(open(Path(__file__).parent / "golden" / "sampler_stream_v2.json"))
+    assert g["stream_version"] == 2
+    for c in g["cases"]:
+        counts = orc.sampler_tile_counts(c["seed"], c["nrep"], c["ndat"], c["nsamp"])
+        assert counts.tolist() == c["counts"]
+        f = orc.sampler_freq(c["seed"], c["nrep"], c["ndat"], c["nsamp"], counts=counts)
+        assert f[:, :48].tolist() == c["freq_head"]
+        w = np.arange(1, c["ndat"] + 1)
+        assert [int((f[r] * w).sum()) for r in range(c["nrep"])] == c["freq_checksum"]
