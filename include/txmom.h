@@ -153,9 +153,9 @@ int txm_sampler_freq(const txm_sampler_spec *spec_host, const uint32_t *counts, 
  *                  monomial is scaled by the window maximum, rounded ONCE to a 51-bit
  *                  fixed-point integer (error <= 2^-51 of the window maximum, unbiased),
  *                  split into seven signed 8-bit digits and accumulated exactly in int32
- *                  (order 1..7; 32 columns per launch, orders above 4 in two passes over
+ *                  (order 0..7; 32 columns per launch, orders above 4 in two passes over
  *                  the sampler stream; taken when every 32-column group holds more than 16 columns and
- *                  nrep >= 64 (order >= 3) or 384 (order 2)).
+ *                  nrep >= 64 (order >= 3), 128 (orders 1, 2) or 384 (order 0)).
  *                  PRECISION GUARD (data dependent, automatic): the pre-pass also takes, per window, a robust
  *                  typical magnitude of the top-power monomial (the smallest of 64 group means of
  *                  |w du^order dx_c|); a window whose scale exceeds 275 sqrt(n) times it -- a heavy tail, an

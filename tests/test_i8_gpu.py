@@ -270,10 +270,11 @@ def test_dispatch_thresholds(eng):
         assert eng.resample_path(big, 32, 1000, 4) == "int8"
         assert eng.resample_path(big, 32, 64, 4) == "int8"
         assert eng.resample_path(big, 32, 48, 4) == "fp64"        # less than one replicate group
-        assert eng.resample_path(big, 32, 300, 2) == "fp64"       # orders 1 and 2 need >= 384
-        assert eng.resample_path(big, 32, 400, 2) == "int8"
+        assert eng.resample_path(big, 32, 100, 2) == "fp64"       # orders 1 and 2 need >= 128
+        assert eng.resample_path(big, 32, 128, 2) == "int8"
         assert eng.resample_path(big, 32, 400, 1) == "int8"
-        assert eng.resample_path(big, 32, 1000, 0) == "fp64"      # order 0: the two kernels are within 5 %
+        assert eng.resample_path(big, 32, 300, 0) == "fp64"       # order 0 needs >= 384
+        assert eng.resample_path(big, 32, 1000, 0) == "int8"
         assert eng.resample_path(big, 8, 1000, 4) == "fp64"       # one 16-column FP64 block is cheaper
         assert eng.resample_path(big, 64, 1000, 4) == "int8"      # two column groups
         assert eng.resample_path(big, 40, 1000, 4) == "fp64"      # 8-column tail group

@@ -699,15 +699,14 @@ static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   const int ov = path_override();
   if (ov == TXM_PATH_FP64) return false;
   if (ov == TXM_PATH_INT8) return true;
-  // measured on MI355X (tools/i8_sweep.py, N = 1e7; tools/ab_order.py, N = 1e8, nrep = 1000): C <= 16 runs one
-  // 16-column FP64 block and stays ahead; with two blocks the int8 kernel wins from one full replicate group on at
-  // order >= 3 (order 4: 1.2x at 64 replicates, 1.5x at 128, 1.6x from 400) and from ~400 replicates at orders 1
-  // and 2 (nrep = 1000: 185 vs 254 ms and 183 vs 341 ms).  Its time hardly depends on the order (167 / 185 / 183 /
-  // 192 / 213 ms for orders 0..4: a k-step is bound by its fixed latency chain, a power costs 11 ms); at order 0
-  // the two kernels are within 5 %, and the FP64 one is kept.  The last column group must also hold more than 16 columns.
+  // measured on MI355X (tools/i8_sweep.py, N = 1e7; tools/ab_order.py, N = 1e8): C <= 16 runs one 16-column FP64
+  // block and stays ahead; with two blocks the int8 kernel wins from one full replicate group on at order >= 3
+  // (order 4: 1.2x at 64 replicates, 1.5x at 128, 1.6x from 400), from 128 replicates at orders 1 and 2 (nrep = 128:
+  // 25 vs 32 ms and 29 vs 43 ms; nrep = 1000: 157 vs 254 ms and 181 vs 342 ms) and from ~400 at order 0 (nrep = 200:
+  // a tie; 400: 74 vs 80 ms; 1000: 151 vs 176 ms).  The last column group must also hold more than 16 columns.
   const int64_t ctail = C % I8_CPAD;
-  const int64_t min_rep = K >= 4 ? 64 : 384;
-  return K >= 2 && C > 16 && (ctail == 0 || ctail > 16) && nrep >= min_rep && N >= 262144;
+  const int64_t min_rep = K >= 4 ? 64 : (K >= 2 ? 128 : 384);
+  return C > 16 && (ctail == 0 || ctail > 16) && nrep >= min_rep && N >= 262144;
 }
 
 }  // namespace txm

@@ -435,6 +435,10 @@ struct I8Chunk {
 template <int K, int J0, int JN, bool WEIGHTED>
 __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
   static_assert(JN >= 1 && JN <= 5 && J0 + JN <= K, "power range");
+#ifndef TXM_I8_XD
+#define TXM_I8_XD 4
+#endif
+  constexpr int XD = JN <= 2 ? TXM_I8_XD : 1;  // x-chunk prefetch depth in k-steps (a power of two, even or 1)
   constexpr int NPAIR = 3 * JN;
   constexpr int UF = (8 * JN + 31) / 32;
   constexpr int NFRG = JN + UF;
@@ -475,7 +479,15 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
   // MFMA role, the same shape for every wave (no per-wave code paths): the pair rows 2 wave and
   // 2 wave + 1 (4 tiles each: two digits x two replicate halves) and the plain fragment `wave`
   // (2 tiles).  Indices past the end are clamped: those tiles compute a duplicate that is never flushed.
-  const int p0i = 2 * wave, p1i = 2 * wave + 1, f2i = wave;
+  // With one or two powers there are fewer rows than waves: they are dealt out one per wave (fragments from the
+  // last wave down) and a wave without a row in a slot skips that slot's reads and MFMAs -- otherwise wave 0 would
+  // carry 10 MFMAs per k-step and six waves would compute duplicates (orders 0 and 1 took as long as order 4).
+  constexpr bool SPREAD = JN <= 2;
+  const int p0i = SPREAD ? wave : 2 * wave, p1i = SPREAD ? wave + I8_WAVES : 2 * wave + 1,
+            f2i = SPREAD ? I8_WAVES - 1 - wave : wave;
+  // (from three powers on, the one or two waves without a first row compute a clamped duplicate as before: a branch
+  // around the slot costs the other waves more than the duplicate does -- order 3: 209 vs 192 ms)
+  const bool s0ok = !SPREAD || p0i < NPAIR, p1ok = p1i < NPAIR, f2ok = f2i < NFRG;  // wave-uniform
   const int p0 = p0i < NPAIR ? p0i : NPAIR - 1, p1 = p1i < NPAIR ? p1i : NPAIR - 1, f2 = f2i < NFRG ? f2i : NFRG - 1;
   static_assert(2 * I8_WAVES >= NPAIR && I8_WAVES >= NFRG, "every row and fragment has an owner");
   const uint32_t prot = (uint32_t)((n32 >> 1) & 3);
@@ -639,7 +651,7 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
     // order); the MFMAs of a slot go out between the powers, the next slot's reads one power ahead
     v4i Ra = (v4i)(0), Rb = (v4i)(0), Rc = (v4i)(0), Rd = (v4i)(0);
 #ifndef TXM_I8_NO_MFMA
-    if (mf) {
+    if (mf && s0ok) {
       Ra = *reinterpret_cast<const v4i *>(bcur + p0 * PAIR_B + pr0);
       Rb = *reinterpret_cast<const v4i *>(bcur + p0 * PAIR_B + pr1);
     }
@@ -660,6 +672,7 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
       }
     }
     if (slice) load_chunk(wbase, snext, r);
+    TXM_TICK(3);
 #pragma unroll
     for (int q = 0; q < J0; ++q) {
       p[0] *= du[0];
@@ -681,23 +694,27 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
 #ifndef TXM_I8_NO_MFMA
       if (mf) {
         if (it == 0) {
-          Rc = *reinterpret_cast<const v4i *>(bcur + p1 * PAIR_B + pr0);
-          Rd = *reinterpret_cast<const v4i *>(bcur + p1 * PAIR_B + pr1);
-          v4i Xa, Xb;
-          deinterleave(Ra, Rb, Xa, Xb);
-          TXM_I8_MFMA2(acc[0], acc[1], Xa);
-          TXM_I8_MFMA2(acc[2], acc[3], Xb);
+          if (SPREAD ? p1ok : true) {
+            Rc = *reinterpret_cast<const v4i *>(bcur + p1 * PAIR_B + pr0);
+            Rd = *reinterpret_cast<const v4i *>(bcur + p1 * PAIR_B + pr1);
+          }
+          if (s0ok) {
+            v4i Xa, Xb;
+            deinterleave(Ra, Rb, Xa, Xb);
+            TXM_I8_MFMA2(acc[0], acc[1], Xa);
+            TXM_I8_MFMA2(acc[2], acc[3], Xb);
+          }
         }
         if (it == 1) {
-          Ra = *reinterpret_cast<const v4i *>(bcur + f2 * I8_FRAG + fr);
-          if (p1i < NPAIR) {  // wave-uniform: the last wave's second row is a clamped duplicate
+          if (SPREAD ? f2ok : true) Ra = *reinterpret_cast<const v4i *>(bcur + f2 * I8_FRAG + fr);
+          if (p1ok) {  // wave-uniform: a wave without a second row skips the slot
             v4i Xa, Xb;
             deinterleave(Rc, Rd, Xa, Xb);
             TXM_I8_MFMA2(acc[4], acc[5], Xa);
             TXM_I8_MFMA2(acc[6], acc[7], Xb);
           }
         }
-        if (it == 2 && f2i < NFRG) TXM_I8_MFMA2(acc[8], acc[9], Ra);
+        if (it == 2 && f2ok) TXM_I8_MFMA2(acc[8], acc[9], Ra);
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);
@@ -761,7 +778,11 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
     // load slot of this tile's last slicing call.  (Weighted launches have no LDS left for second u and w tiles:
     // they prefetch the counts and the x chunk only.)  Nothing is requested across windows.
     bool have_pref = false;  // uniform
-    I8Chunk r0;
+    // x chunks in flight.  With one or two powers per launch a k-step is shorter than the latency of a global load,
+    // so the chunk is requested XD = 4 k-steps ahead (the slicing temporaries of so few powers leave the registers);
+    // from three powers on one step ahead is enough and anything deeper spills (measured: depth 2 at JN = 5, +3 %).
+    I8Chunk rq[XD];
+    I8Chunk &r0 = rq[0];
     const int64_t rep0w = rep0 + wave * I8_REPS_WAVE;
     const uint32_t rl0 = (uint32_t)(wave * I8_REPS_WAVE);
     auto tile_base = [&](int64_t tt) {
@@ -804,7 +825,8 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
       const bool cnt_lane = lane_f < (uint32_t)I8_REPS_WAVE && rep0w + (int64_t)lane_f < a.nrep;
       uint32_t wcnt;  // lane i < 8: draws of replicate rep0w + i in this tile
       if (!have_pref) {  // first tile of a window: nothing was requested ahead
-        load_chunk(wbase, 0, r0);
+#pragma unroll
+        for (int q = 0; q < XD; ++q) load_chunk(wbase, q, rq[q]);
         wcnt = cnt_lane ? a.counts[(size_t)(rep0w + lane_f) * a.ntiles + t] : 0u;
       } else {
         wcnt = lane_f < (uint32_t)I8_REPS_WAVE ? cntlds[rl0 + lane_f] : 0u;
@@ -867,6 +889,35 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
       TXM_TICK(1);
 
       // ---- contraction: chunk s on the matrix pipe, chunk s+1 through the slicer ----
+      if constexpr (XD > 1) {
+        // chunk c lives in rq[c % XD]; the step that slices it requests chunk c + XD into the same registers
+        // (past the end of the tile: the next tile's chunk c + XD - 32, or a harmless re-load on the last tile)
+        auto target = [&](int cl, int64_t &wb, int &sl) {
+          if (cl < I8_STEPS) { wb = wbase; sl = cl; }
+          else if (has_next) { wb = wnext; sl = cl - I8_STEPS; }
+          else { wb = wbase; sl = I8_STEPS - 1; }
+        };
+        {
+          int64_t wb; int sl;
+          target(XD, wb, sl);
+          step(bb1, 0, bb0, rq[0], wb, 0, sl, true, false);  // prologue: slice chunk 0, no MFMAs
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int s0 = 0; s0 < I8_STEPS; s0 += XD) {
+#pragma unroll
+          for (int e = 0; e < XD; ++e) {
+            const int sq = s0 + e, cs = sq + 1;
+            int64_t wb; int sl;
+            target(cs + XD, wb, sl);
+            step((e & 1) ? bb1 : bb0, sq, (e & 1) ? bb0 : bb1, rq[(e + 1) % XD], wb, cs < I8_STEPS ? cs : I8_STEPS - 1, sl,
+                 cs < I8_STEPS);
+            TXM_TICK(4);
+            __syncthreads();
+            TXM_TICK(5);
+          }
+        }
+      } else {
       step(bb1, 0, bb0, r0, wbase, 0, 1, true, false);  // prologue: slice chunk 0, no MFMAs
       TXM_TICK(4);
       __syncthreads();
@@ -887,6 +938,7 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
       __syncthreads();
       step(bb1, I8_STEPS - 1, bb0, r0, wbase, I8_STEPS - 1, I8_STEPS - 1, false);
       __syncthreads();
+      }
       have_pref = has_next;
       if constexpr (!WEIGHTED) {
         if (has_next) {  // the parked u tile becomes the current one

@@ -1,5 +1,5 @@
 """Phase timing of the int8 kernel (build with -DTXM_I8_TIMING; GPU box):
-TXM_LIBRARY=<timing build> python tools/i8_timing.py [N]"""
+TXM_LIBRARY=<timing build> python tools/i8_timing.py [N] [order]"""
 import os, sys, ctypes as ct
 import torch
 sys.path.insert(0, ".")
@@ -8,12 +8,14 @@ os.environ["TXM_THROTTLE"] = os.environ.get("TXM_THROTTLE", "1")
 from thermoextrap_amd import engine as eng, _lib
 from bench import make_data
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20_000_000
-C, order, nrep = 32, 4, 1000
+C, order, nrep = 32, (int(sys.argv[2]) if len(sys.argv) > 2 else 4), 1000
 x, u = make_data(N, C, 0, torch)
 s = eng.DeviceSampler(1, nrep, N)
 L = _lib.load()
 nbytes = L.txm_resample_vals_ws_bytes(N, C, nrep, order)
-eng.resample_vals(x, u, order, sampler=s); torch.cuda.synchronize()
+with eng.forced_path("int8"):
+    eng.resample_vals(x, u, order, sampler=s)
+torch.cuda.synchronize()
 ws = eng.workspace(nbytes)
 # locate the window table: recompute the plan offsets like plan_i8 (n_chunks=16, nrep_pad=1024 for this shape)
 ntiles = -(-N // 1024); K = order + 1
