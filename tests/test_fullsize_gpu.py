@@ -1,5 +1,6 @@
-"""Parity at BASELINE.json's full sizes through size-independent properties (the CPU
-oracle cannot run these sizes):
+"""Parity at BASELINE.json's full sizes: size-independent properties for every replicate and column (the CPU
+oracle cannot run 1e8 x 32 x 1000), the CPU oracle itself on two replicates x two columns of the benchmark shapes
+(test_north_star_bootstrap_vs_oracle_fullsize), the sampler bit for bit and statistically at size:
 
   C2          N = 1e7, N_obs = 8,  order 4, nrep = 200
   north star  N = 1e8, N_obs = 32, order 4, nrep = 1000 (bootstrap), order 6 (reduce)
@@ -236,3 +237,35 @@ def test_sampler_tile_counts_dispersion_at_every_tree_level_fullsize(eng):
         ratio = float((var / want_var).mean())
         tol = 6 * (2.0 / (nrep - 1)) ** 0.5 / m ** 0.5
         assert abs(ratio - 1.0) < tol, (lvl, m, ratio, tol)
+
+
+@pytest.mark.parametrize("order,weighted", [(4, False), (6, True)])
+def test_north_star_bootstrap_vs_oracle_fullsize(eng, orc, order, weighted):
+    """The benchmark shapes end to end against the CPU oracle: N = 1e8, N_obs = 32, nrep = 1000, order 4 (north star)
+    and order 6 with weights (c4: two int8 passes) on the default dispatch (int8 kernel + guard); replicates 0 and 1,
+    observable columns 0 and 31 are recomputed by the oracle's extended-precision two-pass definition on the frequency
+    rows of the same stream (a replicate's draws do not depend on nrep, so a 2-replicate sampler with the same seed
+    materialises them).  1e-12 of the natural scale of every central comoment, as at the small sizes."""
+    N, C, nrep, seed = 100_000_000, 32, 1000, 777001 + order
+    x, u = synth(N, C, 29)
+    w = None
+    if weighted:
+        w = torch.empty(N, dtype=torch.float64, device="cuda").uniform_(0.25, 4.0, generator=torch.Generator("cuda").manual_seed(5))
+    assert eng.resample_path(N, C, nrep, order) == "int8"
+    rep = eng.resample_vals(x, u, order, sampler=eng.DeviceSampler(seed, nrep, N), w=w)
+    freq = eng.DeviceSampler(seed, 2, N).freq().cpu().numpy()               # (2, N) int64
+    cols = [0, C - 1]
+    xh = x[:, cols].contiguous().cpu().numpy()
+    uh = u.cpu().numpy()
+    wh = None if w is None else w.cpu().numpy()
+    su, sx = float(uh.std()), xh.std(axis=0)
+    K = order + 1
+    sc = np.empty((len(cols), 2, K))
+    for b in range(K):
+        sc[:, 0, b] = su**b
+        sc[:, 1, b] = sx * su**b
+    got = rep[:2][:, cols].cpu().numpy()
+    for r in range(2):
+        truth = orc.truth_cov(xh, uh, order, w=None if w is None else wh, freq_row=freq[r])
+        err = np.abs(got[r] - truth) / (np.abs(truth) + sc)
+        assert err.max() <= 1e-12, (r, err.max(), np.unravel_index(err.argmax(), err.shape))
