@@ -98,9 +98,16 @@ def raw_moments(x, u, kmax, w=None):
     u = np.asarray(u, dtype=np.longdouble)
     w = np.ones_like(u) if w is None else np.asarray(w, dtype=np.longdouble)
     W = w.sum()
-    ru = np.array([(w * u**k).sum() / W for k in range(kmax + 1)], dtype=np.longdouble)
     xs = x.reshape(x.shape[0], -1)
-    rxu = np.stack([((w * u**k)[:, None] * xs).sum(axis=0) / W for k in range(kmax + 1)])
+    ru = np.empty(kmax + 1, dtype=np.longdouble)
+    rxu = np.empty((kmax + 1, xs.shape[1]), dtype=np.longdouble)
+    wuk = w.copy()  # w * u^k by repeated products (extended precision; the full-size tests run this on 1e8 samples)
+    for k in range(kmax + 1):
+        ru[k] = wuk.sum() / W
+        for c in range(xs.shape[1]):
+            rxu[k, c] = (wuk * xs[:, c]).sum() / W
+        if k < kmax:
+            wuk *= u
     # kept in extended precision: at order 6 the raw-moment recursion cancels ~13 digits
     # when u ~ 175 +- 5 (the ideal-gas notebook data); callers cast the final jets to float.
     return ru, rxu.reshape((kmax + 1,) + x.shape[1:])

@@ -269,3 +269,37 @@ def test_north_star_bootstrap_vs_oracle_fullsize(eng, orc, order, weighted):
         truth = orc.truth_cov(xh, uh, order, w=None if w is None else wh, freq_row=freq[r])
         err = np.abs(got[r] - truth) / (np.abs(truth) + sc)
         assert err.max() <= 1e-12, (r, err.max(), np.unravel_index(err.argmax(), err.shape))
+
+
+def test_north_star_step_derivs_vs_oracle_fullsize(eng, orc):
+    """The bench step itself -- ExtrapModel.resample({"nrep": 1000, device sampler}).derivs() at N = 1e8, N_obs = 32,
+    order 4 -- against the oracle on the materialised weights of replicates 0 and 1 (columns 0 and 31): the
+    extended-precision central comoments of oracle/cmomy_oracle.c fed to derivs_oracle.average_jet (raw moments about
+    <u>: the derivatives do not depend on the origin of u).  1e-10 relative (north_star's derivative tolerance), a
+    derivative that crosses zero held to its order's size."""
+    import thermoextrap_amd as xtrap
+    from oracle import derivs_oracle as dor
+    from thermoextrap_amd.moments import DeviceDataArray
+
+    N, C, order, nrep, seed = 100_000_000, 32, 4, 1000, 31337
+    K = order + 1
+    x, u = synth(N, C, 31)
+    data_ = xtrap.DataCentralMomentsVals.from_vals(xv=DeviceDataArray(x, ("rec", "val")), uv=DeviceDataArray(u, ("rec",)),
+                                                   order=order, central=True)
+    xem = xtrap.beta.factory_extrapmodel(1.0, data_)
+    boot = xem.resample(sampler={"nrep": nrep, "device": True, "seed": seed})
+    got = np.asarray(boot.derivs(norm=False).values)                 # (order + 1, rep, val)
+    assert got.shape == (K, nrep, C) and np.isfinite(got).all()
+    freq = eng.DeviceSampler(seed, 2, N).freq().cpu().numpy()
+    cols = [0, C - 1]
+    xh = x[:, cols].contiguous().cpu().numpy()
+    uh = u.cpu().numpy()
+    for r in range(2):
+        t = orc.truth_cov(xh, uh, order, freq_row=freq[r])           # (2, 2, K)
+        ru = np.r_[1.0, 0.0, t[0, 0, 2:]]
+        xbar = t[:, 1, 0]
+        rxu = np.stack([xbar if k == 0 else t[:, 1, k] + xbar * ru[k] for k in range(K)])
+        ref = np.asarray(dor.average_jet(rxu, ru, order), dtype=float)            # (order + 1, 2)
+        floor = np.median(np.abs(got[:, r, :]), axis=1, keepdims=True)
+        rel = np.abs(got[:, r, cols] - ref) / np.maximum(np.abs(ref), floor)
+        assert rel.max() < 1e-10, (r, rel.max(), np.unravel_index(rel.argmax(), rel.shape))
