@@ -429,7 +429,7 @@ struct I8Chunk {
 };
 
 // K = order + 1 fixes the layout of the partial sums; one launch slices the JN powers
-// J0 .. J0 + JN - 1 (orders above 4 take two launches: 10 accumulator tiles per wave is what the
+// J0 .. J0 + JN - 1 (orders above 4 take two launches, five powers and the rest: 10 accumulator tiles per wave is what the
 // 256-register budget leaves room for).
 //
 // B operand in LDS (per buffer):
@@ -1028,9 +1028,11 @@ int launch_resample_i8(const I8Args &a, int K, bool weighted, size_t prog_bytes,
     case 4: rc = launch_pass<4, 0, 4>(a, weighted, prog_bytes, st); break;
     case 5: rc = launch_pass<5, 0, 5>(a, weighted, prog_bytes, st); break;
     // orders 5..7: two passes over the sampler stream, each with its own powers
-    case 6: rc = launch_pass<6, 0, 3>(a, weighted, prog_bytes, st); if (rc == TXM_OK) rc = launch_pass<6, 3, 3>(a, weighted, prog_bytes, st); break;
-    case 7: rc = launch_pass<7, 0, 4>(a, weighted, prog_bytes, st); if (rc == TXM_OK) rc = launch_pass<7, 4, 3>(a, weighted, prog_bytes, st); break;
-    case 8: rc = launch_pass<8, 0, 4>(a, weighted, prog_bytes, st); if (rc == TXM_OK) rc = launch_pass<8, 4, 4>(a, weighted, prog_bytes, st); break;
+    // two passes: a full five-power pass, then the rest -- a pass costs ~150 / 157 / 181 / 205 / 202 ms for 1..5 powers
+    // (N = 1e8, nrep = 1000), so 5 + 2 (359 ms) beats 4 + 3 (386 ms) at order 6 and 5 + 3 beats 4 + 4 at order 7
+    case 6: rc = launch_pass<6, 0, 5>(a, weighted, prog_bytes, st); if (rc == TXM_OK) rc = launch_pass<6, 5, 1>(a, weighted, prog_bytes, st); break;
+    case 7: rc = launch_pass<7, 0, 5>(a, weighted, prog_bytes, st); if (rc == TXM_OK) rc = launch_pass<7, 5, 2>(a, weighted, prog_bytes, st); break;
+    case 8: rc = launch_pass<8, 0, 5>(a, weighted, prog_bytes, st); if (rc == TXM_OK) rc = launch_pass<8, 5, 3>(a, weighted, prog_bytes, st); break;
     default: set_error("resample_i8: order out of range"); return TXM_ERR_INVALID;
   }
   return rc;
