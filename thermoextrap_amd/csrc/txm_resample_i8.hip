@@ -446,7 +446,7 @@ template <int K, int J0, int JN, bool WEIGHTED>
 __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
   static_assert(JN >= 1 && JN <= 5 && J0 + JN <= K, "power range");
 #ifndef TXM_I8_XD
-#define TXM_I8_XD 4
+#define TXM_I8_XD 8
 #endif
   constexpr int XD = JN <= 2 ? TXM_I8_XD : 1;  // x-chunk prefetch depth in k-steps (a power of two, even or 1)
   constexpr int NPAIR = 3 * JN;
@@ -455,9 +455,13 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
   constexpr int PAIR_B = 2048, FRAG0 = NPAIR * PAIR_B, BUF = FRAG0 + NFRG * I8_FRAG;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   uint32_t *cnt = reinterpret_cast<uint32_t *>(lds);
+  // One or two powers per launch: a k-step is all latency (operand reads after the barrier, stores before the next
+  // one), so TWO 32-sample chunks go between barriers -- each B buffer holds a pair of chunks (NB = 2), chunk c in
+  // buffer (c >> 1) & 1, half c & 1, and the step that contracts chunk c slices chunk c + 2 into the other buffer.
+  constexpr int NB = JN <= 2 ? 2 : 1;
   unsigned char *bb0 = lds + I8_CNT_BYTES;
-  unsigned char *bb1 = bb0 + BUF;
-  uint32_t *fsum = reinterpret_cast<uint32_t *>(bb1 + BUF);  // [64] draws per replicate in the window
+  unsigned char *bb1 = bb0 + NB * BUF;
+  uint32_t *fsum = reinterpret_cast<uint32_t *>(bb1 + NB * BUF);  // [64] draws per replicate in the window
   // the tile's scaled u deviations (u - pu) / max|u - pu| and weights w / max|w|: loaded once per tile by the
   // whole workgroup instead of once per k-step by every lane
   uint32_t *cntlds = fsum + I8_REPS;  // [64] the next tile's draw counts, parked here while the k-steps run
@@ -523,7 +527,7 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
   for (int e = 0; e < 10; ++e) acc[e] = (v16i)(0);
 
   // rows of the B buffers that are never written (columns >= C, unused u-row columns) stay zero
-  for (int e = threadIdx.x; e < 2 * BUF / 16; e += I8_BLOCK)
+  for (int e = threadIdx.x; e < 2 * NB * BUF / 16; e += I8_BLOCK)
     reinterpret_cast<uint4 *>(bb0)[e] = make_uint4(0, 0, 0, 0);
 
   double inv_du = 0.0, inv_w = 1.0, sc = 0.0;
@@ -788,9 +792,12 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
     // load slot of this tile's last slicing call.  (Weighted launches have no LDS left for second u and w tiles:
     // they prefetch the counts and the x chunk only.)  Nothing is requested across windows.
     bool have_pref = false;  // uniform
-    // x chunks in flight.  With one or two powers per launch a k-step is shorter than the latency of a global load,
-    // so the chunk is requested XD = 4 k-steps ahead (the slicing temporaries of so few powers leave the registers);
-    // from three powers on one step ahead is enough and anything deeper spills (measured: depth 2 at JN = 5, +3 %).
+    // x chunks in flight.  With one or two powers per launch a k-step is shorter than the latency of a global load
+    // (the workgroup that leads its chunk group misses L2), so the chunk is requested XD = 8 k-steps ahead (order 0:
+    // 150.8 / 146.6 / 138.1 / 176.6 ms for 4 / 4 with paired chunks / 8 / 16; the slicing temporaries of so few powers
+    // leave the registers); from three powers on one step ahead is enough and anything deeper spills (depth 2 at
+    // JN = 5: +3 %).  Ablation at order 0: without the x loads 111 ms -- what is left of their cost is the 16 cache
+    // lines a wave's load touches (4 columns x 16 sample pairs), a property of the lane map.
     I8Chunk rq[XD];
     I8Chunk &r0 = rq[0];
     const int64_t rep0w = rep0 + wave * I8_REPS_WAVE;
@@ -907,23 +914,25 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
           else if (has_next) { wb = wnext; sl = cl - I8_STEPS; }
           else { wb = wbase; sl = I8_STEPS - 1; }
         };
-        {
+        static_assert(NB == 2 && XD % 2 == 0, "paired chunks");
+        auto bufof = [&](int c) { return (((c >> 1) & 1) ? bb1 : bb0) + (c & 1) * BUF; };
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {  // prologue: slice chunks 0 and 1, no MFMAs
           int64_t wb; int sl;
-          target(XD, wb, sl);
-          step(bb1, 0, bb0, rq[0], wb, 0, sl, true, false);  // prologue: slice chunk 0, no MFMAs
+          target(c + XD, wb, sl);
+          step(bb1, 0, bufof(c), rq[c % XD], wb, c, sl, true, false);
         }
         __syncthreads();
 #pragma unroll 1
         for (int s0 = 0; s0 < I8_STEPS; s0 += XD) {
 #pragma unroll
           for (int e = 0; e < XD; ++e) {
-            const int sq = s0 + e, cs = sq + 1;
+            const int sq = s0 + e, cs = sq + 2;  // contract chunk sq, slice chunk sq + 2
             int64_t wb; int sl;
             target(cs + XD, wb, sl);
-            step((e & 1) ? bb1 : bb0, sq, (e & 1) ? bb0 : bb1, rq[(e + 1) % XD], wb, cs < I8_STEPS ? cs : I8_STEPS - 1, sl,
-                 cs < I8_STEPS);
+            step(bufof(e), sq, bufof(e + 2), rq[(e + 2) % XD], wb, cs < I8_STEPS ? cs : I8_STEPS - 1, sl, cs < I8_STEPS);
             TXM_TICK(4);
-            __syncthreads();
+            if (e & 1) __syncthreads();
             TXM_TICK(5);
           }
         }
@@ -980,7 +989,8 @@ static int launch_pass(const I8Args &a, bool weighted, size_t prog_bytes, hipStr
   if (a.progress != nullptr) TXM_HIP(hipMemsetAsync(a.progress, 0, prog_bytes, st));  // every pass starts from "not started"
   const dim3 grid((unsigned)(a.n_chunks * a.n_rbg)), block(I8_BLOCK);
   constexpr int buf = 3 * JN * 2048 + (JN + (8 * JN + 31) / 32) * I8_FRAG;  // pair rows + plain fragments
-  const size_t lds = (size_t)I8_CNT_BYTES + 2u * (size_t)buf + 2u * I8_REPS * sizeof(uint32_t) +
+  constexpr int nb = JN <= 2 ? 2 : 1;  // chunks per B buffer (two k-steps per barrier with one or two powers)
+  const size_t lds = (size_t)I8_CNT_BYTES + 2u * nb * (size_t)buf + 2u * I8_REPS * sizeof(uint32_t) +
                      2u * SM_T * sizeof(double);  // + window draws, parked counts; two u tiles, or one u + one w
   // the dynamic-LDS limit is a property of the function: set it once per instantiation (one device per process)
   static bool lds_set[2] = {false, false};
