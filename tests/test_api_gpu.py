@@ -241,6 +241,58 @@ def test_predict_taylor_modes_definition(xtrap):
         engine.predict_taylor(dev, da, "mean")
 
 
+def test_dataset_observables(fixture, xtrap):
+    """``xv`` as a Dataset (reference data.py:347-350): the variables are column blocks of ONE sample matrix -- one
+    reduction, one bootstrap, one derivative evaluation -- and every result comes back as a Dataset whose variables
+    equal what the same variable gives on its own (same sampler for the bootstrap)."""
+    from thermoextrap_amd.xrlite import DataArray, Dataset
+
+    x, u = np.asarray(fixture.x.values), np.asarray(fixture.u.values)            # (rec, val), (rec,)
+    rng = np.random.default_rng(3)
+    a = DataArray(x, ("rec", "val"))
+    b = DataArray(x[:, 0] ** 2 + 0.1 * rng.normal(size=len(u)), ("rec",))                   # a per-record scalar
+    c = DataArray(rng.normal(size=(len(u), 2, 3)) + u[:, None, None], ("rec", "p", "q"),
+                  coords={"p": [10, 20], "q": [0.5, 1.5, 2.5]})
+    ds = Dataset({"a": a, "b": b, "c": c})
+    uv = DataArray(u, ("rec",))
+    order = 3
+    mk = lambda xv: xtrap.beta.factory_extrapmodel(  # noqa: E731
+        fixture.beta0, xtrap.DataCentralMomentsVals.from_vals(xv=xv, uv=uv, order=order, central=True))
+    m = mk(ds)
+    sampler = xtrap.moments.factory_sampler(ndat=len(u), nrep=9, rng=np.random.default_rng(12))
+    for model, single in ((m, mk), (m.resample(sampler=sampler), lambda xv: mk(xv).resample(sampler=sampler))):
+        d = model.derivs()
+        p = model.predict(fixture.betas, order=2)
+        pc = model.predict(fixture.betas[:3], cumsum=True)
+        assert isinstance(d, Dataset) and isinstance(p, Dataset) and set(d) == {"a", "b", "c"}
+        for name, var in ds.items():
+            one = single(var)
+            for got, want in ((d[name], one.derivs()), (p[name], one.predict(fixture.betas, order=2)),
+                              (pc[name], one.predict(fixture.betas[:3], cumsum=True))):
+                assert got.dims == want.dims, (name, got.dims, want.dims)
+                np.testing.assert_allclose(got.values, want.values, rtol=1e-11, atol=1e-13 * np.abs(want.values).max())
+        assert d["c"].coords["p"].tolist() == [10, 20]
+    # block data class: one reduction for all variables
+    blk = xtrap.DataCentralMoments.from_vals(uv=uv, xv=ds, order=order, dim="rec", central=True)
+    dd = xtrap.beta.factory_extrapmodel(fixture.beta0, blk).derivs()
+    np.testing.assert_allclose(dd["b"].values, m.derivs()["b"].values, rtol=1e-11)
+    with pytest.raises(ValueError):
+        xtrap.DataCentralMomentsVals.from_vals(xv=Dataset({"z": DataArray(np.zeros(3), ("other",))}), uv=uv, order=2)
+    # variables that already live in HBM are stacked on the device
+    import torch
+
+    from thermoextrap_amd.moments import DeviceDataArray
+
+    dev = Dataset({"a": DeviceDataArray(torch.as_tensor(a.values).cuda(), ("rec", "val")),
+                   "c": DeviceDataArray(torch.as_tensor(c.values).cuda(), ("rec", "p", "q"))})
+    md = xtrap.beta.factory_extrapmodel(fixture.beta0, xtrap.DataCentralMomentsVals.from_vals(
+        xv=dev, uv=DeviceDataArray(torch.as_tensor(u).cuda(), ("rec",)), order=order, central=True))
+    assert isinstance(md.data.xv, DeviceDataArray)
+    dv = md.derivs()
+    for name in ("a", "c"):
+        np.testing.assert_allclose(dv[name].values, m.derivs()[name].values, rtol=1e-11, atol=1e-13)
+
+
 def test_extrapmodel(fixture, xtrap):
     xem0 = xtrap.beta.factory_extrapmodel(beta=fixture.beta0, data=fixture.rdata)
     for data in [fixture.cdata, fixture.xdata, fixture.xrdata, fixture.xdata_val, fixture.xrdata_val]:

@@ -20,7 +20,7 @@ _LAZY = {
     "factory_data_values": "data", "xrwrap_uv": "data", "xrwrap_xv": "data", "xrwrap_alpha": "data",
     "Derivatives": "models", "ExtrapModel": "models", "StateCollection": "models", "PerturbModel": "models",
     "ExtrapWeightedModel": "models", "InterpModel": "models", "InterpModelPiecewise": "models",
-    "DataArray": "xrlite",
+    "DataArray": "xrlite", "Dataset": "xrlite",
 }
 _MODULES = {"stack", "distributed", "gpr_input", "beta", "data", "models", "moments", "idealgas", "symbolic", "engine", "xrlite", "volume", "volume_idealgas", "lnpi"}
 

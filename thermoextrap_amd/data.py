@@ -23,7 +23,7 @@ import numpy as np
 
 from . import moments as cmomy
 from .moments import MISSING, CentralMomentsData, DeviceDataArray
-from .xrlite import DataArray, as_labelled, concat, is_labelled
+from .xrlite import DataArray, Dataset, as_dataset, as_labelled, concat, is_dataset, is_labelled
 
 __all__ = [
     "DataCallback", "DataCallbackABC", "DataCentralMoments", "DataCentralMomentsVals", "DataSelector",
@@ -81,6 +81,67 @@ def xrwrap_alpha(alpha, dims=None, name="alpha") -> DataArray:
     if a.ndim == 1:
         return DataArray(a, dims, coords={dims: a}, name=name)
     return DataArray(a, dims, name=name)
+
+
+# ---------------------------------------------------------------------------
+# Dataset-valued observables (reference data.py:347-350: ``xv`` may be an xr.Dataset)
+# ---------------------------------------------------------------------------
+DS_DIM = "_dsvar"  # the column axis of a stacked Dataset
+
+
+def stack_dataset(ds, rec_dim):
+    """All variables of ``ds`` as ONE (rec, column) matrix -- each variable's non-record dims flattened into a block
+    of columns -- so that a Dataset costs one launch per kernel instead of one per variable.  Returns the matrix
+    (DataArray, or DeviceDataArray when every variable is one) and the layout ``unstack_dataset`` needs."""
+    ds = as_dataset(ds)
+    if len(ds) == 0:
+        raise ValueError("empty Dataset")
+    on_device = all(isinstance(v, DeviceDataArray) for v in ds.values())
+    blocks, layout, start, nrec = [], [], 0, None
+    for name, v in ds.items():
+        if rec_dim not in v.dims:
+            raise ValueError(f"Dataset variable {name!r} has no {rec_dim!r} dimension")
+        ax = v.dims.index(rec_dim)
+        other = tuple(d for d in v.dims if d != rec_dim)
+        if isinstance(v, DeviceDataArray):
+            t = v.tensor.movedim(ax, 0)
+            shape = tuple(t.shape[1:])
+            blk = t.reshape(t.shape[0], -1)
+            coords = {}
+            if not on_device:
+                blk = blk.cpu().numpy()
+        else:
+            a = np.moveaxis(np.asarray(v.values, dtype=np.float64), ax, 0)
+            shape = a.shape[1:]
+            blk = a.reshape(a.shape[0], -1)
+            coords = {k: (cd, cv) for k, (cd, cv) in v._coords.items() if cd and all(d in other for d in cd)}
+        if nrec is None:
+            nrec = blk.shape[0]
+        elif blk.shape[0] != nrec:
+            raise ValueError("Dataset variables differ in the length of the record dimension")
+        layout.append((name, start, start + blk.shape[1], other, tuple(shape), coords))
+        start += blk.shape[1]
+        blocks.append(blk)
+    if on_device:
+        import torch
+
+        return DeviceDataArray(torch.cat(blocks, dim=1).contiguous(), (rec_dim, DS_DIM)), tuple(layout)
+    return DataArray(np.ascontiguousarray(np.concatenate(blocks, axis=1)), (rec_dim, DS_DIM)), tuple(layout)
+
+
+def unstack_dataset(arr, layout) -> Dataset:
+    """Split the stacked column axis of a result back into the variables of the Dataset it came from."""
+    arr = as_labelled(arr)
+    ax = arr.dims.index(DS_DIM)
+    out = {}
+    for name, lo, hi, dims, shape, coords in layout:
+        vals = np.take(arr.values, np.arange(lo, hi), axis=ax)
+        vals = vals.reshape(arr.shape[:ax] + tuple(shape) + arr.shape[ax + 1:])
+        v = DataArray(vals, arr.dims[:ax] + tuple(dims) + arr.dims[ax + 1:], name=name)
+        v._inherit({k: c for k, c in arr._coords.items() if DS_DIM not in c[0]})
+        v._inherit(coords)
+        out[name] = v
+    return Dataset(out)
 
 
 def _need_dataarray(x, name=None):
@@ -525,9 +586,11 @@ def _source_from_state(state: CentralMomentsData, *, central, x_is_u, deriv_dim,
 # comoment-state based classes (reference data.py:791-1813)
 # ---------------------------------------------------------------------------
 class DataCentralMomentsBase(AbstractData):
-    _fields = ("dxduave", "xmom_dim", "umom_dim", "rec_dim", "deriv_dim", "central", "meta", "x_is_u", "use_cache")
+    _fields = ("dxduave", "xmom_dim", "umom_dim", "rec_dim", "deriv_dim", "central", "meta", "x_is_u", "use_cache",
+               "ds_layout")
 
-    def _init_base(self, dxduave, *, xmom_dim, umom_dim, rec_dim, deriv_dim, central, meta, x_is_u, use_cache):
+    def _init_base(self, dxduave, *, xmom_dim, umom_dim, rec_dim, deriv_dim, central, meta, x_is_u, use_cache,
+                   ds_layout=None):
         if not isinstance(dxduave, CentralMomentsData):
             raise TypeError("dxduave must be a CentralMomentsData")
         self.dxduave = dxduave
@@ -536,10 +599,19 @@ class DataCentralMomentsBase(AbstractData):
         self._use_cache = use_cache
         self._cache: dict[str, Any] = {}
         self.meta = _coerce_meta(meta, self)
+        # set when ``xv`` was a Dataset: its variables are column blocks of one matrix (stack_dataset); results with
+        # the stacked axis are split back by ``as_dataset_result``
+        self.ds_layout = ds_layout
 
     @property
     def use_cache(self):
         return self._use_cache
+
+    def as_dataset_result(self, arr):
+        """A result array of a Dataset-valued ``xv`` as a Dataset again (no-op for DataArray-valued data)."""
+        if self.ds_layout is None or not is_labelled(arr) or DS_DIM not in as_labelled(arr).dims:
+            return arr
+        return unstack_dataset(arr, self.ds_layout)
 
     @property
     def order(self) -> int:
@@ -638,9 +710,9 @@ class DataCentralMoments(DataCentralMomentsBase):
     """Comoment states (possibly several records of them) -- reference data.py:965-1618."""
 
     def __init__(self, dxduave, *, xmom_dim="xmom", umom_dim="umom", rec_dim="rec", deriv_dim=None, central=False,
-                 meta=None, x_is_u=False, use_cache=True):
+                 meta=None, x_is_u=False, use_cache=True, ds_layout=None):
         self._init_base(dxduave, xmom_dim=xmom_dim, umom_dim=umom_dim, rec_dim=rec_dim, deriv_dim=deriv_dim,
-                        central=central, meta=meta, x_is_u=x_is_u, use_cache=use_cache)
+                        central=central, meta=meta, x_is_u=x_is_u, use_cache=use_cache, ds_layout=ds_layout)
 
     def __len__(self):
         return self.values.sizes[self.rec_dim]
@@ -689,9 +761,16 @@ class DataCentralMoments(DataCentralMomentsBase):
                                              mom_dims=umom_dim, **kwargs).moments_to_comoments(
                 mom_dims_out=(xmom_dim, umom_dim), mom=(1, order))
         else:
+            ds_layout = None
+            if is_dataset(xv):  # the variables become column blocks of one matrix: one reduction for all of them
+                red = dim if dim is not MISSING else uv.dims[axis]
+                xv, ds_layout = stack_dataset(xv, red)
+                dim, axis = red, MISSING
             _need_dataarray(xv)
             dxduave = cmomy.wrap_reduce_vals(xv, uv, weight=weight, axis=axis, dim=dim, mom=(1, order),
                                              mom_dims=(xmom_dim, umom_dim), **kwargs)
+            return cls(dxduave=dxduave, xmom_dim=xmom_dim, umom_dim=umom_dim, rec_dim=rec_dim, deriv_dim=deriv_dim,
+                       central=central, meta=meta, x_is_u=x_is_u, ds_layout=ds_layout)
         return cls(dxduave=dxduave, xmom_dim=xmom_dim, umom_dim=umom_dim, rec_dim=rec_dim, deriv_dim=deriv_dim,
                    central=central, meta=meta, x_is_u=x_is_u)
 
@@ -808,15 +887,17 @@ class DataCentralMomentsVals(DataCentralMomentsBase):
     construction, as in the reference (``_convert_dxduave``, data.py:1621-1640)."""
 
     _fields = ("uv", "xv", "order", "weight", "from_vals_kws", "dxduave", "xmom_dim", "umom_dim", "rec_dim",
-               "deriv_dim", "central", "meta", "x_is_u", "use_cache")
+               "deriv_dim", "central", "meta", "x_is_u", "use_cache", "ds_layout")
 
     def __init__(self, uv, xv, *, order=None, weight=None, from_vals_kws=None, dxduave=None, xmom_dim="xmom",
                  umom_dim="umom", rec_dim="rec", deriv_dim=None, central=False, meta=None, x_is_u=False,
-                 use_cache=True):
+                 use_cache=True, ds_layout=None):
         if not _labelled(uv):
             raise TypeError("uv must be a DataArray")
+        if is_dataset(xv):  # reference data.py:347-350; the variables become column blocks of one sample matrix
+            xv, ds_layout = stack_dataset(xv, rec_dim)
         if not _labelled(xv):
-            raise TypeError("xv must be a DataArray")
+            raise TypeError("xv must be a DataArray or Dataset")
         if order is not None and not isinstance(order, (int, np.integer)):
             raise TypeError("order must be an int")
         self.uv, self.xv, self.order_, self.weight = uv, xv, order, weight
@@ -827,7 +908,7 @@ class DataCentralMomentsVals(DataCentralMomentsBase):
             dxduave = cmomy.wrap_reduce_vals(xv, uv, weight=weight, dim=rec_dim, mom=(1, order),
                                              mom_dims=(xmom_dim, umom_dim), **self.from_vals_kws)
         self._init_base(dxduave, xmom_dim=xmom_dim, umom_dim=umom_dim, rec_dim=rec_dim, deriv_dim=deriv_dim,
-                        central=central, meta=meta, x_is_u=x_is_u, use_cache=use_cache)
+                        central=central, meta=meta, x_is_u=x_is_u, use_cache=use_cache, ds_layout=ds_layout)
 
     # `order` is a constructor field here but derived from the state elsewhere
     @property

@@ -250,8 +250,15 @@ class ExtrapModel(_Params):
             order = self.order
         out = self._derivs(order=order, order_dim=order_dim, minus_log=minus_log)
         if norm:
-            return out * taylor_series_norm(order, order_dim)
-        return out
+            out = out * taylor_series_norm(order, order_dim)
+        return self._ds(out)
+
+    def _ds(self, out):
+        """Results of Dataset-valued observables go back out as a Dataset (the kernels saw one stacked matrix)."""
+        f = getattr(self.data, "as_dataset_result", None)
+        if f is None or isinstance(out, list):
+            return out
+        return f(out)
 
     def coefs(self, order=None, order_dim="order", minus_log=None):
         return self.derivs(order=order, order_dim=order_dim, minus_log=minus_log, norm=True)
@@ -290,7 +297,7 @@ class ExtrapModel(_Params):
             out._inherit(dalpha._coords)
             out._inherit(src.coords)
         else:
-            coefs = self.coefs(order=order, order_dim=order_dim, minus_log=minus_log)
+            coefs = self._derivs(order=order, order_dim=order_dim, minus_log=minus_log) * taylor_series_norm(order, order_dim)
             p = DataArray(np.arange(order + 1), order_dim)
             prefac = dalpha**p
             out = prefac * coefs
@@ -303,12 +310,12 @@ class ExtrapModel(_Params):
             coords[alpha0_coords] = self.alpha0
         out = out.assign_coords(coords)
         if fused and order_dim is not None:
-            return out
+            return self._ds(out)
         if no_sum:
-            return out
+            return self._ds(out)
         if cumsum:
-            return out.cumsum(order_dim)
-        return out.sum(order_dim)
+            return self._ds(out.cumsum(order_dim))
+        return self._ds(out.sum(order_dim))
 
     def resample(self, sampler, **kws):
         """New model on resampled data."""

@@ -438,6 +438,81 @@ def _expand(a: DataArray, dims) -> np.ndarray:
     return v.reshape(shape)
 
 
+class Dataset:
+    """A named collection of labelled arrays sharing dims (the part of xarray.Dataset the reference's data classes
+    accept for ``xv``, reference data.py:347-350): mapping access, ``data_vars``, ``map``."""
+
+    def __init__(self, data_vars: Mapping[Hashable, Any] | None = None, attrs: Mapping | None = None):
+        self._vars: dict[Hashable, DataArray] = {}
+        for k, v in (data_vars or {}).items():
+            self[k] = v
+        self.attrs = dict(attrs or {})
+
+    def __setitem__(self, key, value):
+        if is_labelled(value):
+            v = as_labelled(value)
+            self._vars[key] = v if v.name == key else DataArray(v.values, v.dims, v.coords, key, v.attrs)
+        elif hasattr(value, "dims") and hasattr(value, "sizes"):  # e.g. moments.DeviceDataArray (samples resident in HBM)
+            self._vars[key] = value
+        else:
+            raise TypeError(f"Dataset variable {key!r} must be a labelled array")
+
+    def __getitem__(self, key) -> DataArray:
+        return self._vars[key]
+
+    def __iter__(self):
+        return iter(self._vars)
+
+    def __len__(self):
+        return len(self._vars)
+
+    def __contains__(self, key):
+        return key in self._vars
+
+    def keys(self):
+        return self._vars.keys()
+
+    def items(self):
+        return self._vars.items()
+
+    def values(self):
+        return self._vars.values()
+
+    @property
+    def data_vars(self) -> dict:
+        return dict(self._vars)
+
+    @property
+    def sizes(self) -> dict:
+        out: dict = {}
+        for v in self._vars.values():
+            for d, n in v.sizes.items():
+                if out.setdefault(d, n) != n:
+                    raise ValueError(f"conflicting sizes for dimension {d!r}")
+        return out
+
+    @property
+    def dims(self) -> tuple:
+        return tuple(self.sizes)
+
+    def map(self, func, *args, **kwargs) -> "Dataset":
+        return Dataset({k: func(v, *args, **kwargs) for k, v in self._vars.items()}, self.attrs)
+
+    def __repr__(self):
+        body = "\n".join(f"    {k}: {v.dims} {v.shape}" for k, v in self._vars.items())
+        return f"<thermoextrap_amd.xrlite.Dataset>\n{body}"
+
+
+def is_dataset(x) -> bool:
+    return isinstance(x, Dataset) or (_xr is not None and isinstance(x, _xr.Dataset))
+
+
+def as_dataset(x) -> Dataset:
+    if isinstance(x, Dataset):
+        return x
+    return Dataset({k: as_labelled(v) for k, v in x.data_vars.items()}, getattr(x, "attrs", None))
+
+
 def as_labelled(x, dims=None, name=None) -> DataArray:
     """DataArray from ours / xarray's / array-like (dims required for the latter)."""
     if isinstance(x, DataArray):
