@@ -496,12 +496,14 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
   // With one or two powers there are fewer rows than waves: they are dealt out one per wave (fragments from the
   // last wave down) and a wave without a row in a slot skips that slot's reads and MFMAs -- otherwise wave 0 would
   // carry 10 MFMAs per k-step and six waves would compute duplicates (orders 0 and 1 took as long as order 4).
-  constexpr bool SPREAD = JN <= 2;
+  // (measured, N = 1e8, nrep = 1000: the dealt-out map also wins with four powers -- 203.0 -> 191.5 ms, no duplicates on
+  // waves 6 and 7 -- is neutral with three and loses with five, 216 vs 203 ms, where every wave already owns two rows)
+  constexpr bool SPREAD = JN <= 2 || JN == 4;
   const int p0i = SPREAD ? wave : 2 * wave, p1i = SPREAD ? wave + I8_WAVES : 2 * wave + 1,
             f2i = SPREAD ? I8_WAVES - 1 - wave : wave;
   // (from three powers on, the one or two waves without a first row compute a clamped duplicate as before: a branch
   // around the slot costs the other waves more than the duplicate does -- order 3: 209 vs 192 ms)
-  const bool s0ok = !SPREAD || p0i < NPAIR, p1ok = p1i < NPAIR, f2ok = f2i < NFRG;  // wave-uniform
+  const bool s0ok = !SPREAD || NPAIR >= I8_WAVES || p0i < NPAIR, p1ok = p1i < NPAIR, f2ok = f2i < NFRG;  // wave-uniform
   const int p0 = p0i < NPAIR ? p0i : NPAIR - 1, p1 = p1i < NPAIR ? p1i : NPAIR - 1, f2 = f2i < NFRG ? f2i : NFRG - 1;
   static_assert(2 * I8_WAVES >= NPAIR && I8_WAVES >= NFRG, "every row and fragment has an owner");
   const uint32_t prot = (uint32_t)((n32 >> 1) & 3);
