@@ -78,6 +78,11 @@ def truth_err(orc, got, x, u, order, freq, reps, w=None, sc=None):
     (40000, 17, 3, 64, True),       # order 3 (u-row shares block 4), weights
     (20000, 32, 2, 100, True),      # order 2 (no shared blocks)
     (70001, 1, 4, 65, False),       # 1-D observable
+    (50000, 8, 4, 70, False),       # narrow states: four powers per observable column, two row sets
+    (50000, 3, 6, 64, True),        # ... order 6 (powers 0-3 and 4-6), weighted
+    (33000, 1, 7, 65, True),        # ... order 7, 1-D observable
+    (20000, 8, 1, 64, False),       # ... order 1: one row set, two of four power slots used
+    (20000, 6, 3, 130, True),       # ... order 3: exactly one row set
 ])
 def test_i8_matches_fp64_on_same_stream(eng, orc, N, C, order, nrep, weighted):
     x, u = data(N, C, 5)
@@ -275,7 +280,10 @@ def test_dispatch_thresholds(eng):
         assert eng.resample_path(big, 32, 400, 1) == "int8"
         assert eng.resample_path(big, 32, 300, 0) == "fp64"       # order 0 needs >= 384
         assert eng.resample_path(big, 32, 1000, 0) == "int8"
-        assert eng.resample_path(big, 8, 1000, 4) == "fp64"       # one 16-column FP64 block is cheaper
+        assert eng.resample_path(big, 8, 1000, 4) == "int8"       # narrow state: four powers per column
+        assert eng.resample_path(big, 8, 100, 4) == "fp64"        # ... from 128 replicates
+        assert eng.resample_path(big, 8, 1000, 1) == "fp64"       # ... from order 2
+        assert eng.resample_path(big, 12, 1000, 4) == "fp64"      # 8 < C <= 16: one 16-column FP64 block is cheaper
         assert eng.resample_path(big, 64, 1000, 4) == "int8"      # two column groups
         assert eng.resample_path(big, 40, 1000, 4) == "fp64"      # 8-column tail group
         assert eng.resample_path(big, 32, 1000, 8) == "fp64"      # order 8: FP64 only

@@ -704,6 +704,10 @@ static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   // (order 4: 1.2x at 64 replicates, 1.5x at 128, 1.6x from 400), from 128 replicates at orders 1 and 2 (nrep = 128:
   // 25 vs 32 ms and 29 vs 43 ms; nrep = 1000: 157 vs 254 ms and 181 vs 342 ms) and from ~400 at order 0 (nrep = 200:
   // a tie; 400: 74 vs 80 ms; 1000: 151 vs 176 ms).  The last column group must also hold more than 16 columns.
+  // Narrow states (C <= 8) run the int8 kernel with four powers per observable column: ahead of the power-packed
+  // FP64 kernel from 128 replicates on at order >= 2 (N = 1e7, nrep = 200, C = 8: 4.5 vs 4.75 ms at order 3, 4.9 vs
+  // 6.1 at order 4, 6.2 vs 10.7 at order 6; N = 1e8: 40.6 vs 55.1 ms; C <= 4 or order <= 2: within 5 %).
+  if (C <= 8) return K >= 3 && nrep >= 128 && N >= 262144;
   const int64_t ctail = C % I8_CPAD;
   const int64_t min_rep = K >= 4 ? 64 : (K >= 2 ? 128 : 384);
   return C > 16 && (ctail == 0 || ctail > 16) && nrep >= min_rep && N >= 262144;

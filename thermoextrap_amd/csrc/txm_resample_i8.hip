@@ -442,15 +442,22 @@ struct I8Chunk {
 //     the read side.)
 //   plain fragments [32 columns][32 k-bytes] = 1 KiB: digit 6 of every power (b16 stores), then the
 //     packed u-row fragments (column 8 jj + i = digit i of the u-row power jj).
-template <int K, int J0, int JN, bool WEIGHTED>
+//
+// PK > 1 (narrow states, C <= 32 / PK observables): the 32 B-operand columns carry PK powers per observable -- column
+// slot n = jq * CP + c (CP = 32 / PK) holds w * du^(jq + PK * jj) * dx_c in row set jj -- so that a state with 8
+// observables and order 4 needs 2 row sets instead of 5 and no column of an MFMA is wasted.  JN then counts row sets.
+template <int K, int J0, int JN, bool WEIGHTED, int PK = 1>
 __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
-  static_assert(JN >= 1 && JN <= 5 && J0 + JN <= K, "power range");
+  static_assert(JN >= 1 && JN <= 5 && (PK == 1 ? J0 + JN <= K : (J0 == 0 && (JN - 1) * PK < K)), "power range");
+  static_assert(PK == 1 || PK == 2 || PK == 4, "powers per observable column");
+  constexpr int CP = 32 / PK;                                     // observable columns per launch
+  constexpr int KL = PK == 1 ? JN : (K < JN * PK ? K : JN * PK);  // powers of this launch (= u-row monomials)
 #ifndef TXM_I8_XD
 #define TXM_I8_XD 8
 #endif
   constexpr int XD = JN <= 2 ? TXM_I8_XD : 1;  // x-chunk prefetch depth in k-steps (a power of two, even or 1)
   constexpr int NPAIR = 3 * JN;
-  constexpr int UF = (8 * JN + 31) / 32;
+  constexpr int UF = (8 * KL + 31) / 32;
   constexpr int NFRG = JN + UF;
   constexpr int PAIR_B = 2048, FRAG0 = NPAIR * PAIR_B, BUF = FRAG0 + NFRG * I8_FRAG;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -479,13 +486,16 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
   // the lane at position (lane & 15) of its column's 16-dword run slices the pair that the rotation puts there, so
   // that a wave's 64 dwords of a pair row are simply base + 4 * lane: ds_write_addtid_b32
   const int g2 = ((lane & 15) - 4 * ((c >> 1) & 3)) & 15;
-  const int64_t cc = c < a.C ? c : 0;  // columns >= C re-read column 0: their sums are never flushed
+  const int cq = c % CP;               // observable column of this slot
+  const int jq = wave * 4 / CP;        // power offset of this slot: c / CP, the same for the whole wave
+  const int64_t cc = cq < a.C ? cq : 0;  // columns >= C re-read column 0: their sums are never flushed
   const uint32_t poff = (uint32_t)(c * 64 + ((g2 + 4 * ((c >> 1) & 3)) & 15) * 4);
   const uint32_t foff = (uint32_t)(FRAG0 + c * 32 + g2 * 2);
   // u-row role (lanes of column slot 0): wave jj < 4 slices the power J0 + jj; a fifth power goes to
   // wave 7 (fewest MFMAs), not to wave 4, which shares its SIMD with wave 0
+  // (PK > 1: the first wave of every power-offset group slices the u-row monomial jq + PK * jj in row set jj)
   const int jr = wave < 4 ? wave : 4;
-  const bool urow = jr < JN && (wave < 4 || wave == I8_WAVES - 1);  // wave-uniform
+  const bool urow = PK == 1 ? (jr < JN && (wave < 4 || wave == I8_WAVES - 1)) : (wave * 4 % CP == 0);  // wave-uniform
   // column slot k of the wave stores the digits 2k, 2k+1 of the u-row monomial (columns 8 jr + 2k, + 1)
   const uint32_t uoff = (uint32_t)(FRAG0 + (JN + (jr >> 2)) * I8_FRAG + ((jr & 3) * 8 + 2 * cslot) * 32 + g2 * 2);
   const uint32_t usel = (cslot & 1) ? 0x07030602u : 0x05010400u;   // which byte pair of the two source dwords
@@ -555,21 +565,29 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
     bool valid;
     if (urow_f >= 0) {
       const int n = urow_f * 32 + n32;
-      valid = (n & 7) < I8_NSL && (n >> 3) < JN;
+      valid = (n & 7) < I8_NSL && (n >> 3) < KL;
       jj = valid ? n >> 3 : 0;
       i = valid ? n & 7 : 0;
     } else {
       valid = n32 < a.C;
     }
-    const int j = J0 + jj;
-    double dsc = wt[I8_WT_DSP + j] * (urow_f >= 0 ? 0x1p-50 : wt[I8_WT_DSC + n32]);
+    int j = J0 + jj, col = n32;
+    if constexpr (PK > 1) {
+      if (urow_f < 0) {  // column slot n32 = (power offset, observable)
+        col = n32 % CP;
+        j = jj * PK + n32 / CP;
+        valid = col < a.C && j < K;
+        if (!valid) j = 0;
+      }
+    }
+    double dsc = wt[I8_WT_DSP + j] * (urow_f >= 0 ? 0x1p-50 : wt[I8_WT_DSC + col]);
     dsc *= (double)((int64_t)1 << (8 * i));
     const size_t part = (size_t)chunk * I8_NSL + i;
     double *base;
     int64_t stride;
     if (urow_f < 0) {
       // [chunk][digit][power][replicate][32 columns]: the lanes of a row write 256 contiguous bytes
-      base = a.part_x + ((part * K + j) * a.nrep_pad + rep0 + 32 * h + 4 * half) * I8_CPAD + n32 + opq;
+      base = a.part_x + ((part * K + j) * a.nrep_pad + rep0 + 32 * h + 4 * half) * I8_CPAD + col + opq;
       stride = I8_CPAD;
     } else {
       base = a.part_u + (part * a.nrep_pad + rep0 + 32 * h + 4 * half) * K + j + opq;
@@ -694,6 +712,17 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
       p[0] *= du[0];
       p[1] *= du[1];
     }
+    double dstep[2] = {du[0], du[1]};  // what a row set multiplies by: du, or du^PK with PK powers per observable
+    if constexpr (PK > 1) {
+      // this wave's slots start at the power jq (wave-uniform): p = w * du^jq
+      const double d2[2] = {du[0] * du[0], du[1] * du[1]};
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (jq & 1) p[e] *= du[e];
+        if (PK == 4 && (jq & 2)) p[e] *= d2[e];
+        dstep[e] = PK == 2 ? d2[e] : d2[e] * d2[e];
+      }
+    }
     constexpr int NIT = JN > 3 ? JN : 3;
     // M0 = LDS byte address of this wave's 256-byte run in pair row 0 of the buffer being filled (ds_write_addtid_b32:
     // address = M0 + offset + 4 * lane, no address register, half the LDS-path cycles of ds_write_b32)
@@ -736,8 +765,8 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
       __builtin_amdgcn_sched_barrier(0);
       if (do_slice) {
         if (jj > 0) {
-          p[0] *= du[0];
-          p[1] *= du[1];
+          p[0] *= dstep[0];
+          p[1] *= dstep[1];
         }
         i8_slice2(fma(p[0], dx[0], I8_MAGIC), fma(p[1], dx[1], I8_MAGIC), T);
         // (s_nop: one wait state between an SALU write of M0 and an add-TID LDS instruction; the assembler pads
@@ -753,7 +782,14 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
         *reinterpret_cast<uint16_t *>(lds + wf + jj * I8_FRAG) = (uint16_t)T[3];
         // u-row: p is w * du^(J0 + jj) right now; the wave that owns this power slices it (dx = 1)
         // into the columns 8 jj + i of the packed u-row fragments
-        if (jj == jr && urow) {  // wave-uniform
+        bool ur = jj == jr && urow;
+        uint32_t uo = uoff;
+        if constexpr (PK > 1) {  // row set jj holds the monomial jq + PK * jj of this wave's power offset
+          const int qm = jj * PK + jq;
+          ur = urow && qm < KL;
+          uo = (uint32_t)(FRAG0 + (JN + (qm >> 2)) * I8_FRAG + ((qm & 3) * 8 + 2 * cslot) * 32 + g2 * 2);
+        }
+        if (ur) {  // wave-uniform
           // all four column slots of the wave hold this sample pair's p (it does not depend on the column), so
           // slot k cuts and stores the digits 2k and 2k+1 only: 2 stores per wave instead of 7 by a quarter of it.
           // (slot 3's second halfword is the exponent byte pair: it lands in the unused column 8 jj + 7.)
@@ -762,8 +798,8 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
           const uint32_t s0 = cslot < 2 ? (uint32_t)b0 : (uint32_t)(b0 >> 32);
           const uint32_t s1 = cslot < 2 ? (uint32_t)b1 : (uint32_t)(b1 >> 32);
           const uint32_t t = __builtin_amdgcn_perm(s1, s0, usel) ^ uxor;
-          *reinterpret_cast<uint16_t *>(bnxt + uoff) = (uint16_t)t;
-          *reinterpret_cast<uint16_t *>(bnxt + uoff + 32) = (uint16_t)(t >> 16);
+          *reinterpret_cast<uint16_t *>(bnxt + uo) = (uint16_t)t;
+          *reinterpret_cast<uint16_t *>(bnxt + uo + 32) = (uint16_t)(t >> 16);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -986,11 +1022,12 @@ bool i8_supported(int64_t N, int64_t C, int64_t nrep, int K) {
   return N >= SM_T && C >= 1 && C <= 64 * I8_CPAD && K >= 1 && K <= 8;  // C > 32: one launch per 32 columns
 }
 
-template <int K, int J0, int JN>
+template <int K, int J0, int JN, int PK = 1>
 static int launch_pass(const I8Args &a, bool weighted, size_t prog_bytes, hipStream_t st) {
   if (a.progress != nullptr) TXM_HIP(hipMemsetAsync(a.progress, 0, prog_bytes, st));  // every pass starts from "not started"
   const dim3 grid((unsigned)(a.n_chunks * a.n_rbg)), block(I8_BLOCK);
-  constexpr int buf = 3 * JN * 2048 + (JN + (8 * JN + 31) / 32) * I8_FRAG;  // pair rows + plain fragments
+  constexpr int kl = PK == 1 ? JN : (K < JN * PK ? K : JN * PK);             // u-row monomials of the launch
+  constexpr int buf = 3 * JN * 2048 + (JN + (8 * kl + 31) / 32) * I8_FRAG;  // pair rows + plain fragments
   constexpr int nb = JN <= 2 ? 2 : 1;  // chunks per B buffer (two k-steps per barrier with one or two powers)
   const size_t lds = (size_t)I8_CNT_BYTES + 2u * nb * (size_t)buf + 2u * I8_REPS * sizeof(uint32_t) +
                      2u * SM_T * sizeof(double);  // + window draws, parked counts; two u tiles, or one u + one w
@@ -998,17 +1035,26 @@ static int launch_pass(const I8Args &a, bool weighted, size_t prog_bytes, hipStr
   static bool lds_set[2] = {false, false};
   if (!lds_set[weighted ? 1 : 0]) {
     if (weighted)
-      TXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_i8_kernel<K, J0, JN, true>),
+      TXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_i8_kernel<K, J0, JN, true, PK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     else
-      TXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_i8_kernel<K, J0, JN, false>),
+      TXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_i8_kernel<K, J0, JN, false, PK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     lds_set[weighted ? 1 : 0] = true;
   }
-  if (weighted) hipLaunchKernelGGL((resample_i8_kernel<K, J0, JN, true>), grid, block, lds, st, a);
-  else hipLaunchKernelGGL((resample_i8_kernel<K, J0, JN, false>), grid, block, lds, st, a);
+  if (weighted) hipLaunchKernelGGL((resample_i8_kernel<K, J0, JN, true, PK>), grid, block, lds, st, a);
+  else hipLaunchKernelGGL((resample_i8_kernel<K, J0, JN, false, PK>), grid, block, lds, st, a);
   TXM_LAUNCH_CHECK();
   return TXM_OK;
+}
+
+// TXM_I8_PACK=0 keeps one power per column for narrow states too (A/B measurements)
+static bool pack_i8_on() {
+  static const bool on = [] {
+    const char *e = getenv("TXM_I8_PACK");
+    return !(e && e[0] == '0');
+  }();
+  return on;
 }
 
 int launch_resample_i8(const I8Args &a, int K, bool weighted, size_t prog_bytes, hipStream_t st) {
@@ -1033,6 +1079,20 @@ int launch_resample_i8(const I8Args &a, int K, bool weighted, size_t prog_bytes,
                      a.n_list);
   TXM_LAUNCH_CHECK();
   int rc = TXM_OK;
+  // narrow state: four powers per observable column (two row sets at most).  Not for the narrow tail group of a wide
+  // state: its u-row sums would round differently from the other groups' (the monomials are formed in another order)
+  if (a.C <= 8 && a.col0 == 0 && K >= 2 && pack_i8_on()) {
+    switch (K) {
+      case 2: return launch_pass<2, 0, 1, 4>(a, weighted, prog_bytes, st);
+      case 3: return launch_pass<3, 0, 1, 4>(a, weighted, prog_bytes, st);
+      case 4: return launch_pass<4, 0, 1, 4>(a, weighted, prog_bytes, st);
+      case 5: return launch_pass<5, 0, 2, 4>(a, weighted, prog_bytes, st);
+      case 6: return launch_pass<6, 0, 2, 4>(a, weighted, prog_bytes, st);
+      case 7: return launch_pass<7, 0, 2, 4>(a, weighted, prog_bytes, st);
+      case 8: return launch_pass<8, 0, 2, 4>(a, weighted, prog_bytes, st);
+      default: break;
+    }
+  }
   switch (K) {
     case 1: rc = launch_pass<1, 0, 1>(a, weighted, prog_bytes, st); break;
     case 2: rc = launch_pass<2, 0, 2>(a, weighted, prog_bytes, st); break;
