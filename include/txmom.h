@@ -155,7 +155,9 @@ int txm_sampler_freq(const txm_sampler_spec *spec_host, const uint32_t *counts, 
  *                  split into seven signed 8-bit digits and accumulated exactly in int32
  *                  (order 0..7; 32 columns per launch, orders above 4 in two passes over
  *                  the sampler stream; taken when every 32-column group holds more than 16 columns and
- *                  nrep >= 64 (order >= 3), 128 (orders 1, 2) or 384 (order 0)).
+ *                  nrep >= 64 (order >= 3), 128 (orders 1, 2) or 384 (order 0); states with C <= 8
+ *                  (C <= 16) observables carry four (two) powers per column and take it from order 2
+ *                  and 128 (64) replicates on).
  *                  PRECISION GUARD (data dependent, automatic): the pre-pass also takes, per window, a robust
  *                  typical magnitude of the top-power monomial (the smallest of 64 group means of
  *                  |w du^order dx_c|); a window whose scale exceeds 275 sqrt(n) times it -- a heavy tail, an

@@ -83,6 +83,9 @@ def truth_err(orc, got, x, u, order, freq, reps, w=None, sc=None):
     (33000, 1, 7, 65, True),        # ... order 7, 1-D observable
     (20000, 8, 1, 64, False),       # ... order 1: one row set, two of four power slots used
     (20000, 6, 3, 130, True),       # ... order 3: exactly one row set
+    (40000, 16, 4, 70, False),      # 8 < C <= 16: two powers per observable column, three row sets
+    (30000, 12, 5, 64, True),       # ... order 5, weighted
+    (30000, 9, 7, 65, False),       # ... order 7: four row sets
 ])
 def test_i8_matches_fp64_on_same_stream(eng, orc, N, C, order, nrep, weighted):
     x, u = data(N, C, 5)
@@ -283,7 +286,8 @@ def test_dispatch_thresholds(eng):
         assert eng.resample_path(big, 8, 1000, 4) == "int8"       # narrow state: four powers per column
         assert eng.resample_path(big, 8, 100, 4) == "fp64"        # ... from 128 replicates
         assert eng.resample_path(big, 8, 1000, 1) == "fp64"       # ... from order 2
-        assert eng.resample_path(big, 12, 1000, 4) == "fp64"      # 8 < C <= 16: one 16-column FP64 block is cheaper
+        assert eng.resample_path(big, 12, 1000, 4) == "int8"      # 8 < C <= 16: two powers per column
+        assert eng.resample_path(big, 12, 1000, 1) == "fp64"      # ... from order 2
         assert eng.resample_path(big, 64, 1000, 4) == "int8"      # two column groups
         assert eng.resample_path(big, 40, 1000, 4) == "fp64"      # 8-column tail group
         assert eng.resample_path(big, 32, 1000, 8) == "fp64"      # order 8: FP64 only

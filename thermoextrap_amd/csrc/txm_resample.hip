@@ -708,6 +708,9 @@ static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   // FP64 kernel from 128 replicates on at order >= 2 (N = 1e7, nrep = 200, C = 8: 4.5 vs 4.75 ms at order 3, 4.9 vs
   // 6.1 at order 4, 6.2 vs 10.7 at order 6; N = 1e8: 40.6 vs 55.1 ms; C <= 4 or order <= 2: within 5 %).
   if (C <= 8) return K >= 3 && nrep >= 128 && N >= 262144;
+  // 8 < C <= 16: two powers per column against one 16-column FP64 block (N = 1e7, C = 16, nrep = 200: 4.9 vs 5.6 ms at
+  // order 2, 6.2 vs 8.1 at order 4, 6.5 vs 10.6 at order 6; nrep = 64: 2.9 vs 3.1; N = 1e8, nrep = 1000: 193 vs 298 ms)
+  if (C <= 16) return K >= 3 && nrep >= 64 && N >= 262144;
   const int64_t ctail = C % I8_CPAD;
   const int64_t min_rep = K >= 4 ? 64 : (K >= 2 ? 128 : 384);
   return C > 16 && (ctail == 0 || ctail > 16) && nrep >= min_rep && N >= 262144;

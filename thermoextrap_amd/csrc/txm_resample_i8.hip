@@ -1093,6 +1093,18 @@ int launch_resample_i8(const I8Args &a, int K, bool weighted, size_t prog_bytes,
       default: break;
     }
   }
+  if (a.C > 8 && a.C <= 16 && a.col0 == 0 && K >= 2 && pack_i8_on()) {  // two powers per observable column
+    switch (K) {
+      case 2: return launch_pass<2, 0, 1, 2>(a, weighted, prog_bytes, st);
+      case 3: return launch_pass<3, 0, 2, 2>(a, weighted, prog_bytes, st);
+      case 4: return launch_pass<4, 0, 2, 2>(a, weighted, prog_bytes, st);
+      case 5: return launch_pass<5, 0, 3, 2>(a, weighted, prog_bytes, st);
+      case 6: return launch_pass<6, 0, 3, 2>(a, weighted, prog_bytes, st);
+      case 7: return launch_pass<7, 0, 4, 2>(a, weighted, prog_bytes, st);
+      case 8: return launch_pass<8, 0, 4, 2>(a, weighted, prog_bytes, st);
+      default: break;
+    }
+  }
   switch (K) {
     case 1: rc = launch_pass<1, 0, 1>(a, weighted, prog_bytes, st); break;
     case 2: rc = launch_pass<2, 0, 2>(a, weighted, prog_bytes, st); break;

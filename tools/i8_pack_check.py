@@ -11,7 +11,7 @@ from thermoextrap_amd import engine as eng
 
 torch.manual_seed(0)
 worst = 0.0
-for C in (1, 3, 8):
+for C in (1, 3, 8, 9, 13, 16):
     for order in (1, 2, 3, 4, 5, 6, 7):
         for weighted in (False, True):
             N, nrep = 300_000 + 1024 * C + 77, 70
