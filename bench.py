@@ -377,11 +377,17 @@ def main():
     if path == "int8":
         # executed int8 operations: what the 8 waves of a workgroup issue per k-step (txm_resample_i8.hip: two
         # pair rows x 4 tiles + one plain fragment x 2 tiles per wave, minus the slots past the last row)
-        passes = {2: [2], 3: [3], 4: [4], 5: [5], 6: [3, 3], 7: [4, 3], 8: [4, 4]}[K]
-        n_mfma = 0  # v_mfma_i32_32x32x32_i8 issued per workgroup and k-step (32 samples x 64 replicates), all passes
-        for jn in passes:
-            npair, nfrg = 3 * jn, jn + -(-8 * jn // 32)
-            n_mfma += sum(4 * (2 * wv < npair) + 4 * (2 * wv + 1 < npair) + 2 * (wv < nfrg) for wv in range(8))
+        # passes as (row sets, u-row monomials): one power per column, five powers per pass (txm_resample_i8.hip:
+        # launch_resample_i8), or -- narrow states -- four (C <= 8) / two (C <= 16) powers per observable column
+        if C <= 16 and K >= 2:
+            pk = 4 if C <= 8 else 2
+            jn = -(-K // pk)
+            passes = [(jn, min(K, jn * pk))]
+        else:
+            passes = [(jn, jn) for jn in {1: [1], 2: [2], 3: [3], 4: [4], 5: [5], 6: [5, 1], 7: [5, 2], 8: [5, 3]}[K]]
+        # v_mfma_i32_32x32x32_i8 per workgroup and k-step (32 samples x 64 replicates), all passes: 4 tiles per pair
+        # row (two digits x two replicate halves), 2 per plain fragment (digit 6 of a row set, packed u-row columns)
+        n_mfma = sum(4 * 3 * jn + 2 * (jn + -(-8 * kl // 32)) for jn, kl in passes)
         ksteps = -(-nrep_rank // 64) * (-(-N // 1024) * 32) * -(-C // 32)   # replicate groups x k-steps x column groups
         i8_ops = 2.0 * 32 * 32 * 32 * n_mfma * ksteps
         tops = i8_ops / (t_boot * 1e-3) / 1e12
