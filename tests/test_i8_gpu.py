@@ -159,13 +159,15 @@ def test_i8_vs_oracle_truth(eng, orc):
     assert truth_err(orc, got, x, u, order, s.freq(), range(nrep)) < TOL
 
 
-def test_guard_sends_outlier_windows_to_fp64(eng, orc):
-    """A 1e4-sigma sample in u (and another in x): the windows holding them are scaled by the outlier, so
+@pytest.mark.parametrize("C", [32, 8, 12])
+def test_guard_sends_outlier_windows_to_fp64(eng, orc, C):
+    """(C = 8 and 12: the narrow-state variants with four / two powers per observable column.)
+    A 1e4-sigma sample in u (and another in x): the windows holding them are scaled by the outlier, so
     the ordinary samples around it would be rounded at ~their own size -- and the replicates that do NOT
     draw the outlier (37 %) consist of exactly those.  The guard hands these windows to the FP64 kernel:
     the result matches the FP64 kernel and the long-double truth at the usual bound, for replicates with
     and without the outlier, with the scale taken from the clean data."""
-    N, C, order, nrep = 150000, 32, 4, 64
+    N, order, nrep = 150000, 4, 64
     x, u = data(N, C, 33, heavy=True)
     xc, uc = data(N, C, 33, heavy=False)
     sc_clean = scale(xc, uc, order + 1)
