@@ -351,10 +351,23 @@ def main():
     t_red = timed(lambda: engine.reduce_vals(x, u, order), 10)
     path = info["path"]
     t_fp64 = None
+    parity = None
     if path == "int8" and not args.no_fp64_leg:
         with engine.forced_path("fp64"):
             engine.resample_vals(x, u, order, sampler=sampler, pivot=pivot, out=out)
             t_fp64 = timed(lambda: engine.resample_vals(x, u, order, sampler=sampler, pivot=pivot, out=out), 2)
+        # parity of what was timed (outside the timed region): the default dispatch against the FP64 kernel on the same
+        # sampler draw, every replicate and column, relative to each comoment's natural scale sigma_x^a sigma_u^b
+        got = engine.resample_vals(x, u, order, sampler=sampler, pivot=pivot)
+        sx, su = x[: 1 << 20].std(dim=0), u[: 1 << 20].std()
+        sc = torch.empty((C, 2, K), dtype=torch.float64, device="cuda")
+        for b in range(K):
+            sc[:, 0, b] = su**b
+            sc[:, 1, b] = sx * su**b
+        parity = {"max_scaled_abs_diff_vs_fp64_kernel": float(((got - out).abs() / (out.abs() + sc[None])).max()),
+                  "over": f"{nrep_rank} replicates x {C} columns x 2 x {K} comoments, same sampler draw",
+                  "tolerance_in_tests": 1e-12}
+        del got
 
     shape = (N, C, order, nrep_rank)
     alg_bytes = 8.0 * N * (C + 1)                         # samples read once
@@ -461,6 +474,8 @@ def main():
         }
         if roofline_fp64 is not None:
             rec["roofline_fp64_path"] = roofline_fp64
+        if parity is not None:
+            rec["parity_check"] = parity
         if t_dxdq is not None:
             rec["dxdq_bootstrap_ms"] = t_dxdq
         if world == 1 and not args.no_cpu_baseline:
