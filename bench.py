@@ -15,8 +15,9 @@ relays rank 0's JSON line; under torchrun (WORLD_SIZE set) it is a rank.
   --mode states   (default) every rank bootstraps its own state point (own data, own nrep replicates);
                   the replicate-state slabs are all-gathered at the end of the step.  "scaling": "weak",
                   value = ranks * N_samp / time.
-  --mode replicas every rank holds the same state point and bootstraps nrep / ranks replicates with its
-                  own seed (thermoextrap_amd.distributed.sharded_bootstrap); one all-gather.
+  --mode replicas every rank holds the same state point and bootstraps its contiguous nrep / ranks replicates of
+                  the ONE sampler stream (thermoextrap_amd.distributed.sharded_bootstrap: same seed, replicate
+                  offset per rank -- the gathered result is the one-GPU result bit for bit); one all-gather.
                   "scaling": "strong", value = N_samp / time.
 """
 
@@ -81,8 +82,10 @@ def dry_run(args):
     rank, world = txd.world()
     nrep = 8
 
-    def compute(n, seed):
-        return torch.full((n, 2, 2, 3), float(rank), dtype=torch.float64)
+    def compute(n, seed, rep0):
+        out = torch.full((n, 2, 2, 3), float(rank), dtype=torch.float64)
+        out[:, 1, 1, 1] = torch.arange(rep0, rep0 + n, dtype=torch.float64)  # the stream replicates of this slab
+        return out
 
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -94,6 +97,8 @@ def dry_run(args):
         dt = float(t.item())
     want = world * nrep if args.mode == "states" else nrep
     assert out.shape[0] == want, (out.shape, want)
+    # one stream for the whole job: the gathered slabs cover stream replicates 0 .. rows - 1 exactly once, in order
+    assert out[:, 1, 1, 1].tolist() == list(range(want)), out[:, 1, 1, 1].tolist()
     if rank == 0:
         print(json.dumps({"metric": "dry-run", "n_gpus": world, "steps": args.steps, "mode": args.mode,
                           "rows": int(out.shape[0]), "ranks_seen": sorted({int(v) for v in out[:, 0, 0, 0].tolist()})}), flush=True)
@@ -288,9 +293,10 @@ def main():
 
     from thermoextrap_amd import moments as cm
 
-    def one_bootstrap(n_rep, seed):
-        # one sampler object per step (the tile-count kernel runs here), shared by the moments and the callback's <dx/dq>
-        smp = cm.factory_sampler({"nrep": n_rep, "device": True, "seed": seed}, data=xv, dim="rec")
+    def one_bootstrap(n_rep, seed, rep0):
+        # one sampler object per step (the tile-count kernel runs here), shared by the moments and the callback's <dx/dq>;
+        # replicates rep0 .. rep0 + n_rep of the stream of `seed`: the gathered job equals one rank's result bit for bit
+        smp = cm.factory_sampler({"nrep": n_rep, "device": True, "seed": seed, "rep0": rep0}, data=xv, dim="rec")
         boot = xem.resample(sampler=smp)
         results["derivs"] = boot.derivs(norm=False)  # host labelled array (order+1, rep, val)
         if dxdq is not None:

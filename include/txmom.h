@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define TXM_ABI_VERSION 1
+#define TXM_ABI_VERSION 2 /* 2: txm_sampler_spec.rep0 */
 #define TXM_MAX_ORDER 8 /* K = order + 1 <= 9 */
 
 typedef enum txm_status {
@@ -96,9 +96,11 @@ int txm_reduce_vals_1d(const double *u, int64_t ldu_r, int64_t ldu_s, const doub
  *   reference: sampler built at data.py:1028-1037, 1344-1352, 1782-1789;
  *   tests/test_data.py:94-112 feeds explicit indices.
  * Returns TXM_ERR_INVALID if any index is outside [0, ndat) (checked on device,
- * reported after a stream sync). */
+ * reported after a stream sync).  ws: txm_indices_to_freq_ws_bytes() bytes; it holds the call's
+ * error word, so concurrent calls on different streams share no state. */
+size_t txm_indices_to_freq_ws_bytes(void);
 int txm_indices_to_freq(const int64_t *indices, int64_t nrep, int64_t nsamp, int64_t ndat,
-                        int64_t *freq, txm_stream stream);
+                        int64_t *freq, void *ws, size_t ws_bytes, txm_stream stream);
 
 /* Device multinomial sampler ("scale mode").  The reference draws
  *   indices = rng.choice(ndat, (nrep, ndat), replace=True)   
@@ -117,13 +119,19 @@ int txm_indices_to_freq(const int64_t *indices, int64_t nrep, int64_t nsamp, int
  */
 typedef struct txm_sampler_spec {
   uint64_t seed;
-  int64_t nrep;  /* replicates */
+  int64_t nrep;  /* replicates of this call */
   int64_t ndat;  /* samples being resampled */
   int64_t nsamp; /* draws per replicate; 0 means ndat */
+  int64_t rep0;  /* replicate r of this call draws STREAM replicate rep0 + r (rep0 + nrep <= 2^32).  The stream
+                    is keyed by (seed, stream replicate, tile) and a replicate's draws depend on nothing else, so
+                    the rows [a, b) of an (seed, nrep) table equal the (seed, b - a, rep0 = a) table bit for bit:
+                    a rank that owns replicates [a, b) -- or the states [s0, s1) of a collection whose state s owns
+                    replicates s * nrep ... -- reproduces its slab of the one-GPU result exactly (the reference
+                    runs those loops serially: models.py:614-641).  0 for a whole table. */
 } txm_sampler_spec;
 
 /* Per-(replicate, tile) draw counts, tile = 1024 consecutive samples.
- * counts: [nrep][txm_sampler_ntiles(ndat)] uint32.  ndat <= 2^30; the workspace
+ * counts: [nrep][txm_sampler_ntiles(ndat)] uint32.  ndat <= 2^30, nrep <= 2^24; the workspace
  * is no longer used (the tile tree lives in LDS) but the query still returns a
  * valid size and the arguments are accepted. */
 int64_t txm_sampler_ntiles(int64_t ndat);
@@ -164,24 +172,55 @@ int txm_sampler_freq(const txm_sampler_spec *spec_host, const uint32_t *counts, 
  *                  outlier, weights spanning decades: the rounding would no longer stay within 1e-13 of what
  *                  the window contributes -- is contracted by the FP64 kernel instead, in the same call, and
  *                  the two sets of partial sums are added.  Ordinary data flags nothing.
- * txm_resample_path reports the shape-based choice; txm_set_resample_path(TXM_PATH_FP64 / TXM_PATH_INT8)
- * forces one kernel wherever it applies, -1 restores the automatic choice (initial value: the
- * environment variable TXM_I8=0 / TXM_I8=1, read once).  txm_resample_vals_info reads back, from the
- * workspace of the LAST txm_resample_vals call of that shape, info_host[0] = path taken, [1] = scaling
- * windows x column groups, [2] = how many of them the guard sent to the FP64 kernel (synchronises).
+ * txm_resample_path reports the shape-based choice.  The kernel of ONE CALL is chosen by txm_resample_opts.path
+ * (TXM_PATH_AUTO = that rule); txm_set_resample_path is a process-wide default for TXM_PATH_AUTO calls kept for tests
+ * and A/B timing (initial value: the environment variable TXM_I8=0 / TXM_I8=1, read once) -- calls that pass a path
+ * share no mutable state and are re-entrant per (workspace, stream).
+ *
+ * txm_resample_opts (HOST struct, NULL = all defaults):
+ *   path        TXM_PATH_AUTO / TXM_PATH_FP64 / TXM_PATH_INT8 for this call.
+ *   info        DEVICE pointer to 4 int64 (nullable), written on the stream, no synchronisation:
+ *               [0] path taken, [1] scaling windows x column groups, [2] how many of them the precision guard sent
+ *               to the FP64 kernel, [3] 1 when the pre-pass tables came from `prep` (below) instead of being computed.
+ *   prep, prep_bytes, prep_valid
+ *               The int8 path's pre-pass (pivot + per-window scale table, guard flags and fallback list) depends on
+ *               (x, u, w, pivot, N, C, nrep, order) only -- not on the sampler -- and costs one more read of the samples.
+ *               A caller that bootstraps the SAME data repeatedly (the reference caches per data object: data.py:285,
+ *               844-942) passes a device buffer of txm_resample_prep_bytes() that it keeps next to the data: a call with
+ *               prep_valid == 0 computes the tables into it, later calls with prep_valid == 1 reuse them (one HBM pass
+ *               and three launches fewer).  The caller invalidates by passing 0 again; the library keeps no state.
+ *   y, ldy_s, out_y
+ *               optional second sample matrix y[N][C] (row pitch ldy_s) resampled with the SAME replicate weights:
+ *               out_y[nrep][C] = sum_i f_ri w_i y_ic / sum_i f_ri w_i   (the per-replicate mean; DEVICE pointers).
+ *               This is VolumeDataCallback's <dx/dq> over the bootstrap sample (reference volume.py:121-134,
+ *               dxdqv[sampler.indices].mean): carried by the same pass over the sampler stream instead of a
+ *               separate order-0 bootstrap.
+ * txm_resample_vals_info is the older synchronising read-back of [0..2] from the workspace of the last call.
  */
+#define TXM_PATH_AUTO (-1)
 #define TXM_PATH_FP64 0
 #define TXM_PATH_INT8 1
+typedef struct txm_resample_opts {
+  int32_t path;
+  int32_t prep_valid;
+  void *prep;
+  size_t prep_bytes;
+  int64_t *info;
+  const double *y;
+  int64_t ldy_s;
+  double *out_y;
+} txm_resample_opts;
 int txm_resample_path(int64_t N, int64_t C, int64_t nrep, int order);
 int txm_set_resample_path(int path);
 int txm_resample_vals_info(const void *ws, int64_t N, int64_t C, int64_t nrep, int order,
                            int64_t *info_host, txm_stream stream);
+size_t txm_resample_prep_bytes(int64_t N, int64_t C, int64_t nrep, int order);
 size_t txm_resample_vals_ws_bytes(int64_t N, int64_t C, int64_t nrep, int order);
 int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, const double *u,
                       const double *w, int64_t N, int64_t C, int order, int64_t nrep,
                       const int64_t *freq, const txm_sampler_spec *spec_host,
-                      const uint32_t *counts, const double *pivot, double *out, void *ws,
-                      size_t ws_bytes, txm_stream stream);
+                      const uint32_t *counts, const double *pivot, double *out,
+                      const txm_resample_opts *opts_host, void *ws, size_t ws_bytes, txm_stream stream);
 
 /* ---- (f-1) S state points of one shape in one set of launches ------------- */
 /* The reference handles a collection of states with a serial Python loop

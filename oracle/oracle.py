@@ -244,11 +244,12 @@ def sampler_ntiles(ndat):
     return int(lib().orc_sampler_ntiles(ndat))
 
 
-def sampler_tile_counts(seed, nrep, ndat, nsamp=0):
+def sampler_tile_counts(seed, nrep, ndat, nsamp=0, rep0=0):
+    """Row r = replicate rep0 + r of the stream (txm_sampler_spec.rep0)."""
     nt = sampler_ntiles(ndat)
     counts = np.zeros((nrep, nt), dtype=np.uint32)
-    rc = lib().orc_sampler_tile_counts(
-        ct.c_uint64(seed), ct.c_int64(nrep), ct.c_int64(ndat), ct.c_int64(nsamp),
+    rc = lib().orc_sampler_tile_counts_rep0(
+        ct.c_uint64(seed), ct.c_int64(nrep), ct.c_int64(ndat), ct.c_int64(nsamp), ct.c_int64(rep0),
         counts.ctypes.data_as(c_u32p),
     )
     if rc != 0:
@@ -256,12 +257,12 @@ def sampler_tile_counts(seed, nrep, ndat, nsamp=0):
     return counts
 
 
-def sampler_freq(seed, nrep, ndat, nsamp=0, counts=None):
+def sampler_freq(seed, nrep, ndat, nsamp=0, counts=None, rep0=0):
     if counts is None:
-        counts = sampler_tile_counts(seed, nrep, ndat, nsamp)
+        counts = sampler_tile_counts(seed, nrep, ndat, nsamp, rep0)
     freq = np.zeros((nrep, ndat), dtype=np.int64)
-    rc = lib().orc_sampler_freq(
-        ct.c_uint64(seed), ct.c_int64(nrep), ct.c_int64(ndat),
+    rc = lib().orc_sampler_freq_rep0(
+        ct.c_uint64(seed), ct.c_int64(nrep), ct.c_int64(ndat), ct.c_int64(rep0),
         counts.ctypes.data_as(c_u32p), _i(freq),
     )
     if rc != 0:

@@ -35,6 +35,9 @@
  *     ctr = (h, q >> 7, r, 1 + 256 * j)).  (The call index sits in the second counter word so that the
  *     first Philox rounds are partly the same for all calls of a node.)
  *     counts[r][t] = n(k, t).
+ *   Replicate offset (txm_sampler_spec.rep0): row r of a call's tables is replicate rep0 + r of the stream, i.e.
+ *     every `r` in a Philox counter above and below is rep0 + r.  A replicate's draws depend on (seed, stream
+ *     replicate, tile) only, so rows [a, b) of the (seed, nrep) tables equal the (seed, b - a, rep0 = a) tables.
  *   Per-sample counts (per replicate r, tile t), n = counts[r][t]:
  *     full tile: draw d uses field d % 12 of call c = d / 12 (three 10-bit
  *     fields per word: bits 0-9, 10-19, 20-29); ctr = (t, c, r, 3); the field
@@ -146,11 +149,11 @@ static uint32_t split_left(uint32_t k0, uint32_t k1, uint32_t h, uint32_t r, uin
   return left;
 }
 
-/* counts [nrep][ntiles] uint32 */
-int orc_sampler_tile_counts(uint64_t seed, int64_t nrep, int64_t ndat, int64_t nsamp,
-                            uint32_t *counts) {
+/* counts [nrep][ntiles] uint32; row r = stream replicate rep0 + r */
+int orc_sampler_tile_counts_rep0(uint64_t seed, int64_t nrep, int64_t ndat, int64_t nsamp, int64_t rep0,
+                                 uint32_t *counts) {
   sm_geom g;
-  if (ndat < 1 || nrep < 1 || sm_geometry(ndat, &g)) return -1;
+  if (ndat < 1 || nrep < 1 || rep0 < 0 || rep0 + nrep > ((int64_t)1 << 32) || sm_geometry(ndat, &g)) return -1;
   if (nsamp <= 0) nsamp = ndat;
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   const size_t P = (size_t)1 << g.k;
@@ -164,7 +167,7 @@ int orc_sampler_tile_counts(uint64_t seed, int64_t nrep, int64_t ndat, int64_t n
         const uint32_t n = cur[i];
         uint32_t left = 0;
         if (n > 0)
-          left = split_left(k0, k1, (uint32_t)(nn + i), (uint32_t)r, n, node_size(ndat, g.k, l + 1, 2 * i),
+          left = split_left(k0, k1, (uint32_t)(nn + i), (uint32_t)(rep0 + r), n, node_size(ndat, g.k, l + 1, 2 * i),
                             node_size(ndat, g.k, l + 1, 2 * i + 1));
         nxt[2 * i] = left;
         nxt[2 * i + 1] = n - left;
@@ -178,11 +181,15 @@ int orc_sampler_tile_counts(uint64_t seed, int64_t nrep, int64_t ndat, int64_t n
   return 0;
 }
 
-/* freq [nrep][ndat] int64 from counts (stage 3) */
-int orc_sampler_freq(uint64_t seed, int64_t nrep, int64_t ndat, const uint32_t *counts,
-                     int64_t *freq) {
+int orc_sampler_tile_counts(uint64_t seed, int64_t nrep, int64_t ndat, int64_t nsamp, uint32_t *counts) {
+  return orc_sampler_tile_counts_rep0(seed, nrep, ndat, nsamp, 0, counts);
+}
+
+/* freq [nrep][ndat] int64 from counts (stage 3); row r = stream replicate rep0 + r */
+int orc_sampler_freq_rep0(uint64_t seed, int64_t nrep, int64_t ndat, int64_t rep0, const uint32_t *counts,
+                          int64_t *freq) {
   sm_geom g;
-  if (ndat < 1 || nrep < 1 || sm_geometry(ndat, &g)) return -1;
+  if (ndat < 1 || nrep < 1 || rep0 < 0 || rep0 + nrep > ((int64_t)1 << 32) || sm_geometry(ndat, &g)) return -1;
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   memset(freq, 0, sizeof(int64_t) * (size_t)nrep * ndat);
   for (int64_t r = 0; r < nrep; ++r)
@@ -192,7 +199,7 @@ int orc_sampler_freq(uint64_t seed, int64_t nrep, int64_t ndat, const uint32_t *
       if (size_t_ == SM_T) {
         for (int64_t c = 0; c * 12 < n; ++c) {
           uint32_t o[4];
-          philox4x32_10((uint32_t)t, (uint32_t)c, (uint32_t)r, 3u, k0, k1, o);
+          philox4x32_10((uint32_t)t, (uint32_t)c, (uint32_t)(rep0 + r), 3u, k0, k1, o);
           const int64_t nd = (n - c * 12 < 12) ? n - c * 12 : 12;
           for (int64_t q = 0; q < nd; ++q)
             freq[r * ndat + t * SM_T + ((o[q / 3] >> (10 * (int)(q % 3))) & 1023u)]++;
@@ -203,7 +210,7 @@ int orc_sampler_freq(uint64_t seed, int64_t nrep, int64_t ndat, const uint32_t *
           uint32_t j = 0;
           while (quota > 0) {
             uint32_t o[4];
-            philox4x32_10(j++, (uint32_t)(t * 64 + lane), (uint32_t)r, 6u, k0, k1, o);
+            philox4x32_10(j++, (uint32_t)(t * 64 + lane), (uint32_t)(rep0 + r), 6u, k0, k1, o);
             for (int e = 0; e < 8 && quota > 0; ++e) {
               const int64_t off = slot16(o, e) & (SM_T - 1);
               if (off >= size_t_) continue;
@@ -215,4 +222,8 @@ int orc_sampler_freq(uint64_t seed, int64_t nrep, int64_t ndat, const uint32_t *
       }
     }
   return 0;
+}
+
+int orc_sampler_freq(uint64_t seed, int64_t nrep, int64_t ndat, const uint32_t *counts, int64_t *freq) {
+  return orc_sampler_freq_rep0(seed, nrep, ndat, 0, counts, freq);
 }

@@ -43,7 +43,53 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_abi_version(lib):
-    assert lib.txm_abi_version() == 1
+    from thermoextrap_amd import _lib
+
+    hdr = int(re.search(r"#define TXM_ABI_VERSION (\d+)", (ROOT / "include" / "txmom.h").read_text()).group(1))
+    assert lib.txm_abi_version() == hdr == _lib.ABI_VERSION == 2
+
+
+def test_struct_layouts_match_the_header():
+    """The ctypes mirrors of the header's host structs: field order, offsets and sizes (ABI 2: txm_sampler_spec.rep0,
+    txm_resample_opts)."""
+    from thermoextrap_amd import _lib
+
+    text = (ROOT / "include" / "txmom.h").read_text()
+
+    def fields(name):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), text, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        return [m.group(1) for m in re.finditer(r"(\w+);", body)]
+
+    assert fields("txm_sampler_spec") == [f[0] for f in _lib.SamplerSpec._fields_] == ["seed", "nrep", "ndat", "nsamp", "rep0"]
+    assert ct.sizeof(_lib.SamplerSpec) == 40 and _lib.SamplerSpec.rep0.offset == 32
+    assert fields("txm_resample_opts") == [f[0] for f in _lib.ResampleOpts._fields_]
+    assert ct.sizeof(_lib.ResampleOpts) == 56 and _lib.ResampleOpts.prep.offset == 8 and _lib.ResampleOpts.out_y.offset == 48
+    assert fields("txm_state_ptrs") == [f[0] for f in _lib.StatePtrs._fields_]
+
+
+def test_per_call_entry_points_validate_without_a_device(lib):
+    """ABI 2 additions: the replicate offset is range-checked on the host, the index histogram takes its error
+    word in caller scratch, the prep-block size is pure host logic."""
+    from thermoextrap_amd import _lib
+
+    sp = _lib.SamplerSpec(seed=1, nrep=4, ndat=5000, nsamp=0, rep0=0)
+    assert lib.txm_sampler_counts_ws_bytes(ct.byref(sp)) > 0
+    sp.rep0 = 2**32 - 4
+    assert lib.txm_sampler_counts_ws_bytes(ct.byref(sp)) > 0
+    sp.rep0 = 2**32 - 3                                    # stream replicates would pass 2^32
+    assert lib.txm_sampler_counts_ws_bytes(ct.byref(sp)) == 0 and b"2^32" in lib.txm_last_error()
+    sp.rep0 = -1
+    assert lib.txm_sampler_counts_ws_bytes(ct.byref(sp)) == 0
+    sp.rep0, sp.nrep = 0, 1 << 20                          # many replicates: no 65535 limit any more
+    assert lib.txm_sampler_counts_ws_bytes(ct.byref(sp)) > 0
+    assert lib.txm_indices_to_freq_ws_bytes() >= 4
+    assert lib.txm_indices_to_freq(None, 1, 1, 1, None, None, 0, None) == -1
+    p_small = lib.txm_resample_prep_bytes(1_000_000, 32, 1000, 4)
+    p_wide = lib.txm_resample_prep_bytes(1_000_000, 64, 1000, 4)
+    assert 0 < p_small < p_wide                           # one table set per 32-column group
+    assert lib.txm_resample_prep_bytes(0, 32, 1000, 4) == 0
+    assert lib.txm_resample_vals_ws_bytes(1_000_000, 32, 1000, 4) > p_small
 
 
 def test_no_gpu_means_loud_failure_not_fallback(lib):

@@ -21,34 +21,84 @@ WORKER = textwrap.dedent(
     dist.init_process_group("gloo")
     rank, w = D.world()
     assert w == 2
-    # replicate-sharded bootstrap: nrep = 7 -> shares (4, 3); slab content encodes (rank, seed, local index)
-    seeds = D.replicate_seeds(123, w)
-    assert len(set(seeds)) == w
-    def compute(n, seed):
-        assert seed == seeds[rank]
+    # replicate-sharded bootstrap: nrep = 7 -> shares (4, 3); slab content encodes (rank, local index, stream replicate)
+    assert D.replicate_offsets(7, w) == [0, 4]
+    def compute(n, seed, rep0):
+        assert seed == 123 and rep0 == (0, 4)[rank]          # ONE stream, contiguous replicate ranges
         out = torch.zeros((n, 3, 2, 5), dtype=torch.float64)
         out += rank * 100
         out[:, 0, 0, 0] += torch.arange(n, dtype=torch.float64)
+        out[:, 2, 1, 4] = torch.arange(rep0, rep0 + n, dtype=torch.float64)
         return out
     full = D.sharded_bootstrap(compute, nrep=7, seed=123)
     assert full.shape == (7, 3, 2, 5)
     want = torch.tensor([0, 1, 2, 3, 100, 101, 102], dtype=torch.float64)
     assert torch.equal(full[:, 0, 0, 0], want), full[:, 0, 0, 0]
+    assert full[:, 2, 1, 4].tolist() == [0, 1, 2, 3, 4, 5, 6]    # stream replicates 0..6, each exactly once, in order
     assert torch.equal(full[:4, 1], torch.zeros(4, 2, 5, dtype=torch.float64))
     assert torch.equal(full[4:, 1], torch.full((3, 2, 5), 100.0, dtype=torch.float64))
     # the step function bench.py runs, both modes (stand-in compute)
-    def compute2(n, seed):
+    def compute2(n, seed, rep0):
         out = torch.full((n, 2, 2, 3), float(seed % 1000), dtype=torch.float64)
         out[:, 0, 0, 0] = torch.arange(n, dtype=torch.float64) + 1000 * rank
+        out[:, 1, 0, 2] = torch.arange(rep0, rep0 + n, dtype=torch.float64)
         return out
     st = D.run_step("states", compute2, 5, 40)
     assert st.shape == (10, 2, 2, 3)
     assert st[:, 0, 0, 0].tolist() == [0, 1, 2, 3, 4, 1000, 1001, 1002, 1003, 1004]
-    assert st[:5, 1, 1, 1].eq(40.0).all() and st[5:, 1, 1, 1].eq(41.0).all()      # seed + rank
+    assert st[:, 1, 1, 1].eq(40.0).all()                          # one seed for the whole job
+    assert st[:, 1, 0, 2].tolist() == list(range(10))             # state r owns stream replicates r * nrep ...
     rp = D.run_step("replicas", compute2, 5, 40)
     assert rp.shape == (5, 2, 2, 3) and rp[:, 0, 0, 0].tolist() == [0, 1, 2, 1000, 1001]
-    sd = D.replicate_seeds(40, w)
-    assert rp[0, 1, 1, 1] == float(sd[0] % 1000) and rp[4, 1, 1, 1] == float(sd[1] % 1000)
+    assert rp[:, 1, 1, 1].eq(40.0).all() and rp[:, 1, 0, 2].tolist() == [0, 1, 2, 3, 4]
+    assert D.broadcast_int(77 + rank) == 77
+    # StateCollection.resample(sharded=True): the method itself, with a stand-in for the GPU bootstrap of a rank's
+    # sub-collection (the real one is held against the unsharded call on the GPU in tests/test_batched_gpu.py)
+    import numpy as np
+    from thermoextrap_amd import models as M
+    class FakeDX:
+        def __init__(self, t): self.device_values = t; self.dims = ("rep", "val", "xmom", "umom")
+    class FakeData:
+        rec_dim = "rep"; meta = None
+        def __init__(self, dx=None): self.dxduave = dx
+        def new_like(self, **kw): return FakeData(kw.get("dxduave"))
+    class FakeState:
+        order = 1; alpha0 = 0.0; derivatives = None; minus_log = False; alpha_name = "beta"
+        def __init__(self, i, data=None): self.i = i; self.data = data or FakeData()
+        def new_like(self, **kw): return FakeState(self.i, kw.get("data"))
+    class FakeColl(M.StateCollection):
+        calls = []
+        def _batch_eligible(self): return None
+        def resample(self, sampler, batched=None, **kws):
+            if kws.get("sharded"):
+                return super().resample(sampler, batched=batched, **kws)
+            # what _resample_batched / the serial loop do with (spec, state0): state s draws replicates (state0 + s) * nrep ...
+            state0, nrep = kws.pop("state0", 0), sampler["nrep"]
+            FakeColl.calls.append((sampler["seed"], sampler.get("device"), state0, len(self)))
+            sts = []
+            for s, st in enumerate(self.states):
+                t = torch.zeros((nrep, 2, 2, 2), dtype=torch.float64)
+                t[:, 0, 0, 0] = torch.arange(nrep, dtype=torch.float64) + (state0 + s) * nrep
+                t[:, 1, 1, 1] = float(sampler["seed"])
+                sts.append(FakeState(st.i, FakeData(FakeDX(t))))
+            return FakeColl(states=tuple(sts), kws=self.kws)
+    import thermoextrap_amd.moments as cm
+    cm.CentralMomentsData = lambda t, mom_ndim, dims: FakeDX(t)
+    coll = FakeColl(states=tuple(FakeState(i) for i in range(5)))
+    out = coll.resample({"nrep": 3, "seed": 999}, sharded=True)
+    assert FakeColl.calls == [(999, True, (0, 3)[rank], (3, 2)[rank])], FakeColl.calls
+    got = torch.stack([st.data.dxduave.device_values[:, 0, 0, 0] for st in out.states]).reshape(-1)
+    assert got.tolist() == list(range(15))                         # == the unsharded replicate ranges, in order
+    FakeColl.calls.clear()
+    out2 = coll.resample({"nrep": 3}, sharded=True)                # no seed: rank 0 draws one, every rank uses it
+    seeds = {float(st.data.dxduave.device_values[0, 1, 1, 1]) for st in out2.states}
+    assert len(seeds) == 1
+    for bad in ({"nrep": 3, "device": False}, np.zeros((3, 4), dtype=np.int64)):
+        try:
+            coll.resample(bad, sharded=True)
+            raise SystemExit("sharded resample accepted a sampler it cannot split consistently")
+        except ValueError:
+            pass
     # state sharding: 5 states over 2 ranks, results come back in order on every rank
     states = list(range(5))
     outs = D.sharded_states(states, lambda s: torch.full((2, 2), float(s * s)))

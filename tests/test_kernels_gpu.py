@@ -234,7 +234,7 @@ def test_device_sampler_matches_committed_stream_vectors(eng):
 
     g = json.load(open(Path(__file__).parent / "golden" / "sampler_stream_v2.json"))
     for c in g["cases"]:
-        s = eng.DeviceSampler(c["seed"], c["nrep"], c["ndat"], nsamp=c["nsamp"])
+        s = eng.DeviceSampler(c["seed"], c["nrep"], c["ndat"], nsamp=c["nsamp"], rep0=c.get("rep0", 0))
         assert s.counts.cpu().numpy().view(np.uint32).tolist() == c["counts"]
         f = s.freq().cpu().numpy()
         assert f[:, :48].tolist() == c["freq_head"]

@@ -240,9 +240,18 @@ def test_sampler_stream_v2_golden(orc):
     g = json.load(open(Path(__file__).parent / "golden" / "sampler_stream_v2.json"))
     assert g["stream_version"] == 2
     for c in g["cases"]:
-        counts = orc.sampler_tile_counts(c["seed"], c["nrep"], c["ndat"], c["nsamp"])
+        r0 = c.get("rep0", 0)
+        counts = orc.sampler_tile_counts(c["seed"], c["nrep"], c["ndat"], c["nsamp"], rep0=r0)
         assert counts.tolist() == c["counts"]
-        f = orc.sampler_freq(c["seed"], c["nrep"], c["ndat"], c["nsamp"], counts=counts)
+        f = orc.sampler_freq(c["seed"], c["nrep"], c["ndat"], c["nsamp"], counts=counts, rep0=r0)
         assert f[:, :48].tolist() == c["freq_head"]
         w = np.arange(1, c["ndat"] + 1)
         assert [int((f[r] * w).sum()) for r in range(c["nrep"])] == c["freq_checksum"]
+    # the replicate offset (txm_sampler_spec.rep0): rows a..b of a table == the (b - a, rep0 = a) table
+    full_c = orc.sampler_tile_counts(2026, 7, 9001)
+    full_f = orc.sampler_freq(2026, 7, 9001, counts=full_c)
+    for a, b in ((0, 7), (2, 5), (6, 7)):
+        part_c = orc.sampler_tile_counts(2026, b - a, 9001, rep0=a)
+        assert np.array_equal(part_c, full_c[a:b])
+        assert np.array_equal(orc.sampler_freq(2026, b - a, 9001, counts=part_c, rep0=a), full_f[a:b])
+    assert not np.array_equal(orc.sampler_tile_counts(2026, 1, 9001, rep0=1), full_c[0:1])

@@ -15,9 +15,12 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libtxmom.so"
 SOURCES = ["txm_api.hip", "txm_reduce.hip", "txm_sampler.hip", "txm_small.hip", "txm_resample.hip", "txm_resample_i8.hip",
-           "txm_perturb.hip"]
+           "txm_resample_i8t.hip", "txm_perturb.hip"]
 HEADERS = ["txm_common.h", "txm_pivot.h", "txm_sampler.h", "txm_resample_i8.h", "../../include/txmom.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed"]
+# per-file flags.  txm_resample_i8t.hip: 11 int32 accumulator tiles (176 registers) per wave at two waves per SIMD only
+# fit when the 256 registers are ONE file -- MFMA accumulators in VGPRs, no AGPR split (see the file's header)
+EXTRA_FLAGS = {"txm_resample_i8t.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _hipcc() -> str:
@@ -43,7 +46,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
 
     def compile_one(src: str) -> Path:
         obj = objdir / (src.replace(".hip", ".o"))
-        cmd = [cc, *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+        cmd = [cc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -20,7 +20,15 @@ c_size = ct.c_size_t
 
 
 class SamplerSpec(ct.Structure):
-    _fields_ = [("seed", ct.c_uint64), ("nrep", c_i64), ("ndat", c_i64), ("nsamp", c_i64)]
+    _fields_ = [("seed", ct.c_uint64), ("nrep", c_i64), ("ndat", c_i64), ("nsamp", c_i64), ("rep0", c_i64)]
+
+
+class ResampleOpts(ct.Structure):
+    """txm_resample_opts (include/txmom.h): per-call kernel choice, device info words, the persistent pre-pass
+    block and the optional second sample matrix."""
+
+    _fields_ = [("path", ct.c_int32), ("prep_valid", ct.c_int32), ("prep", c_void_p), ("prep_bytes", c_size),
+                ("info", c_void_p), ("y", c_void_p), ("ldy_s", c_i64), ("out_y", c_void_p)]
 
 
 class StatePtrs(ct.Structure):
@@ -58,7 +66,8 @@ SIGNATURES = {
     "txm_reduce_vals_1d_ws_bytes": (c_size, [c_i64, c_i64, c_int]),
     "txm_reduce_vals_1d": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p,
                                    c_size, c_void_p]),
-    "txm_indices_to_freq": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_void_p]),
+    "txm_indices_to_freq_ws_bytes": (c_size, []),
+    "txm_indices_to_freq": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_size, c_void_p]),
     "txm_sampler_ntiles": (c_i64, [c_i64]),
     "txm_sampler_counts_ws_bytes": (c_size, [ct.POINTER(SamplerSpec)]),
     "txm_sampler_tile_counts": (c_int, [ct.POINTER(SamplerSpec), c_void_p, c_void_p, c_size, c_void_p]),
@@ -66,10 +75,11 @@ SIGNATURES = {
     "txm_resample_path": (c_int, [c_i64, c_i64, c_i64, c_int]),
     "txm_set_resample_path": (c_int, [c_int]),
     "txm_resample_vals_info": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_int, ct.POINTER(c_i64), c_void_p]),
+    "txm_resample_prep_bytes": (c_size, [c_i64, c_i64, c_i64, c_int]),
     "txm_resample_vals_ws_bytes": (c_size, [c_i64, c_i64, c_i64, c_int]),
     "txm_resample_vals": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_i64, c_i64, c_int, c_i64,
-                                  c_void_p, ct.POINTER(SamplerSpec), c_void_p, c_void_p, c_void_p, c_void_p,
-                                  c_size, c_void_p]),
+                                  c_void_p, ct.POINTER(SamplerSpec), c_void_p, c_void_p, c_void_p,
+                                  ct.POINTER(ResampleOpts), c_void_p, c_size, c_void_p]),
     "txm_reduce_vals_batched_ws_bytes": (c_size, [c_i64, c_i64, c_i64, c_int]),
     "txm_reduce_vals_batched": (c_int, [ct.POINTER(StatePtrs), c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p,
                                         c_size, c_void_p]),
@@ -89,6 +99,7 @@ SIGNATURES = {
                             c_i64, c_void_p, c_void_p, c_size, c_void_p]),
 }
 
+ABI_VERSION = 2  # include/txmom.h TXM_ABI_VERSION
 _lib = None
 _gpu_ready = False
 
@@ -120,8 +131,8 @@ def load(path: Path | None = None):
         fn = getattr(lib, name)  # AttributeError here == ABI drift: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.txm_abi_version() != 1:
-        raise TxmError(f"ABI version mismatch: library {lib.txm_abi_version()} vs binding 1")
+    if lib.txm_abi_version() != ABI_VERSION:
+        raise TxmError(f"ABI version mismatch: library {lib.txm_abi_version()} vs binding {ABI_VERSION}")
     _lib = lib
     return lib
 

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "../../include/txmom.h"
 
 #define TXM_MAXK (TXM_MAX_ORDER + 1)
@@ -40,6 +42,21 @@ static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; 
 
 // Number of CUs of the current device (cached by txm_init; 256 on MI355X).
 int num_cus();
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to (function, device): set it once per device the calling
+// process launches on (`mask` is the call site's static bit set of devices already served).
+#define TXM_SET_MAX_LDS(func, bytes)                                                                   \
+  do {                                                                                                 \
+    static std::atomic<uint64_t> lds_mask_{0};                                                         \
+    int dev_ = 0;                                                                                      \
+    TXM_HIP(hipGetDevice(&dev_));                                                                      \
+    const uint64_t bit_ = (uint64_t)1 << (dev_ & 63);                                                  \
+    if (!(lds_mask_.load(std::memory_order_relaxed) & bit_)) {                                         \
+      TXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(func),                                \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)));          \
+      lds_mask_.fetch_or(bit_, std::memory_order_relaxed);                                             \
+    }                                                                                                  \
+  } while (0)
 
 // ---- pivot-sum -> central moment shift (device + host) --------------------
 // S0[j] = sum w du^j, S1[j] = sum w dx du^j about the pivot (pu, px), j < K.

@@ -69,6 +69,7 @@ struct ResampleArgs {
   const int64_t *freq;      // parity mode
   const uint32_t *counts;   // scale mode: [nrep][ntiles]
   uint32_t k0, k1;          // philox key
+  uint32_t rep_base;        // replicate r of the call draws stream replicate rep_base + r (txm_sampler_spec.rep0)
   int64_t ntiles;
   uint32_t last_tile_size;
   const double *pivot;      // [1 + C]
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
   const uint32_t *CNT = a.counts;
   const int64_t *FREQ = a.freq;
   double *PX = a.part_x, *PU = a.part_u;
-  uint32_t rid0 = 0;
+  uint32_t rid0 = a.rep_base;
   if constexpr (MODE == RS_BATCHED) {
     const int64_t sidx = blockIdx.z;
     const txm_state_ptrs bs = a.batch[sidx];
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
     if (FREQ) FREQ += (size_t)sidx * a.nrep * a.N;
     PX += (size_t)sidx * a.n_chunks * a.nrep_pad * a.C_pad * K;
     PU += (size_t)sidx * a.n_chunks * a.nrep_pad * K;
-    rid0 = (uint32_t)(sidx * a.nrep);
+    rid0 += (uint32_t)(sidx * a.nrep);
   }
   constexpr bool listed = MODE == RS_LISTED;
   int64_t nruns = 1;
@@ -552,26 +553,34 @@ __global__ __launch_bounds__(256) void resample_finalize_kernel(
   for (int q = 0; q < 2 * K; ++q) o[q] = st[q];
 }
 
-// finalize of the int8 path: partial sums of the observables come as [chunk x digit][power][replicate][32
-// columns] (what the accumulator tiles write contiguously), the u-row sums as [chunk x digit][replicate][K]
+// finalize of the int8 path: one slot of partial sums per scaling window, [window][replicate][power][column][8 digit
+// slots] (u-row: [window][replicate][power][8]); windows in ascending order, digits in ascending order -- a fixed order
+// that does not depend on the launch geometry.  Windows the precision guard flagged hold nothing: they were contracted
+// by the FP64 kernel, whose sums are added behind (same pivot).
 template <int K>
 __global__ __launch_bounds__(256) void resample_finalize_i8_kernel(
-    const double *__restrict__ part_x, const double *__restrict__ part_u, int n_parts, int64_t nrep_pad,
-    int64_t nrep, int64_t C, const double *__restrict__ pivot, double *__restrict__ out, int64_t c_off,
-    int64_t C_total, const double *__restrict__ fb_x, const double *__restrict__ fb_u, int fb_chunks,
-    int64_t fb_cpad, const uint32_t *__restrict__ n_list) {
+    const double *__restrict__ part_x, const double *__restrict__ part_u, int64_t nwin,
+    const uint32_t *__restrict__ wflag, int64_t nrep_pad, int64_t nrep, int64_t C,
+    const double *__restrict__ pivot, double *__restrict__ out, int64_t c_off, int64_t C_total,
+    const double *__restrict__ fb_x, const double *__restrict__ fb_u, int fb_chunks, int64_t fb_cpad,
+    const uint32_t *__restrict__ n_list) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nrep * C) return;
   const int64_t r = e / C, c = e % C;
   double S0[K], S1[K];
 #pragma unroll
   for (int j = 0; j < K; ++j) S0[j] = S1[j] = 0.0;
-  for (int ch = 0; ch < n_parts; ++ch) {
-    const double *pu_ = part_u + ((size_t)ch * nrep_pad + r) * K;
+  for (int64_t w = 0; w < nwin; ++w) {
+    if (wflag[w] != 0u) continue;
+    const double *pu_ = part_u + ((size_t)w * nrep_pad + r) * K * 8;
+    const double *px_ = part_x + (((size_t)w * nrep_pad + r) * K * I8_CPAD + c) * 8;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      S0[j] += pu_[j];
-      S1[j] += part_x[(((size_t)ch * K + j) * nrep_pad + r) * I8_CPAD + c];
+      const double4 ua = *reinterpret_cast<const double4 *>(pu_ + j * 8), ub = *reinterpret_cast<const double4 *>(pu_ + j * 8 + 4);
+      const double4 xa = *reinterpret_cast<const double4 *>(px_ + (size_t)j * I8_CPAD * 8),
+                    xb = *reinterpret_cast<const double4 *>(px_ + (size_t)j * I8_CPAD * 8 + 4);
+      S0[j] += ((((((ua.x + ua.y) + ua.z) + ua.w) + ub.x) + ub.y) + ub.z);  // digit slots 0..6, ascending
+      S1[j] += ((((((xa.x + xa.y) + xa.z) + xa.w) + xb.x) + xb.y) + xb.z);
     }
   }
   // windows the precision guard handed to the FP64 kernel (same pivot: the sums simply add)
@@ -627,12 +636,15 @@ static ResamplePlan plan_resample(int64_t N, int64_t C, int64_t nrep, int K) {
 // int8-sliced path (txm_resample_i8.hip): 64 replicates x all columns per workgroup,
 // chunks of whole scaling windows, one workgroup per CU.
 struct I8Plan {
-  int n_rbg, n_chunks;
+  int n_rbg, n_chunks, ngroups;
   int64_t tiles_per_chunk, nrep_pad, ntiles, nwin, win_tiles;
-  size_t off_pivot, off_px, off_pu, off_wt, total;
-  // precision-guard fallback: window flags, run list, and the FP64 kernel's plan / partial sums for one column group
+  size_t off_px, off_pu, total;
+  // precision-guard fallback: the FP64 kernel's plan / partial sums for one column group
   int sub_tiles;
-  size_t off_flag, off_list, off_nlist, off_fbx, off_fbu, off_prog, prog_bytes, off_stats;
+  size_t off_fbx, off_fbu, off_prog, prog_bytes, off_stats, off_prep;
+  // the pre-pass block ("prep": what depends on the data and the shape, not on the sampler):
+  //   [pivot (1 + C)] then per 32-column group [window table | guard flags | fallback run list | n_list (256 B)]
+  size_t prep_wt, prep_flag, prep_list, prep_nlist, prep_group0, prep_group_stride, prep_total;
   ResamplePlan fb;
 };
 
@@ -641,33 +653,40 @@ static I8Plan plan_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   p.n_rbg = (int)cdiv(nrep, I8_REPS);
   p.nrep_pad = (int64_t)p.n_rbg * I8_REPS;
   p.ntiles = cdiv(N, SM_T);
-  // one workgroup per CU: chunks x replicate groups should fill the CUs once, not 1.1 times
+  p.ngroups = (int)cdiv(C, I8_CPAD);
+  // scaling window = the slot of the partial sums: 256 tiles (262144 samples) on long series, shorter on short ones.
+  // A function of N ALONE: the window decides the fixed-point scale of every monomial and the order of the final
+  // summation, so a replicate's bits must not depend on nrep / the chunking (txm_sampler_spec.rep0: replicate slabs of
+  // a multi-GPU run equal the one-GPU rows bit for bit).
+  p.win_tiles = I8_WIN_TILES;
+  while (p.win_tiles > 4 && p.ntiles < 256 * p.win_tiles) p.win_tiles /= 4;  // >= 256 windows where N allows
+  p.nwin = cdiv(p.ntiles, p.win_tiles);
+  // one workgroup per CU: chunks (whole windows) x replicate groups should fill the CUs once, not 1.1 times
   int64_t nc = (int64_t)num_cus() / p.n_rbg / 8 * 8;
   if (nc < 8) nc = 8;
-  // scaling window: 256 tiles (one flush of the int32 accumulators into the FP64 partial sums per window: the
-  // read-modify-write of the partials is 7 GB instead of 29 GB per launch at the north-star size), shorter
-  // while a chunk would hold fewer than eight of them (chunks are whole windows: that keeps the workgroups
-  // balanced to 1/8 on small N x many chunks)
-  p.win_tiles = I8_WIN_TILES;
-  while (p.win_tiles > 4 && cdiv(p.ntiles, p.win_tiles) < 8 * nc) p.win_tiles /= 4;
-  p.nwin = cdiv(p.ntiles, p.win_tiles);
+  if (nc > p.nwin) nc = cdiv(p.nwin, 8) * 8;
   p.tiles_per_chunk = cdiv(p.nwin, nc) * p.win_tiles;
   p.n_chunks = (int)(cdiv(cdiv(p.ntiles, p.tiles_per_chunk), 8) * 8);
-  p.off_pivot = 0;
-  p.off_px = align_up((size_t)(1 + C) * sizeof(double), 256);
-  p.off_pu = p.off_px + align_up((size_t)p.n_chunks * I8_NSL * p.nrep_pad * I8_CPAD * K * sizeof(double), 256);
-  p.off_wt = p.off_pu + align_up((size_t)p.n_chunks * I8_NSL * p.nrep_pad * K * sizeof(double), 256);
-  p.off_flag = p.off_wt + align_up((size_t)p.nwin * I8_WT_STRIDE * sizeof(double) + 2048, 256);  // + timing slots of debug builds
   p.sub_tiles = p.win_tiles < I8_SUB_TILES ? (int)p.win_tiles : I8_SUB_TILES;
-  p.off_list = p.off_flag + align_up((size_t)p.nwin * sizeof(uint32_t), 256);
-  p.off_nlist = p.off_list + align_up((size_t)p.nwin * (size_t)(p.win_tiles / p.sub_tiles) * sizeof(uint32_t), 256);
+  // prep block
+  p.prep_wt = 0;
+  p.prep_flag = p.prep_wt + align_up((size_t)p.nwin * I8_WT_STRIDE * sizeof(double) + 2048, 256);  // + timing slots of debug builds
+  p.prep_list = p.prep_flag + align_up((size_t)p.nwin * sizeof(uint32_t), 256);
+  p.prep_nlist = p.prep_list + align_up((size_t)p.nwin * (size_t)(p.win_tiles / p.sub_tiles) * sizeof(uint32_t), 256);
+  p.prep_group_stride = p.prep_nlist + 256;
+  p.prep_group0 = align_up((size_t)(1 + C) * sizeof(double), 256);
+  p.prep_total = p.prep_group0 + (size_t)p.ngroups * p.prep_group_stride;
+  // workspace
+  p.off_px = 0;
+  p.off_pu = p.off_px + align_up((size_t)p.nwin * p.nrep_pad * K * I8_CPAD * 8 * sizeof(double), 256);
   p.fb = plan_resample(N, C < I8_CPAD ? C : I8_CPAD, nrep, K);
-  p.off_fbx = p.off_nlist + 256;
+  p.off_fbx = p.off_pu + align_up((size_t)p.nwin * p.nrep_pad * K * 8 * sizeof(double), 256);
   p.off_fbu = p.off_fbx + align_up((size_t)p.fb.n_chunks * p.fb.nrep_pad * p.fb.C_pad * K * sizeof(double), 256);
   p.off_prog = p.off_fbu + align_up((size_t)p.fb.n_chunks * p.fb.nrep_pad * K * sizeof(double), 256);
   p.prog_bytes = (size_t)p.n_chunks * 64 * sizeof(uint32_t);
   p.off_stats = p.off_prog + align_up(p.prog_bytes, 256);
-  p.total = p.off_stats + align_up((size_t)cdiv(p.ntiles, p.win_tiles < 16 ? p.win_tiles : 16) * 100 * sizeof(double), 256);
+  p.off_prep = p.off_stats + align_up((size_t)cdiv(p.ntiles, p.win_tiles < 16 ? p.win_tiles : 16) * 100 * sizeof(double), 256);
+  p.total = p.off_prep + align_up(p.prep_total, 256);
   return p;
 }
 
@@ -694,9 +713,9 @@ static bool throttle_on() {
   return on != 0;
 }
 
-static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K) {
+static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K, int call_path = TXM_PATH_AUTO) {
   if (!i8_supported(N, C, nrep, K)) return false;
-  const int ov = path_override();
+  const int ov = call_path != TXM_PATH_AUTO ? call_path : path_override();
   if (ov == TXM_PATH_FP64) return false;
   if (ov == TXM_PATH_INT8) return true;
   // measured on MI355X (tools/i8_sweep.py, N = 1e7; tools/ab_order.py, N = 1e8): C <= 16 runs one 16-column FP64
@@ -726,6 +745,29 @@ extern "C" int txm_set_resample_path(int path) {
   return TXM_OK;
 }
 
+namespace txm {
+// info [4] on the device: path, windows x groups, windows the guard sent to the FP64 kernel, tables came from prep
+__global__ void i8_info_kernel(const unsigned char *prep_groups, size_t group_stride, size_t off_nlist, int ngroups,
+                               int64_t nwin, int from_prep, int64_t *info) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int64_t flagged = 0;
+    for (int g = 0; g < ngroups; ++g)
+      flagged += reinterpret_cast<const uint32_t *>(prep_groups + (size_t)g * group_stride + off_nlist)[1];
+    info[0] = TXM_PATH_INT8;
+    info[1] = nwin * ngroups;
+    info[2] = flagged;
+    info[3] = from_prep;
+  }
+}
+__global__ void fp64_info_kernel(int64_t *info) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    info[0] = TXM_PATH_FP64;
+    info[1] = info[2] = info[3] = 0;
+  }
+}
+}  // namespace txm
+using namespace txm;
+
 extern "C" int txm_resample_vals_info(const void *ws, int64_t N, int64_t C, int64_t nrep, int order,
                                       int64_t *info_host, txm_stream stream) {
   TXM_REQUIRE(ws && info_host, "resample_vals_info: null pointer");
@@ -734,18 +776,45 @@ extern "C" int txm_resample_vals_info(const void *ws, int64_t N, int64_t C, int6
   info_host[1] = info_host[2] = 0;
   if (!use_i8(N, C, nrep, order + 1)) return TXM_OK;
   const I8Plan q = plan_i8(N, C, nrep, order + 1);
-  uint32_t nl[2] = {0, 0};
-  TXM_HIP(hipMemcpyAsync(nl, (const char *)ws + q.off_nlist, sizeof(nl), hipMemcpyDeviceToHost, (hipStream_t)stream));
-  TXM_HIP(hipStreamSynchronize((hipStream_t)stream));
+  // the last call's info block sits at the head of the workspace's own prep region's n_list words; read them back
+  int64_t flagged = 0;
+  for (int g = 0; g < q.ngroups; ++g) {
+    uint32_t nl[2] = {0, 0};
+    TXM_HIP(hipMemcpyAsync(nl, (const char *)ws + q.off_prep + q.prep_group0 + (size_t)g * q.prep_group_stride + q.prep_nlist,
+                           sizeof(nl), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    TXM_HIP(hipStreamSynchronize((hipStream_t)stream));
+    flagged += nl[1];
+  }
   info_host[0] = TXM_PATH_INT8;
-  info_host[1] = q.nwin * cdiv(C, I8_CPAD);
-  info_host[2] = nl[1];
+  info_host[1] = q.nwin * q.ngroups;
+  info_host[2] = flagged;
   return TXM_OK;
 }
 
 extern "C" int txm_resample_path(int64_t N, int64_t C, int64_t nrep, int order) {
   if (N < 1 || C < 1 || nrep < 1 || order < 0 || order > TXM_MAX_ORDER) return TXM_PATH_FP64;
   return use_i8(N, C, nrep, order + 1) ? TXM_PATH_INT8 : TXM_PATH_FP64;
+}
+
+extern "C" size_t txm_resample_prep_bytes(int64_t N, int64_t C, int64_t nrep, int order) {
+  if (N < 1 || C < 1 || nrep < 1 || order < 0 || order > TXM_MAX_ORDER) return 0;
+  if (!i8_supported(N, C, nrep, order + 1)) return 256;
+  return plan_i8(N, C, nrep, order + 1).prep_total;
+}
+
+// the second sample matrix of txm_resample_opts (y -> per-replicate means) runs as an order-0 bootstrap of its own
+// behind the main call unless the kernel of the main call carries it: its states [nrep][C][2][1] and its own
+// workspace sit behind the main plan's
+static size_t y_main_bytes(int64_t N, int64_t C, int64_t nrep) {
+  size_t n = plan_resample(N, C, nrep, 1).total;
+  if (i8_supported(N, C, nrep, 1)) {
+    const size_t m = plan_i8(N, C, nrep, 1).total;
+    if (m > n) n = m;
+  }
+  return align_up(n, 256);
+}
+static size_t y_extra_bytes(int64_t N, int64_t C, int64_t nrep) {
+  return align_up((size_t)nrep * C * 2 * sizeof(double), 256) + y_main_bytes(N, C, nrep);
 }
 
 extern "C" size_t txm_resample_vals_ws_bytes(int64_t N, int64_t C, int64_t nrep, int order) {
@@ -755,7 +824,7 @@ extern "C" size_t txm_resample_vals_ws_bytes(int64_t N, int64_t C, int64_t nrep,
     const size_t m = plan_i8(N, C, nrep, order + 1).total;
     if (m > n) n = m;
   }
-  return n;
+  return align_up(n, 256) + y_extra_bytes(N, C, nrep);
 }
 
 #define TXM_K_SWITCH(K_, CALL)                          \
@@ -862,45 +931,58 @@ static int run_listed(const ResampleArgs &a, const ResamplePlan &p0, int K, bool
 }
 }  // namespace txm
 
-extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, const double *u,
-                                 const double *w, int64_t N, int64_t C, int order, int64_t nrep,
-                                 const int64_t *freq, const txm_sampler_spec *spec,
-                                 const uint32_t *counts, const double *pivot, double *out, void *ws,
-                                 size_t ws_bytes, txm_stream stream) {
-  TXM_REQUIRE(x && u && out && ws, "resample_vals: null pointer");
-  TXM_REQUIRE(N >= 1 && C >= 1 && nrep >= 1, "resample_vals: need N, C, nrep >= 1");
-  TXM_REQUIRE(order >= 0 && order <= TXM_MAX_ORDER, "resample_vals: order %d outside [0, %d]", order,
-              TXM_MAX_ORDER);
-  TXM_REQUIRE(ldx_c == 1 && ldx_s >= C, "resample_vals: x must be (rec, val) row-major (ldx_c == 1)");
+namespace txm {
+// y[N][C] -> the mean column of its order-0 replicate states
+__global__ void y_means_kernel(const double *__restrict__ st /*[n][2]*/, int64_t n, double *__restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) out[e] = st[2 * e + 1];
+}
+
+static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, const double *w, int64_t N, int64_t C,
+                              int order, int64_t nrep, const int64_t *freq, const txm_sampler_spec *spec,
+                              const uint32_t *counts, const double *pivot, double *out, int path, void *prep,
+                              size_t prep_bytes, bool prep_valid, int64_t *info, void *ws, size_t ws_bytes,
+                              hipStream_t st) {
   const bool explicit_ = freq != nullptr;
-  TXM_REQUIRE(explicit_ != (spec != nullptr && counts != nullptr),
-              "resample_vals: give either freq or (spec, counts)");
   const int K = order + 1;
-  if (!explicit_ && use_i8(N, C, nrep, K)) {
+  if (!explicit_ && use_i8(N, C, nrep, K, path)) {
     const I8Plan q = plan_i8(N, C, nrep, K);
     if (ws_bytes < q.total) {
       set_error("resample_vals: workspace too small (%zu < %zu)", ws_bytes, q.total);
       return TXM_ERR_WORKSPACE;
     }
     TXM_REQUIRE(spec->ndat == N && spec->nrep == nrep, "resample_vals: sampler spec does not match N/nrep");
-    hipStream_t st = (hipStream_t)stream;
-    double *piv = (double *)((char *)ws + q.off_pivot);
-    if (pivot) {
-      TXM_HIP(hipMemcpyAsync(piv, pivot, sizeof(double) * (size_t)(1 + C), hipMemcpyDeviceToDevice, st));
-    } else {
-      hipLaunchKernelGGL(pivot_kernel, dim3((unsigned)(1 + C)), dim3(256), 0, st, x, ldx_s, (int64_t)1,
-                         u, (int64_t)1, N, piv);
-      TXM_LAUNCH_CHECK();
+    TXM_REQUIRE(spec->rep0 >= 0 && spec->rep0 + nrep <= ((int64_t)1 << 32), "resample_vals: sampler rep0 out of range");
+    // the pre-pass block: the caller's persistent buffer (tables reused when prep_valid) or scratch in ws
+    unsigned char *pb = (unsigned char *)ws + q.off_prep;
+    bool have_tables = false;
+    if (prep != nullptr) {
+      if (prep_bytes < q.prep_total) {
+        set_error("resample_vals: prep buffer too small (%zu < %zu)", prep_bytes, q.prep_total);
+        return TXM_ERR_WORKSPACE;
+      }
+      pb = (unsigned char *)prep;
+      have_tables = prep_valid;
+    }
+    double *piv = (double *)pb;
+    if (!have_tables) {
+      if (pivot) {
+        TXM_HIP(hipMemcpyAsync(piv, pivot, sizeof(double) * (size_t)(1 + C), hipMemcpyDeviceToDevice, st));
+      } else {
+        hipLaunchKernelGGL(pivot_kernel, dim3((unsigned)(1 + C)), dim3(256), 0, st, x, ldx_s, (int64_t)1,
+                           u, (int64_t)1, N, piv);
+        TXM_LAUNCH_CHECK();
+      }
     }
     I8Args b;
-    b.x = x; b.ldx_s = ldx_s; b.u = u; b.w = w; b.N = N; b.nrep = nrep;
+    b.x = x; b.ldx_s = ldx_s; b.u = u; b.w = w; b.N = N; b.nrep = nrep; b.C_call = C;
     b.counts = counts;
     b.k0 = (uint32_t)spec->seed;
     b.k1 = (uint32_t)(spec->seed >> 32);
+    b.rep_base = (uint32_t)spec->rep0;
     b.ntiles = q.ntiles;
     b.last_tile_size = (uint32_t)(N - (q.ntiles - 1) * SM_T);
     b.pivot = piv;
-    b.wtab = (double *)((char *)ws + q.off_wt);
     b.stats = (double *)((char *)ws + q.off_stats);
     b.nwin = q.nwin;
     b.part_x = (double *)((char *)ws + q.off_px);
@@ -908,30 +990,36 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
     b.n_chunks = q.n_chunks; b.n_rbg = q.n_rbg; b.tiles_per_chunk = q.tiles_per_chunk;
     b.nrep_pad = q.nrep_pad;
     b.win_tiles = q.win_tiles;
-    b.wflag = (uint32_t *)((char *)ws + q.off_flag);
-    b.list = (uint32_t *)((char *)ws + q.off_list);
-    b.n_list = (uint32_t *)((char *)ws + q.off_nlist);
     b.sub_tiles = q.sub_tiles;
-    TXM_HIP(hipMemsetAsync(b.n_list, 0, 256, st));
     b.progress = (throttle_on() && q.n_rbg > 1) ? (uint32_t *)((char *)ws + q.off_prog) : nullptr;
     // the FP64 kernel in listed mode: contracts the windows the precision guard flags (none on ordinary data)
     ResampleArgs f;
     f.ldx_s = ldx_s; f.u = u; f.w = w; f.N = N; f.nrep = nrep;
     f.freq = nullptr; f.counts = counts;
-    f.k0 = b.k0; f.k1 = b.k1;
+    f.k0 = b.k0; f.k1 = b.k1; f.rep_base = b.rep_base;
     f.ntiles = q.ntiles; f.last_tile_size = b.last_tile_size;
     f.pivot = piv;
     f.part_x = (double *)((char *)ws + q.off_fbx);
     f.part_u = (double *)((char *)ws + q.off_fbu);
     f.n_chunks = q.fb.n_chunks; f.n_rbg = q.fb.n_rbg; f.tiles_per_chunk = q.fb.tiles_per_chunk;
     f.nrep_pad = q.fb.nrep_pad; f.C_pad = q.fb.C_pad;
-    f.list = b.list; f.n_list = b.n_list; f.sub_tiles = q.sub_tiles; f.batch = nullptr; f.progress = nullptr;
+    f.sub_tiles = q.sub_tiles; f.batch = nullptr; f.progress = nullptr;
     TXM_REQUIRE(q.fb.nrep_pad == q.nrep_pad, "resample_vals: replicate padding of the two kernels differs");
     // one launch (or two, orders 5-7) per group of 32 columns; the groups reuse the partial buffers
-    for (int64_t col0 = 0; col0 < C; col0 += I8_CPAD) {
+    int g = 0;
+    for (int64_t col0 = 0; col0 < C; col0 += I8_CPAD, ++g) {
+      unsigned char *pg = pb + q.prep_group0 + (size_t)g * q.prep_group_stride;
+      b.wtab = (double *)(pg + q.prep_wt);
+      b.wflag = (uint32_t *)(pg + q.prep_flag);
+      b.list = (uint32_t *)(pg + q.prep_list);
+      b.n_list = (uint32_t *)(pg + q.prep_nlist);
+      f.list = b.list; f.n_list = b.n_list;
       b.col0 = col0;
       b.C = C - col0 < I8_CPAD ? C - col0 : I8_CPAD;
-      TXM_HIP(hipMemsetAsync(b.part_x, 0, q.off_wt - q.off_px, st));
+      if (!have_tables) {
+        const int rc0 = launch_i8_prepass(b, K, st);
+        if (rc0 != TXM_OK) return rc0;
+      }
       const int rc = launch_resample_i8(b, K, w != nullptr, q.prog_bytes, st);
       if (rc != TXM_OK) return rc;
       f.x = x + col0; f.C = b.C; f.col_off = col0;
@@ -942,7 +1030,7 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
       const int64_t ne = nrep * b.C;
 #define TXM_I8_FIN(KK)                                                                                 \
   hipLaunchKernelGGL((resample_finalize_i8_kernel<KK>), dim3((unsigned)cdiv(ne, 256)), dim3(256), 0, st, \
-                     b.part_x, b.part_u, q.n_chunks * I8_NSL, q.nrep_pad, nrep, b.C, piv, out, col0, C,   \
+                     b.part_x, b.part_u, q.nwin, b.wflag, q.nrep_pad, nrep, b.C, piv, out, col0, C,        \
                      f.part_x, f.part_u, q.fb.n_chunks, q.fb.C_pad, b.n_list)
       switch (K) {
         case 1: TXM_I8_FIN(1); break;
@@ -957,7 +1045,19 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
 #undef TXM_I8_FIN
       TXM_LAUNCH_CHECK();
     }
+    // a reused prep block keeps its n_list words; a fresh one inside ws is what txm_resample_vals_info reads back
+    if (prep != nullptr)
+      TXM_HIP(hipMemcpyAsync((char *)ws + q.off_prep, pb, q.prep_total, hipMemcpyDeviceToDevice, st));
+    if (info != nullptr) {
+      hipLaunchKernelGGL(i8_info_kernel, dim3(1), dim3(64), 0, st, pb + q.prep_group0, q.prep_group_stride, q.prep_nlist,
+                         q.ngroups, q.nwin, have_tables ? 1 : 0, info);
+      TXM_LAUNCH_CHECK();
+    }
     return TXM_OK;
+  }
+  if (info != nullptr) {
+    hipLaunchKernelGGL(fp64_info_kernel, dim3(1), dim3(64), 0, st, info);
+    TXM_LAUNCH_CHECK();
   }
   const ResamplePlan p = plan_resample(N, C, nrep, K);
   if (ws_bytes < p.total) {
@@ -965,7 +1065,6 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
     return TXM_ERR_WORKSPACE;
   }
   TXM_REQUIRE((int64_t)p.n_chunks * p.n_rbg < ((int64_t)1 << 31), "resample_vals: grid too large");
-  hipStream_t st = (hipStream_t)stream;
   double *piv = (double *)((char *)ws + p.off_pivot);
   if (pivot) {
     TXM_HIP(hipMemcpyAsync(piv, pivot, sizeof(double) * (size_t)(1 + C), hipMemcpyDeviceToDevice, st));
@@ -978,12 +1077,15 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
   a.x = x; a.ldx_s = ldx_s; a.u = u; a.w = w; a.N = N; a.C = C; a.nrep = nrep;
   a.freq = freq; a.counts = counts;
   a.k0 = a.k1 = 0;
+  a.rep_base = 0;
   a.ntiles = p.ntiles;
   a.last_tile_size = (uint32_t)(N - (p.ntiles - 1) * SM_T);
   if (!explicit_) {
     TXM_REQUIRE(spec->ndat == N && spec->nrep == nrep, "resample_vals: sampler spec does not match N/nrep");
+    TXM_REQUIRE(spec->rep0 >= 0 && spec->rep0 + nrep <= ((int64_t)1 << 32), "resample_vals: sampler rep0 out of range");
     a.k0 = (uint32_t)spec->seed;
     a.k1 = (uint32_t)(spec->seed >> 32);
+    a.rep_base = (uint32_t)spec->rep0;
   }
   a.pivot = piv;
   a.part_x = (double *)((char *)ws + p.off_px);
@@ -997,6 +1099,49 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
     TXM_HIP(hipMemsetAsync(a.progress, 0, p.prog_bytes, st));
   }
   TXM_K_SWITCH(K, return run_resample<KK>(a, p, w != nullptr, explicit_, out, st));
+  return TXM_OK;
+}
+}  // namespace txm
+
+extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, const double *u,
+                                 const double *w, int64_t N, int64_t C, int order, int64_t nrep,
+                                 const int64_t *freq, const txm_sampler_spec *spec,
+                                 const uint32_t *counts, const double *pivot, double *out,
+                                 const txm_resample_opts *opts, void *ws, size_t ws_bytes, txm_stream stream) {
+  TXM_REQUIRE(x && u && out && ws, "resample_vals: null pointer");
+  TXM_REQUIRE(N >= 1 && C >= 1 && nrep >= 1, "resample_vals: need N, C, nrep >= 1");
+  TXM_REQUIRE(order >= 0 && order <= TXM_MAX_ORDER, "resample_vals: order %d outside [0, %d]", order,
+              TXM_MAX_ORDER);
+  TXM_REQUIRE(ldx_c == 1 && ldx_s >= C, "resample_vals: x must be (rec, val) row-major (ldx_c == 1)");
+  const bool explicit_ = freq != nullptr;
+  TXM_REQUIRE(explicit_ != (spec != nullptr && counts != nullptr),
+              "resample_vals: give either freq or (spec, counts)");
+  txm_resample_opts o;
+  o.path = TXM_PATH_AUTO; o.prep_valid = 0; o.prep = nullptr; o.prep_bytes = 0; o.info = nullptr;
+  o.y = nullptr; o.ldy_s = 0; o.out_y = nullptr;
+  if (opts) o = *opts;
+  TXM_REQUIRE(o.path == TXM_PATH_AUTO || o.path == TXM_PATH_FP64 || o.path == TXM_PATH_INT8,
+              "resample_vals: opts.path %d is not a path", (int)o.path);
+  TXM_REQUIRE((o.y == nullptr) == (o.out_y == nullptr), "resample_vals: opts.y and opts.out_y go together");
+  TXM_REQUIRE(o.y == nullptr || o.ldy_s >= C, "resample_vals: opts.ldy_s < C");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t main_bytes = txm_resample_vals_ws_bytes(N, C, nrep, order) - y_extra_bytes(N, C, nrep);
+  const size_t avail = ws_bytes < main_bytes ? ws_bytes : main_bytes;
+  int rc = resample_vals_impl(x, ldx_s, u, w, N, C, order, nrep, freq, spec, counts, pivot, out, o.path, o.prep,
+                              o.prep_bytes, o.prep_valid != 0, o.info, ws, avail, st);
+  if (rc != TXM_OK || o.y == nullptr) return rc;
+  // second sample matrix: an order-0 bootstrap on the same sampler draw, then its mean column
+  if (ws_bytes < main_bytes + y_extra_bytes(N, C, nrep)) {
+    set_error("resample_vals: workspace too small for opts.y (%zu < %zu)", ws_bytes, main_bytes + y_extra_bytes(N, C, nrep));
+    return TXM_ERR_WORKSPACE;
+  }
+  double *ystates = (double *)((char *)ws + main_bytes);
+  void *yws = (char *)ws + main_bytes + align_up((size_t)nrep * C * 2 * sizeof(double), 256);
+  rc = resample_vals_impl(o.y, o.ldy_s, u, w, N, C, 0, nrep, freq, spec, counts, nullptr, ystates, o.path, nullptr, 0,
+                          false, nullptr, yws, y_main_bytes(N, C, nrep), st);
+  if (rc != TXM_OK) return rc;
+  hipLaunchKernelGGL(y_means_kernel, dim3((unsigned)cdiv(nrep * C, 256)), dim3(256), 0, st, ystates, nrep * C, o.out_y);
+  TXM_LAUNCH_CHECK();
   return TXM_OK;
 }
 
@@ -1064,13 +1209,15 @@ extern "C" int txm_resample_vals_batched(const txm_state_ptrs *states_host, int6
   a.x = nullptr; a.ldx_s = ldx_s; a.u = nullptr; a.w = nullptr; a.N = N; a.C = C; a.nrep = nrep;
   a.freq = freq; a.counts = counts;
   a.k0 = a.k1 = 0;
+  a.rep_base = 0;
   a.ntiles = p.ntiles;
   a.last_tile_size = (uint32_t)(N - (p.ntiles - 1) * SM_T);
   if (!explicit_) {
     TXM_REQUIRE(spec->ndat == N && spec->nrep == S * nrep, "resample_vals_batched: the sampler must span S * nrep replicates of N samples");
-    TXM_REQUIRE(spec->nrep < ((int64_t)1 << 32), "resample_vals_batched: S * nrep too large");
+    TXM_REQUIRE(spec->rep0 >= 0 && spec->rep0 + spec->nrep <= ((int64_t)1 << 32), "resample_vals_batched: sampler replicates outside [0, 2^32)");
     a.k0 = (uint32_t)spec->seed;
     a.k1 = (uint32_t)(spec->seed >> 32);
+    a.rep_base = (uint32_t)spec->rep0;
   }
   a.pivot = piv;
   a.part_x = (double *)((char *)ws + b.off_px);

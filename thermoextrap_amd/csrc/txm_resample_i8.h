@@ -32,23 +32,28 @@ struct I8Args {
   const double *w;
   int64_t N, C, nrep;      // C <= 32: the columns col0 .. col0 + C - 1 of x (one column group per launch)
   int64_t col0;
+  int64_t C_call;          // all columns of the call (decides the kernel family: i8t_applicable)
   const uint32_t *counts;  // [nrep][ntiles]
   uint32_t k0, k1;
+  uint32_t rep_base;       // replicate r of the call draws stream replicate rep_base + r (txm_sampler_spec.rep0)
   int64_t ntiles;
   uint32_t last_tile_size;
   const double *pivot;     // [1 + all columns]: {pivot_u, pivot_x[...]}, indexed with col0
   double *wtab;            // [nwin][I8_WT_STRIDE]
   double *stats;           // [ceil(ntiles / min(16, win_tiles))][100] per-sub-block statistics of the pre-pass
   int64_t nwin;
-  double *part_x;          // [n_chunks][7 digits][K][nrep_pad][32]   (zeroed by the launcher)
-  double *part_u;          // [n_chunks][7 digits][nrep_pad][K]
+  // partial sums: ONE SLOT PER SCALING WINDOW, written once (no read-modify-write, no zeroing; the finalize kernel
+  // skips the windows the guard flagged and adds the rest in window order, so a replicate's sums do not depend on the
+  // launch geometry)
+  double *part_x;          // [nwin][nrep_pad][K][32 columns][8 digit slots]
+  double *part_u;          // [nwin][nrep_pad][K][8 digit slots]
   int n_chunks, n_rbg;
   int64_t tiles_per_chunk; // multiple of win_tiles
   int64_t win_tiles;       // sampler tiles per scaling window: 256, 64, 16 or 4
   int64_t nrep_pad;
   // precision guard: flag[w] != 0 -> window w is left to the FP64 kernel (run list built by i8_list_kernel)
   uint32_t *wflag;         // [nwin]
-  uint32_t *list;          // [nwin * (win_tiles / sub_tiles)] first tile of every run; n_list[0] = runs, n_list[1] += flagged windows
+  uint32_t *list;          // [nwin * (win_tiles / sub_tiles)] first tile of every run; n_list[0] = runs, n_list[1] = flagged windows
   uint32_t *n_list;
   int sub_tiles;           // tiles per run: min(I8_SUB_TILES, win_tiles)
   // L2-sharing hint (see ResampleArgs::progress in txm_resample.hip): the replicate groups of a chunk publish the
@@ -63,7 +68,12 @@ constexpr int I8_THROTTLE_SPINS = 48;
 
 // true when the int8 path can take this problem (device-sampler mode only)
 bool i8_supported(int64_t N, int64_t C, int64_t nrep, int K);
-// launches the window-scale pass and the bootstrap kernel; partial sums land in part_x/part_u
+// the pre-pass (window table, guard flags, fallback list) and the bootstrap kernel; partial sums land in part_x/part_u
+int launch_i8_prepass(const I8Args &a, int K, hipStream_t st);
 int launch_resample_i8(const I8Args &a, int K, bool weighted, size_t prog_bytes, hipStream_t st);
+// the same contraction with the B operands built by the LDS transposing read (txm_resample_i8t.hip): one power per
+// observable column, every order the int8 path serves
+int launch_resample_i8t(const I8Args &a, int K, bool weighted, size_t prog_bytes, hipStream_t st);
+bool i8t_applicable(const double *x, int64_t ldx_s, int64_t C);  // C = all columns of the call
 
 }  // namespace txm

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void i8_list_kernel(const uint32_t *__restrict
   }
   if (tid == 0) {
     n_list[0] = running * (uint32_t)per;
-    n_list[1] += running;  // over all column groups of a call (zeroed by the launcher)
+    n_list[1] = running;  // flagged windows of this column group
   }
 }
 
@@ -389,17 +389,18 @@ __device__ __forceinline__ void i8_fill_full(const I8Args &a, uint32_t *cnt, int
     const uint32_t na = (uint32_t)__builtin_amdgcn_readlane((int)wcnt, 2 * p);
     const uint32_t nb = (uint32_t)__builtin_amdgcn_readlane((int)wcnt, 2 * p + 1);
     const uint32_t la = rl0 + 2u * p, lb = la + 1u;
-    if (na >= 768u) i8_tile_calls<true>(cnt, a.k0, a.k1, (uint32_t)ra, (uint32_t)t, (uint32_t)lane, na, la);
-    else i8_tile_calls<false>(cnt, a.k0, a.k1, (uint32_t)ra, (uint32_t)t, (uint32_t)lane, na, la);
-    if (nb >= 768u) i8_tile_calls<true>(cnt, a.k0, a.k1, (uint32_t)rb, (uint32_t)t, (uint32_t)lane, nb, lb);
-    else i8_tile_calls<false>(cnt, a.k0, a.k1, (uint32_t)rb, (uint32_t)t, (uint32_t)lane, nb, lb);
+    const uint32_t sa = a.rep_base + (uint32_t)ra, sb = a.rep_base + (uint32_t)rb;  // replicates of the stream
+    if (na >= 768u) i8_tile_calls<true>(cnt, a.k0, a.k1, sa, (uint32_t)t, (uint32_t)lane, na, la);
+    else i8_tile_calls<false>(cnt, a.k0, a.k1, sa, (uint32_t)t, (uint32_t)lane, na, la);
+    if (nb >= 768u) i8_tile_calls<true>(cnt, a.k0, a.k1, sb, (uint32_t)t, (uint32_t)lane, nb, lb);
+    else i8_tile_calls<false>(cnt, a.k0, a.k1, sb, (uint32_t)t, (uint32_t)lane, nb, lb);
     const bool hb = lane >= 32;
-    i8_tile_calls<false>(cnt, a.k0, a.k1, (uint32_t)(hb ? rb : ra), (uint32_t)t, 64u + ((uint32_t)lane & 31u),
+    i8_tile_calls<false>(cnt, a.k0, a.k1, hb ? sb : sa, (uint32_t)t, 64u + ((uint32_t)lane & 31u),
                          hb ? nb : na, hb ? lb : la);
     const uint32_t nmax = na > nb ? na : nb;
     for (uint32_t c0 = 96u; c0 * 12u < nmax; c0 += 64u) {
-      i8_tile_calls<false>(cnt, a.k0, a.k1, (uint32_t)ra, (uint32_t)t, c0 + (uint32_t)lane, na, la);
-      i8_tile_calls<false>(cnt, a.k0, a.k1, (uint32_t)rb, (uint32_t)t, c0 + (uint32_t)lane, nb, lb);
+      i8_tile_calls<false>(cnt, a.k0, a.k1, sa, (uint32_t)t, c0 + (uint32_t)lane, na, la);
+      i8_tile_calls<false>(cnt, a.k0, a.k1, sb, (uint32_t)t, c0 + (uint32_t)lane, nb, lb);
     }
   }
   __builtin_amdgcn_s_setprio(0);
@@ -560,6 +561,7 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
   // window loop and spills them (227 VGPRs in round 1), and every scratch RELOAD in the per-tile code is a vector-memory
   // wait that also waits for whatever global loads are in flight (s_waitcnt vmcnt is in order) -- the prefetches.
   int64_t opq = 0;
+  int64_t fwin = 0;  // the window being flushed
   // one tile: digit i of power J0 + jj; observable columns (urow_f < 0) or the packed u-row fragment urow_f
   auto flush_tile = [&](v16i &T, int h, int jj, int i, int urow_f) {
     bool valid;
@@ -582,26 +584,24 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
     }
     double dsc = wt[I8_WT_DSP + j] * (urow_f >= 0 ? 0x1p-50 : wt[I8_WT_DSC + col]);
     dsc *= (double)((int64_t)1 << (8 * i));
-    const size_t part = (size_t)chunk * I8_NSL + i;
+    // one slot per scaling window: [window][replicate][power][column][digit slot] (u-row: [window][replicate][power]
+    // [digit slot]), stored once and added up by the finalize kernel in window order -- a replicate's sums do not depend
+    // on how the launch was cut into chunks (txm_resample_i8t.hip has the same layout)
     double *base;
     int64_t stride;
     if (urow_f < 0) {
-      // [chunk][digit][power][replicate][32 columns]: the lanes of a row write 256 contiguous bytes
-      base = a.part_x + ((part * K + j) * a.nrep_pad + rep0 + 32 * h + 4 * half) * I8_CPAD + col + opq;
-      stride = I8_CPAD;
+      base = a.part_x + ((((size_t)fwin * a.nrep_pad + rep0 + 32 * h + 4 * half) * K + j) * I8_CPAD + col) * 8 + i + opq;
+      stride = (int64_t)K * I8_CPAD * 8;
     } else {
-      base = a.part_u + (part * a.nrep_pad + rep0 + 32 * h + 4 * half) * K + j + opq;
-      stride = K;
+      base = a.part_u + (((size_t)fwin * a.nrep_pad + rep0 + 32 * h + 4 * half) * K + j) * 8 + i + opq;
+      stride = (int64_t)K * 8;
     }
-    double old[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) old[r] = valid ? base[(int64_t)((r >> 2) * 8 + (r & 3)) * stride] : 0.0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = (r >> 2) * 8 + (r & 3);
       int v = T[r];
       if (i == I8_NSL - 1) v -= I8_D6_BIAS * (int)fsum[32 * h + m + 4 * half];
-      if (valid) base[(int64_t)m * stride] = old[r] + (double)v * dsc;
+      if (valid) base[(int64_t)m * stride] = (double)v * dsc;
     }
     T = (v16i)(0);
   };
@@ -612,6 +612,7 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
       opq = (int64_t)z;
     }
     wt = a.wtab + win * I8_WT_STRIDE;
+    fwin = win;
     if (lane < I8_REPS_WAVE) fsum[wave * I8_REPS_WAVE + lane] = fdraws;
     fdraws = 0;
     __syncthreads();
@@ -924,7 +925,7 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
             const int64_t r = rep0w + rr;
             if (r >= a.nrep) break;  // wave-uniform
             const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)wcnt, rr);
-            sampler_fine_tile(a.k0, a.k1, (uint32_t)r, (uint32_t)t, n, tsize, lane, [&](uint32_t off0) {
+            sampler_fine_tile(a.k0, a.k1, a.rep_base + (uint32_t)r, (uint32_t)t, n, tsize, lane, [&](uint32_t off0) {
               const uint32_t off = off0 + shift;
               atomicAdd(&cnt[(rl0 + (uint32_t)rr) * I8_CNT_ROW + (off >> 2)], 1u << ((off & 3u) << 3));
             });
@@ -1031,17 +1032,9 @@ static int launch_pass(const I8Args &a, bool weighted, size_t prog_bytes, hipStr
   constexpr int nb = JN <= 2 ? 2 : 1;  // chunks per B buffer (two k-steps per barrier with one or two powers)
   const size_t lds = (size_t)I8_CNT_BYTES + 2u * nb * (size_t)buf + 2u * I8_REPS * sizeof(uint32_t) +
                      2u * SM_T * sizeof(double);  // + window draws, parked counts; two u tiles, or one u + one w
-  // the dynamic-LDS limit is a property of the function: set it once per instantiation (one device per process)
-  static bool lds_set[2] = {false, false};
-  if (!lds_set[weighted ? 1 : 0]) {
-    if (weighted)
-      TXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_i8_kernel<K, J0, JN, true, PK>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    else
-      TXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_i8_kernel<K, J0, JN, false, PK>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lds_set[weighted ? 1 : 0] = true;
-  }
+  // the dynamic-LDS limit is a property of (function, device)
+  if (weighted) TXM_SET_MAX_LDS((&resample_i8_kernel<K, J0, JN, true, PK>), lds);
+  else TXM_SET_MAX_LDS((&resample_i8_kernel<K, J0, JN, false, PK>), lds);
   if (weighted) hipLaunchKernelGGL((resample_i8_kernel<K, J0, JN, true, PK>), grid, block, lds, st, a);
   else hipLaunchKernelGGL((resample_i8_kernel<K, J0, JN, false, PK>), grid, block, lds, st, a);
   TXM_LAUNCH_CHECK();
@@ -1057,27 +1050,40 @@ static bool pack_i8_on() {
   return on;
 }
 
-int launch_resample_i8(const I8Args &a, int K, bool weighted, size_t prog_bytes, hipStream_t st) {
-  {
-    // sub-blocks of <= 16 tiles; a window is 1 sub-block (4- and 16-tile windows) or win_tiles / 16 of them
-    const int64_t sub_tiles = a.win_tiles < I8_STAT_TILES ? a.win_tiles : I8_STAT_TILES;
-    const int nsub = (int)(a.win_tiles / sub_tiles);
-    const int64_t nsub_total = cdiv(a.ntiles, sub_tiles);
-    const bool vec2 = ((reinterpret_cast<uintptr_t>(a.x + a.col0) & 15) == 0) && (a.ldx_s % 2 == 0);
-    if (vec2)
-      hipLaunchKernelGGL(i8_stats_kernel<true>, dim3((unsigned)nsub_total), dim3(256), 0, st, a.x, a.ldx_s, a.u, a.w,
-                         a.N, a.C, a.col0, sub_tiles * SM_T, nsub == 1 ? 1 : 0, a.pivot, K - 1, a.stats);
-    else
-      hipLaunchKernelGGL(i8_stats_kernel<false>, dim3((unsigned)nsub_total), dim3(256), 0, st, a.x, a.ldx_s, a.u, a.w,
-                         a.N, a.C, a.col0, sub_tiles * SM_T, nsub == 1 ? 1 : 0, a.pivot, K - 1, a.stats);
-    TXM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(i8_table_kernel, dim3((unsigned)a.nwin), dim3(64), 0, st, a.stats, nsub, nsub_total, a.N, a.C,
-                       a.win_tiles * SM_T, a.w != nullptr, K - 1, a.wtab, a.wflag);
-    TXM_LAUNCH_CHECK();
-  }
+// the pre-pass: per-window scale table, guard flags and the FP64 fallback list.  Depends on (x, u, w, pivot, shape)
+// only -- a caller that bootstraps the same data again passes the tables back in (txm_resample_opts.prep)
+int launch_i8_prepass(const I8Args &a, int K, hipStream_t st) {
+  // sub-blocks of <= 16 tiles; a window is 1 sub-block (4- and 16-tile windows) or win_tiles / 16 of them
+  const int64_t sub_tiles = a.win_tiles < I8_STAT_TILES ? a.win_tiles : I8_STAT_TILES;
+  const int nsub = (int)(a.win_tiles / sub_tiles);
+  const int64_t nsub_total = cdiv(a.ntiles, sub_tiles);
+  const bool vec2 = ((reinterpret_cast<uintptr_t>(a.x + a.col0) & 15) == 0) && (a.ldx_s % 2 == 0);
+  if (vec2)
+    hipLaunchKernelGGL(i8_stats_kernel<true>, dim3((unsigned)nsub_total), dim3(256), 0, st, a.x, a.ldx_s, a.u, a.w,
+                       a.N, a.C, a.col0, sub_tiles * SM_T, nsub == 1 ? 1 : 0, a.pivot, K - 1, a.stats);
+  else
+    hipLaunchKernelGGL(i8_stats_kernel<false>, dim3((unsigned)nsub_total), dim3(256), 0, st, a.x, a.ldx_s, a.u, a.w,
+                       a.N, a.C, a.col0, sub_tiles * SM_T, nsub == 1 ? 1 : 0, a.pivot, K - 1, a.stats);
+  TXM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(i8_table_kernel, dim3((unsigned)a.nwin), dim3(64), 0, st, a.stats, nsub, nsub_total, a.N, a.C,
+                     a.win_tiles * SM_T, a.w != nullptr, K - 1, a.wtab, a.wflag);
+  TXM_LAUNCH_CHECK();
+  TXM_HIP(hipMemsetAsync(a.n_list, 0, 256, st));
   hipLaunchKernelGGL(i8_list_kernel, dim3(1), dim3(256), 0, st, a.wflag, a.nwin, a.win_tiles, a.sub_tiles, a.list,
                      a.n_list);
   TXM_LAUNCH_CHECK();
+  return TXM_OK;
+}
+
+static bool i8t_on() {
+  static const bool on = [] {
+    const char *e = getenv("TXM_I8T");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
+int launch_resample_i8(const I8Args &a, int K, bool weighted, size_t prog_bytes, hipStream_t st) {
   int rc = TXM_OK;
   // narrow state: four powers per observable column (two row sets at most).  Not for the narrow tail group of a wide
   // state: its u-row sums would round differently from the other groups' (the monomials are formed in another order)
@@ -1105,6 +1111,9 @@ int launch_resample_i8(const I8Args &a, int K, bool weighted, size_t prog_bytes,
       default: break;
     }
   }
+  // one power per observable column: the transposing-read kernel (txm_resample_i8t.hip); TXM_I8T=0 keeps this
+  // file's kernel for A/B timing
+  if (i8t_on() && i8t_applicable(a.x, a.ldx_s, a.C_call)) return launch_resample_i8t(a, K, weighted, prog_bytes, st);
   switch (K) {
     case 1: rc = launch_pass<1, 0, 1>(a, weighted, prog_bytes, st); break;
     case 2: rc = launch_pass<2, 0, 2>(a, weighted, prog_bytes, st); break;

@@ -12,25 +12,23 @@
 
 namespace txm {
 
-__device__ int g_index_error;
-
-__global__ void clear_index_error_kernel() { g_index_error = 0; }
-
+// `err` is a word of the CALLER's workspace: concurrent calls on different streams do not share it
 __global__ __launch_bounds__(256) void indices_to_freq_kernel(const int64_t *__restrict__ idx,
                                                               int64_t nrep, int64_t nsamp,
                                                               int64_t ndat,
-                                                              int64_t *__restrict__ freq) {
-  const int64_t r = blockIdx.y;
-  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nsamp;
-       k += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t j = idx[r * nsamp + k];
-    if (j < 0 || j >= ndat) {
-      g_index_error = 1;
-    } else {
-      atomicAdd(reinterpret_cast<unsigned long long *>(freq + r * ndat + j), 1ULL);
+                                                              int64_t *__restrict__ freq,
+                                                              int *__restrict__ err) {
+  for (int64_t r = blockIdx.y; r < nrep; r += gridDim.y) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nsamp;
+         k += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t j = idx[r * nsamp + k];
+      if (j < 0 || j >= ndat) {
+        *err = 1;
+      } else {
+        atomicAdd(reinterpret_cast<unsigned long long *>(freq + r * ndat + j), 1ULL);
+      }
     }
   }
-  (void)nrep;
 }
 
 // ---- tile counts: recursive binomial splitting (stream v2, oracle/philox_oracle.c) -------------------
@@ -102,7 +100,8 @@ __device__ __forceinline__ uint32_t split_left(uint32_t k0, uint32_t k1, uint32_
 
 // grid nrep, block 64 * nwaves (a power of two), dynamic LDS: heap[2^(ka+1)] + nwaves * sub[2^(depth+1)] + red[nwaves]
 __global__ __launch_bounds__(1024) void sampler_tree_kernel(uint32_t k0, uint32_t k1key, uint32_t nsamp,
-                                                            SamplerGeom g, uint32_t *__restrict__ counts) {
+                                                            SamplerGeom g, uint32_t rep0,
+                                                            uint32_t *__restrict__ counts) {
   extern __shared__ uint32_t tree_lds[];
   const int k = g.k;
   const int depth = k < ST_DEPTH ? k : ST_DEPTH;
@@ -112,7 +111,7 @@ __global__ __launch_bounds__(1024) void sampler_tree_kernel(uint32_t k0, uint32_
   uint32_t *heap = tree_lds;                                   // levels 0 .. ka, heap indexed
   uint32_t *sub_all = heap + ((size_t)2 << ka);                // per wave: subtree levels 0 .. depth
   uint32_t *red = sub_all + (size_t)nwaves * ((size_t)2 << depth);
-  const uint32_t r = blockIdx.x;
+  const uint32_t r = rep0 + blockIdx.x;  // replicate of the STREAM; row blockIdx.x of this call's table
 
   for (uint32_t q = threadIdx.x; q < ((uint32_t)2 << ka); q += blockDim.x) heap[q] = 0u;
   __syncthreads();
@@ -202,7 +201,7 @@ __global__ __launch_bounds__(1024) void sampler_tree_kernel(uint32_t k0, uint32_
     }
     for (uint32_t j = (uint32_t)lane; j < (1u << depth); j += 64u) {
       const int64_t t = ((int64_t)s << depth) + j;
-      if (t < g.ntiles) counts[(size_t)r * g.ntiles + t] = sh[(1u << depth) + j];
+      if (t < g.ntiles) counts[(size_t)blockIdx.x * g.ntiles + t] = sh[(1u << depth) + j];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -213,7 +212,7 @@ __global__ __launch_bounds__(1024) void sampler_tree_kernel(uint32_t k0, uint32_
 // one wave per (r, t); block 256 = 4 waves, each with a private 1024-bin tile.
 __global__ __launch_bounds__(256) void sampler_freq_kernel(uint32_t k0, uint32_t k1key,
                                                            int64_t nrep, int64_t ndat,
-                                                           SamplerGeom g,
+                                                           SamplerGeom g, uint32_t rep0,
                                                            const uint32_t *__restrict__ counts,
                                                            int64_t *__restrict__ freq) {
   __shared__ uint32_t tile[4][SM_T];
@@ -228,7 +227,7 @@ __global__ __launch_bounds__(256) void sampler_freq_kernel(uint32_t k0, uint32_t
   if (active) {
     const uint32_t n = counts[(size_t)r * g.ntiles + t];
     uint32_t *tl = tile[wave];
-    sampler_fine_tile(k0, k1key, r, t, n, tsize, lane, [&](uint32_t off) { atomicAdd(&tl[off], 1u); });
+    sampler_fine_tile(k0, k1key, rep0 + r, t, n, tsize, lane, [&](uint32_t off) { atomicAdd(&tl[off], 1u); });
   }
   __syncthreads();
   if (active) {
@@ -241,22 +240,28 @@ __global__ __launch_bounds__(256) void sampler_freq_kernel(uint32_t k0, uint32_t
 
 using namespace txm;
 
+extern "C" size_t txm_indices_to_freq_ws_bytes(void) { return 256; }
+
 extern "C" int txm_indices_to_freq(const int64_t *indices, int64_t nrep, int64_t nsamp,
-                                   int64_t ndat, int64_t *freq, txm_stream stream) {
-  TXM_REQUIRE(indices && freq, "indices_to_freq: null pointer");
-  TXM_REQUIRE(nrep >= 1 && nsamp >= 1 && ndat >= 1 && nrep <= 65535, "indices_to_freq: bad sizes");
+                                   int64_t ndat, int64_t *freq, void *ws, size_t ws_bytes,
+                                   txm_stream stream) {
+  TXM_REQUIRE(indices && freq && ws, "indices_to_freq: null pointer");
+  TXM_REQUIRE(nrep >= 1 && nsamp >= 1 && ndat >= 1, "indices_to_freq: bad sizes");
+  if (ws_bytes < txm_indices_to_freq_ws_bytes()) {
+    set_error("indices_to_freq: workspace too small (%zu < 256)", ws_bytes);
+    return TXM_ERR_WORKSPACE;
+  }
   hipStream_t st = (hipStream_t)stream;
+  int *err = reinterpret_cast<int *>(ws);
   TXM_HIP(hipMemsetAsync(freq, 0, sizeof(int64_t) * (size_t)nrep * ndat, st));
-  hipLaunchKernelGGL(clear_index_error_kernel, dim3(1), dim3(1), 0, st);
-  TXM_LAUNCH_CHECK();
+  TXM_HIP(hipMemsetAsync(err, 0, sizeof(int), st));
   int gx = (int)cdiv(nsamp, 256 * 4);
   if (gx > 4096) gx = 4096;
-  hipLaunchKernelGGL(indices_to_freq_kernel, dim3(gx, (unsigned)nrep), dim3(256), 0, st, indices,
-                     nrep, nsamp, ndat, freq);
+  const unsigned gy = (unsigned)(nrep < 65535 ? nrep : 65535);
+  hipLaunchKernelGGL(indices_to_freq_kernel, dim3(gx, gy), dim3(256), 0, st, indices, nrep, nsamp, ndat, freq, err);
   TXM_LAUNCH_CHECK();
   int flag = 0;
-  TXM_HIP(hipMemcpyFromSymbolAsync(&flag, HIP_SYMBOL(g_index_error), sizeof(int), 0,
-                                   hipMemcpyDeviceToHost, st));
+  TXM_HIP(hipMemcpyAsync(&flag, err, sizeof(int), hipMemcpyDeviceToHost, st));
   TXM_HIP(hipStreamSynchronize(st));
   if (flag) {
     set_error("indices_to_freq: index outside [0, %lld)", (long long)ndat);
@@ -269,8 +274,11 @@ extern "C" int64_t txm_sampler_ntiles(int64_t ndat) { return ndat < 1 ? 0 : (nda
 
 static int check_spec(const txm_sampler_spec *sp, SamplerGeom *g, int64_t *nsamp) {
   TXM_REQUIRE(sp, "sampler: null spec");
-  TXM_REQUIRE(sp->nrep >= 1 && sp->nrep <= 65535, "sampler: nrep=%lld outside [1, 65535]",
+  TXM_REQUIRE(sp->nrep >= 1 && sp->nrep <= ((int64_t)1 << 24), "sampler: nrep=%lld outside [1, 2^24]",
               (long long)sp->nrep);
+  TXM_REQUIRE(sp->rep0 >= 0 && sp->rep0 + sp->nrep <= ((int64_t)1 << 32),
+              "sampler: stream replicates [%lld, %lld) outside [0, 2^32)", (long long)sp->rep0,
+              (long long)(sp->rep0 + sp->nrep));
   TXM_REQUIRE(sp->ndat >= 1, "sampler: ndat < 1");
   *nsamp = sp->nsamp > 0 ? sp->nsamp : sp->ndat;
   TXM_REQUIRE(*nsamp < ((int64_t)1 << 32), "sampler: nsamp >= 2^32 unsupported");
@@ -306,13 +314,9 @@ extern "C" int txm_sampler_tile_counts(const txm_sampler_spec *sp, uint32_t *cou
   const int nwaves = nsamp >= ((int64_t)1 << 22) ? 16 : 4;
   const int depth = g.k < ST_DEPTH ? g.k : ST_DEPTH, ka = g.k - depth;
   const size_t lds = (((size_t)2 << ka) + (size_t)nwaves * ((size_t)2 << depth) + (size_t)nwaves) * sizeof(uint32_t);
-  static bool attr = false;
-  if (!attr) {
-    TXM_HIP(hipFuncSetAttribute((const void *)sampler_tree_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
-  }
+  TXM_SET_MAX_LDS(sampler_tree_kernel, 160 * 1024);
   hipLaunchKernelGGL(sampler_tree_kernel, dim3((unsigned)sp->nrep), dim3(64 * nwaves), lds, st, k0, k1,
-                     (uint32_t)nsamp, g, counts);
+                     (uint32_t)nsamp, g, (uint32_t)sp->rep0, counts);
   TXM_LAUNCH_CHECK();
   return TXM_OK;
 }
@@ -328,7 +332,7 @@ extern "C" int txm_sampler_freq(const txm_sampler_spec *sp, const uint32_t *coun
   TXM_REQUIRE(cdiv(tasks, 4) < ((int64_t)1 << 31), "sampler_freq: too many tiles");
   const uint32_t k0 = (uint32_t)sp->seed, k1 = (uint32_t)(sp->seed >> 32);
   hipLaunchKernelGGL(sampler_freq_kernel, dim3((unsigned)cdiv(tasks, 4)), dim3(256), 0,
-                     (hipStream_t)stream, k0, k1, sp->nrep, sp->ndat, g, counts, freq);
+                     (hipStream_t)stream, k0, k1, sp->nrep, sp->ndat, g, (uint32_t)sp->rep0, counts, freq);
   TXM_LAUNCH_CHECK();
   return TXM_OK;
 }

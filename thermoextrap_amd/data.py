@@ -938,7 +938,15 @@ class DataCentralMomentsVals(DataCentralMomentsBase):
         sampler = cmomy.factory_sampler(sampler, data=self.xv, dim=dim, axis=axis, rep_dim=rep_dim, parallel=parallel)
         kws = {"sampler": sampler, "parallel": parallel, "axis": axis, "dim": dim, "rep_dim": rep_dim, **kwargs}
         meta = self.meta.resample(data=self, meta_kws=meta_kws, **kws)
+        # the int8 bootstrap path's pre-pass (window scale table, guard flags) depends on the samples only: kept
+        # with this object's other cached quantities (reference: per-object cache, data.py:285, 844-942), so a
+        # bootstrap loop on one data object runs it once; new_like() starts from an empty cache
+        prep = self._cache.get("resample_prep")
+        if prep is None:
+            from . import engine
+
+            prep = self._cache["resample_prep"] = engine.ResamplePrep()
         dxduave = cmomy.wrap_resample_vals(self.xv, self.uv, weight=self.weight, mom=(1, self.order),
-                                           mom_dims=(self.xmom_dim, self.umom_dim), **kws)
+                                           mom_dims=(self.xmom_dim, self.umom_dim), _prep=prep, **kws)
         dxduave = dxduave.transpose(rep_dim, ...)
         return self.new_like(dxduave=dxduave, rec_dim=rep_dim, meta=meta)

@@ -62,20 +62,38 @@ def all_gather_slabs(local: torch.Tensor, counts: Sequence[int] | None = None, g
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
 
 
-def replicate_seeds(seed: int, world_size: int) -> list[int]:
-    """Independent sampler seeds per rank (replicate-sharded bootstrap): the
-    device stream is keyed by (seed, replicate, tile), so distinct seeds give
-    independent replicate slabs."""
-    return [(int(seed) * 0x9E3779B97F4A7C15 + r * 0xD1B54A32D192ED03) & (2**63 - 1) for r in range(world_size)]
+def broadcast_int(value: int, src: int = 0, group=None) -> int:
+    """The same Python int on every rank (rank `src`'s)."""
+    rank, w = world()
+    if w == 1:
+        return int(value)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    dist.broadcast(t, src=src, group=group)
+    return int(t.item())
 
 
-def sharded_bootstrap(compute: Callable[[int, int], torch.Tensor], nrep: int, seed: int, group=None) -> torch.Tensor:
+def replicate_offsets(nrep: int, world_size: int) -> list[int]:
+    """First stream replicate of every rank's slab: rank r computes replicates
+    ``[offsets[r], offsets[r] + counts[r])`` of ONE stream (one seed), so the gathered result is the one-rank
+    result bit for bit (txm_sampler_spec.rep0)."""
+    counts = shard_counts(nrep, world_size)
+    offs, a = [], 0
+    for c in counts:
+        offs.append(a)
+        a += c
+    return offs
+
+
+def sharded_bootstrap(compute: Callable[[int, int, int], torch.Tensor], nrep: int, seed: int, group=None,
+                      rep0: int = 0) -> torch.Tensor:
     """Replicate-sharded bootstrap of ONE state point whose samples every rank holds:
-    rank r computes ``compute(nrep_r, seed_r)`` -> slab ``[nrep_r, ...]`` and all ranks
-    receive the ``[nrep, ...]`` concatenation."""
+    rank r computes ``compute(nrep_r, seed, rep0_r)`` -> slab ``[nrep_r, ...]`` (replicates ``rep0_r ...`` of the
+    stream of ``seed``) and all ranks receive the ``[nrep, ...]`` concatenation -- identical, bit for bit, to
+    ``compute(nrep, seed, rep0)`` on one rank."""
     rank, w = world()
     counts = shard_counts(nrep, w)
-    slab = compute(counts[rank], replicate_seeds(seed, w)[rank])
+    slab = compute(counts[rank], seed, rep0 + replicate_offsets(nrep, w)[rank])
     if slab.shape[0] != counts[rank]:
         raise ValueError("compute returned the wrong number of replicates")
     return all_gather_slabs(slab, counts, group)
@@ -97,21 +115,24 @@ def sharded_states(states: Sequence, func: Callable, group=None) -> list:
     return list(full.unbind(0))
 
 
-def run_step(mode: str, compute: Callable[[int, int], torch.Tensor], nrep: int, seed: int, group=None) -> torch.Tensor:
+def run_step(mode: str, compute: Callable[[int, int, int], torch.Tensor], nrep: int, seed: int, group=None) -> torch.Tensor:
     """One multi-GPU bootstrap step, the way bench.py (and a user script) shards it -- the single place both the
-    benchmark and the gloo tests go through:
+    benchmark and the gloo tests go through.  ``compute(n, seed, rep0)`` returns the ``[n, ...]`` slab of stream
+    replicates ``rep0 .. rep0 + n`` of ``seed``.
 
-    "states"   every rank bootstraps ITS OWN state point: ``compute(nrep, seed + rank)`` -> ``[nrep, ...]``;
+    "states"   every rank bootstraps ITS OWN state point: state ``rank`` of a collection that shares one seed draws
+               replicates ``rank * nrep ...`` (independent across states, as StateCollection.resample does);
                returns the ``[world * nrep, ...]`` concatenation of all ranks' slabs (weak scaling).
-    "replicas" every rank holds the SAME state point and computes ``nrep / world`` replicates with its own
-               seed (`sharded_bootstrap`); returns the ``[nrep, ...]`` concatenation (strong scaling).
+    "replicas" every rank holds the SAME state point and computes its contiguous ``nrep / world`` replicates of the
+               one stream (`sharded_bootstrap`); returns the ``[nrep, ...]`` concatenation (strong scaling) --
+               bit for bit what one rank computes for all ``nrep``.
     One all-gather ends the step; there is no data-path collective."""
     rank, w = world()
     if mode == "replicas":
         return sharded_bootstrap(compute, nrep, seed, group)
     if mode != "states":
         raise ValueError(f"unknown mode {mode!r}")
-    slab = compute(nrep, seed + rank)
+    slab = compute(nrep, seed, rank * nrep)
     if slab.shape[0] != nrep:
         raise ValueError("compute returned the wrong number of replicates")
     return all_gather_slabs(slab, [nrep] * w, group)

@@ -15,9 +15,10 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import SamplerSpec, check
+from ._lib import ResampleOpts, SamplerSpec, check
 
 F64 = torch.float64
+_last_info: dict[tuple[int, int], torch.Tensor] = {}
 _ws_cache: dict[tuple[int, int, str], torch.Tensor] = {}
 
 
@@ -129,7 +130,9 @@ def indices_to_freq(indices: torch.Tensor, ndat: int | None = None) -> torch.Ten
     nrep, nsamp = idx.shape
     ndat = nsamp if ndat is None else int(ndat)
     freq = torch.empty((nrep, ndat), dtype=torch.int64, device="cuda")
-    check(L.txm_indices_to_freq(_ptr(idx), nrep, nsamp, ndat, _ptr(freq), _stream()), "txm_indices_to_freq")
+    ws = workspace(L.txm_indices_to_freq_ws_bytes(), "indices")
+    check(L.txm_indices_to_freq(_ptr(idx), nrep, nsamp, ndat, _ptr(freq), _ptr(ws), ws.numel(), _stream()),
+          "txm_indices_to_freq")
     return freq
 
 
@@ -138,11 +141,16 @@ class DeviceSampler:
 
     Holds only the per-(replicate, tile) draw counts (uint32, nrep x ceil(ndat/1024));
     the per-sample counts are regenerated inside the bootstrap kernel.
+
+    ``rep0``: row r of this sampler is replicate ``rep0 + r`` of the stream of ``seed`` -- a replicate's draws
+    depend on (seed, stream replicate, tile) only, so ``DeviceSampler(seed, b - a, ndat, rep0=a)`` is rows
+    ``a:b`` of ``DeviceSampler(seed, n, ndat)`` bit for bit.  That is how replicate slabs and state shards of a
+    multi-GPU run reproduce the one-GPU result exactly (distributed.py).
     """
 
-    def __init__(self, seed: int, nrep: int, ndat: int, nsamp: int = 0):
+    def __init__(self, seed: int, nrep: int, ndat: int, nsamp: int = 0, rep0: int = 0):
         L = _L()
-        self.spec = SamplerSpec(seed=0, nrep=int(nrep), ndat=int(ndat), nsamp=int(nsamp))
+        self.spec = SamplerSpec(seed=0, nrep=int(nrep), ndat=int(ndat), nsamp=int(nsamp), rep0=int(rep0))
         self.ntiles = int(L.txm_sampler_ntiles(ndat))
         self.counts = torch.empty((nrep, self.ntiles), dtype=torch.int32, device="cuda")  # bit pattern of uint32
         self._nws = L.txm_sampler_counts_ws_bytes(ct.byref(self.spec))
@@ -173,11 +181,60 @@ class DeviceSampler:
     def ndat(self):
         return self.spec.ndat
 
+    @property
+    def rep0(self):
+        return self.spec.rep0
+
     def freq(self) -> torch.Tensor:
         L = _L()
         out = torch.empty((self.spec.nrep, self.spec.ndat), dtype=torch.int64, device="cuda")
         check(L.txm_sampler_freq(ct.byref(self.spec), _ptr(self.counts), _ptr(out), _stream()), "txm_sampler_freq")
         return out
+
+
+class ResamplePrep:
+    """Persistent pre-pass block of the int8 bootstrap path for ONE set of sample arrays
+    (txm_resample_opts.prep): pivot, per-window scale table, guard flags and the FP64 fallback list depend on
+    (x, u, w, pivot, N, C, nrep, order) only, so a bootstrap loop over the same data computes them once.  The
+    reference caches per data object the same way (data.py:285, 844-942).  The key holds the tensors' storage
+    pointers and torch version counters: an in-place edit of the samples, another shape or another replicate count
+    invalidates the block; so does ``new_like`` on the owning data object (a fresh cache)."""
+
+    def __init__(self):
+        self.buf: torch.Tensor | None = None
+        self.key = None
+        self.hits = 0
+        self.misses = 0
+
+    def bind(self, key, nbytes: int) -> tuple[torch.Tensor, bool]:
+        valid = self.key == key and self.buf is not None and self.buf.numel() >= nbytes
+        if not valid:
+            if self.buf is None or self.buf.numel() < nbytes:
+                self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device="cuda")
+            self.key = None  # set by commit() once the call that fills the block has been issued
+            self.misses += 1
+        else:
+            self.hits += 1
+        return self.buf, valid
+
+    def commit(self, key):
+        self.key = key
+
+    def invalidate(self):
+        self.key = None
+
+
+def _tkey(t):
+    return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()))
+
+
+def _call_path(path, N, C, nrep, order) -> int:
+    """The kernel one device-sampler call takes: an explicit path, else the forced_path() context, else the
+    library's shape rule (txm_resample_path, which honours TXM_I8 and txm_set_resample_path)."""
+    eff = path if path is not None else _forced
+    if eff in ("fp64", "int8"):
+        return _PATHS[eff]
+    return -1
 
 
 def resample_vals(
@@ -190,8 +247,19 @@ def resample_vals(
     w: torch.Tensor | None = None,
     pivot: torch.Tensor | None = None,
     out: torch.Tensor | None = None,
-) -> torch.Tensor:
-    """(nrep, C, 2, K) bootstrap states; x is (N, C) row-major (or (N,))."""
+    path: str | None = None,
+    prep: ResamplePrep | None = None,
+    info: torch.Tensor | None = None,
+    y: torch.Tensor | None = None,
+):
+    """(nrep, C, 2, K) bootstrap states; x is (N, C) row-major (or (N,)).
+
+    ``path``: "fp64" / "int8" for THIS call (None: the forced_path() context, else the library's rule).
+    ``prep``: a ResamplePrep kept by the caller next to the data -- the int8 path's pre-pass is then computed once.
+    ``info``: an int64 CUDA tensor of 4 words the library fills on the stream (path, windows, windows the guard
+    sent to the FP64 kernel, tables reused) -- no synchronisation.
+    ``y``: a second (N, C) sample matrix; returns ``(states, ymean)`` with ymean (nrep, C) = the per-replicate
+    weighted mean of y on the same draw (VolumeDataCallback's <dx/dq>, reference volume.py:121-134)."""
     L = _L()
     _check_f64_cuda(x, "x")
     _check_f64_cuda(u, "u")
@@ -239,13 +307,45 @@ def resample_vals(
         _check_f64_cuda(out, "out")
         if tuple(out.shape) != (nrep, C, 2, order + 1) or not out.is_contiguous():
             raise ValueError(f"out must be a contiguous ({nrep}, {C}, 2, {order + 1}) tensor, got {tuple(out.shape)}")
+    opts = ResampleOpts()
+    opts.path = _call_path(path, N, C, nrep, order)
+    key = None
+    if prep is not None and freq is None:
+        takes_i8 = opts.path == 1 or (opts.path == -1 and L.txm_resample_path(N, C, nrep, order) == 1)
+        if takes_i8:
+            key = (_tkey(x2), ls, _tkey(u), _tkey(w), _tkey(pivot), N, C, nrep, order)
+            buf, valid = prep.bind(key, L.txm_resample_prep_bytes(N, C, nrep, order))
+            opts.prep, opts.prep_bytes, opts.prep_valid = buf.data_ptr(), buf.numel(), int(valid)
+    if info is None:  # the words resample_info() reads back: one block per (device, stream)
+        ikey = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+        info = _last_info.get(ikey)
+        if info is None:
+            info = _last_info[ikey] = torch.zeros(4, dtype=torch.int64, device="cuda")
+    if not (info.is_cuda and info.dtype == torch.int64 and info.numel() >= 4 and info.is_contiguous()):
+        raise TypeError("info must be a contiguous int64 CUDA tensor with >= 4 elements")
+    opts.info = info.data_ptr()
+    ymean = None
+    if y is not None:
+        _check_f64_cuda(y, "y")
+        y2 = y.unsqueeze(1) if y.dim() == 1 else y
+        if tuple(y2.shape) != (N, C):
+            raise ValueError(f"y must have the shape of x, ({N}, {C}); got {tuple(y2.shape)}")
+        if y2.stride(1) != 1 or (N > 1 and y2.stride(0) < C):
+            y2 = y2.contiguous()
+        ymean = torch.empty((nrep, C), dtype=F64, device="cuda")
+        opts.y, opts.ldy_s, opts.out_y = y2.data_ptr(), max(y2.stride(0) if N > 1 else C, C), ymean.data_ptr()
     ws = workspace(L.txm_resample_vals_ws_bytes(N, C, nrep, order))
     check(
         L.txm_resample_vals(_ptr(x2), ls, 1, _ptr(u), _ptr(w), N, C, order, nrep, _ptr(freq), spec_p, counts_p,
-                            _ptr(pivot), _ptr(out), _ptr(ws), ws.numel(), _stream()),
+                            _ptr(pivot), _ptr(out), ct.byref(opts), _ptr(ws), ws.numel(), _stream()),
         "txm_resample_vals",
     )
-    return out[:, 0] if squeeze else out
+    if key is not None:
+        prep.commit(key)
+    res = out[:, 0] if squeeze else out
+    if y is not None:
+        return res, (ymean[:, 0] if y.dim() == 1 else ymean)
+    return res
 
 
 def _state_table(xs, us, ws):
@@ -323,8 +423,14 @@ def resample_vals_batched(xs, us, order: int, *, nrep: int, sampler: DeviceSampl
 
 
 def resample_path(N: int, C: int, nrep: int, order: int) -> str:
-    """Which kernel the device-sampler bootstrap takes for this shape: "fp64" or "int8"."""
-    return "int8" if _L().txm_resample_path(int(N), int(C), int(nrep), int(order)) == 1 else "fp64"
+    """Which kernel the device-sampler bootstrap takes for this shape: "fp64" or "int8" (inside a forced_path()
+    context: that path wherever the int8 kernel supports the shape)."""
+    L = _L()
+    if _forced == "fp64":
+        return "fp64"
+    if _forced == "int8":  # wherever the int8 kernel supports the shape (i8_supported)
+        return "int8" if int(N) >= 1024 and int(order) <= 7 and int(C) <= 2048 else "fp64"
+    return "int8" if L.txm_resample_path(int(N), int(C), int(nrep), int(order)) == 1 else "fp64"
 
 
 _PATHS = {None: -1, "auto": -1, "fp64": 0, "int8": 1}
@@ -333,33 +439,34 @@ _forced: str | None = None
 
 @contextlib.contextmanager
 def forced_path(path: str | None):
-    """Force the FP64 ("fp64") or the int8-sliced ("int8") bootstrap kernel wherever it applies
-    (txm_set_resample_path); None / "auto" is the library's own choice.  For tests and benchmarks: the
-    automatic choice plus the precision guard is what users get."""
+    """Force the FP64 ("fp64") or the int8-sliced ("int8") bootstrap kernel wherever it applies, for the calls
+    made inside the context; None / "auto" is the library's own choice.  The path travels with every call
+    (txm_resample_opts.path): no process-global library state is touched.  For tests and benchmarks: the automatic
+    choice plus the precision guard is what users get."""
     global _forced
     if path not in _PATHS:
         raise ValueError(f"path must be one of {sorted(k for k in _PATHS if k)} or None")
-    L = _L()
+    _L()
     prev = _forced
-    check(L.txm_set_resample_path(_PATHS[path]), "txm_set_resample_path")
-    _forced = path
+    _forced = None if path == "auto" else path
     try:
         yield
     finally:
-        check(L.txm_set_resample_path(_PATHS[prev]), "txm_set_resample_path")
         _forced = prev
 
 
-def resample_info(N: int, C: int, nrep: int, order: int) -> dict:
-    """What the last device-sampler `resample_vals` call of this shape (on the current stream) did:
-    {"path", "windows", "windows_fp64"} -- the last one counts the scaling windows (x column groups) that the
-    precision guard of the int8 path handed to the FP64 kernel.  Synchronises."""
-    L = _L()
-    ws = workspace(L.txm_resample_vals_ws_bytes(N, C, nrep, order))
-    info = (ct.c_int64 * 4)()
-    check(L.txm_resample_vals_info(_ptr(ws), int(N), int(C), int(nrep), int(order), info, _stream()),
-          "txm_resample_vals_info")
-    return {"path": "int8" if info[0] == 1 else "fp64", "windows": int(info[1]), "windows_fp64": int(info[2])}
+def resample_info(N: int | None = None, C: int | None = None, nrep: int | None = None, order: int | None = None) -> dict:
+    """What the last `resample_vals` call on the current stream did: {"path", "windows", "windows_fp64",
+    "prep_reused"} -- "windows_fp64" counts the scaling windows (x column groups) that the precision guard of the
+    int8 path handed to the FP64 kernel.  Reads the info words the library wrote on the stream
+    (txm_resample_opts.info); synchronises.  The shape arguments are accepted for compatibility and ignored."""
+    _L()
+    info = _last_info.get((torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream))
+    if info is None:
+        raise RuntimeError("no resample_vals call has been made on this stream")
+    v = info.cpu().tolist()
+    return {"path": "int8" if v[0] == 1 else "fp64", "windows": int(v[1]), "windows_fp64": int(v[2]),
+            "prep_reused": bool(v[3])}
 
 
 def resample_data(data: torch.Tensor, freq: torch.Tensor | None, order: int) -> torch.Tensor:

@@ -371,14 +371,24 @@ class StateCollection(_Params):
                 return None
         return key
 
-    def _resample_batched(self, spec: Mapping, rep_dim="rep"):
-        """One sampler over S * nrep replicates, one bootstrap launch, per-state views of the result."""
+    # states per launch of the batched path: the sampler table is [S * nrep][ntiles] and the grid carries the state on z
+    _BATCH_MAX_REPS = 1 << 22
+
+    def _resample_batched(self, spec: Mapping, rep_dim=None, state0: int = 0):
+        """One sampler over S * nrep replicates, one bootstrap launch, per-state views of the result.
+
+        With the device sampler, state s of THIS collection draws replicates ``(state0 + s) * nrep ...`` of the
+        stream of ``spec["seed"]`` (plus ``spec["rep0"]``): a sub-collection ``states[a:b]`` resampled with
+        ``state0=a`` reproduces rows ``a:b`` of the whole collection's result bit for bit -- what
+        ``resample(sharded=True)`` relies on."""
         from . import engine, moments as cm
 
         d0 = self.states[0].data
         S, N = len(self), len(d0)
         nrep = int(spec["nrep"])
         nsamp = spec.get("nsamp")
+        if rep_dim is None:
+            rep_dim = spec.get("rep_dim", "rep")
         xs, us, ws = [], [], []
         for st in self.states:
             xt, _ = cm._dev_and_dims(st.data.xv)
@@ -391,14 +401,27 @@ class StateCollection(_Params):
                           else engine.to_device(np.asarray(w)))
         use_device = spec.get("device")
         if use_device is None:
-            use_device = nrep * (nsamp or N) > cm.EXPLICIT_SAMPLER_MAX // max(S, 1)
+            # the serial loop's rule, per state (reference draws below that size): the batched call must not change
+            # which draws a seeded {"nrep", "rng"} spec gets
+            use_device = nrep * (nsamp or N) > cm.EXPLICIT_SAMPLER_MAX
         if use_device:
             seed = spec.get("seed")
             if seed is None:
                 seed = int(cm.validate_rng(spec.get("rng")).integers(0, 2**63 - 1))
-            smp = engine.DeviceSampler(seed, S * nrep, N, 0 if (nsamp is None or nsamp == N) else int(nsamp))
-            big = engine.resample_vals_batched(xs, us, d0.order, nrep=nrep, sampler=smp, ws=ws or None)
+            rep0 = int(spec.get("rep0", 0)) + int(state0) * nrep
+            ns = 0 if (nsamp is None or nsamp == N) else int(nsamp)
+            # groups of states whose S_g * nrep replicates fit one sampler table / launch
+            per = max(1, min(S, self._BATCH_MAX_REPS // max(nrep, 1)))
+            parts = []
+            for a in range(0, S, per):
+                b = min(S, a + per)
+                smp = engine.DeviceSampler(seed, (b - a) * nrep, N, ns, rep0=rep0 + a * nrep)
+                parts.append(engine.resample_vals_batched(xs[a:b], us[a:b], d0.order, nrep=nrep, sampler=smp,
+                                                          ws=ws[a:b] if ws else None))
+            big = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
         else:
+            if spec.get("rep0") or state0:
+                raise ValueError("rep0 / state shards address the device sampler's stream: pass device=True in the spec")
             # the reference's draws, state after state from the same generator (what the serial loop consumes)
             rng = cm.validate_rng(spec.get("rng"))
             idx = np.concatenate([rng.choice(N, size=(nrep, nsamp or N), replace=True) for _ in range(S)])
@@ -430,14 +453,25 @@ class StateCollection(_Params):
         ``sharded=True`` (extension) splits the states over the ranks of an initialised torch.distributed
         group (thermoextrap_amd.distributed.sharded_states) and all-gathers the replicate states."""
         sharded = kws.pop("sharded", False)
+        state0 = kws.pop("state0", 0)
         is_spec = isinstance(sampler, Mapping) and "nrep" in sampler and "indices" not in sampler and "freq" not in sampler
         if sharded:
             return self._resample_sharded(sampler, batched=batched, **kws)
         if batched is not False and is_spec and not kws and self._batch_eligible() is not None:
-            return self._resample_batched(sampler)
+            return self._resample_batched(sampler, state0=state0)
         if batched is True:
             raise ValueError("batched=True needs ExtrapModel states over DataCentralMomentsVals of one shape and a "
                              '{"nrep": n} sampler mapping')
+        if state0:
+            # the serial loop on the device stream: state s draws replicates (state0 + s) * nrep ... like the batched path
+            if not (is_spec and sampler.get("device") and sampler.get("seed") is not None):
+                raise ValueError('state0 needs a {"nrep", "seed", "device": True} sampler mapping')
+            nrep, r0 = int(sampler["nrep"]), int(sampler.get("rep0", 0))
+            sampler = [{**sampler, "rep0": r0 + (state0 + i) * nrep} for i in range(len(self))]
+        elif is_spec and sampler.get("device") and sampler.get("seed") is not None:
+            # one seed for the collection: independent replicate ranges per state, the same as the batched path
+            nrep, r0 = int(sampler["nrep"]), int(sampler.get("rep0", 0))
+            sampler = [{**sampler, "rep0": r0 + i * nrep} for i in range(len(self))]
         if isinstance(sampler, (np.ndarray, IndexSampler, Mapping)) or is_labelled(sampler):
             sampler = [sampler] * len(self)
         elif len(sampler) != len(self):
@@ -448,14 +482,31 @@ class StateCollection(_Params):
     def _resample_sharded(self, sampler, batched=None, **kws):
         """State-point sharding over torch.distributed ranks: rank r bootstraps its contiguous share of the states
         (batched when eligible), the replicate states are all-gathered (one collective of a few MB) and every
-        rank returns the full collection."""
+        rank returns the full collection.
+
+        The result equals the unsharded ``resample(sampler)`` BIT FOR BIT: the spec must name the device stream
+        (``{"nrep": n, "seed": s, "device": True}``) and state ``i`` of the collection draws stream replicates
+        ``i * nrep ...`` on whichever rank owns it (txm_sampler_spec.rep0).  A spec without a seed gets one drawn
+        on rank 0 and broadcast; numpy draws (``device=False``) cannot be sharded consistently and are refused.
+        (The reference runs this loop serially with independent draws per state: models.py:614-641.)"""
         from . import distributed as D, moments as cm
 
         rank, w = D.world()
+        is_spec = isinstance(sampler, Mapping) and "nrep" in sampler and "indices" not in sampler and "freq" not in sampler
+        if not is_spec:
+            raise ValueError('sharded=True needs a {"nrep": n, ...} sampler mapping (one stream for the whole collection)')
+        if sampler.get("device") is False:
+            raise ValueError("sharded=True draws from the device sampler stream; device=False (numpy draws) cannot be "
+                             "split over ranks consistently")
+        spec = {**sampler, "device": True}
+        if spec.get("seed") is None:
+            seed0 = int(cm.validate_rng(spec.get("rng")).integers(0, 2**63 - 1)) if rank == 0 else 0
+            spec["seed"] = D.broadcast_int(seed0)
         mine = D.shard_range(len(self), rank, w)
         if len(mine) == 0:
             raise ValueError("more ranks than states: give every rank at least one state")
-        sub = type(self)(states=tuple(self.states[i] for i in mine), kws=self.kws).resample(sampler, batched=batched, **kws)
+        sub = type(self)(states=tuple(self.states[i] for i in mine), kws=self.kws).resample(
+            spec, batched=batched, state0=mine[0], **kws)
         slabs = torch.stack([st.data.dxduave.device_values for st in sub.states])
         full = D.all_gather_slabs(slabs, D.shard_counts(len(self), w))
         states = []

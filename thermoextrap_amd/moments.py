@@ -191,10 +191,13 @@ class IndexSampler:
 
 def factory_sampler(sampler=None, *, indices=None, freq=None, ndat=None, nrep=None, nsamp=None, rng=None,
                     data=None, dim=None, axis=None, mom_ndim=None, mom_dims=None, rep_dim="rep",
-                    parallel=None, device: bool | None = None, seed: int | None = None) -> IndexSampler:
+                    parallel=None, device: bool | None = None, seed: int | None = None,
+                    rep0: int = 0) -> IndexSampler:
     """cmomy.factory_sampler.  `sampler` may be an IndexSampler, a mapping of the
     keyword arguments, or an array of indices.  `device=True` (or a table above
-    EXPLICIT_SAMPLER_MAX elements) selects the device multinomial sampler."""
+    EXPLICIT_SAMPLER_MAX elements) selects the device multinomial sampler; `rep0` (extension, device sampler
+    only) makes replicate r of the result replicate rep0 + r of the stream of `seed` -- rows rep0 .. rep0 + nrep
+    of a larger table, bit for bit (multi-GPU shards, txm_sampler_spec.rep0)."""
     del parallel, mom_ndim
     if isinstance(sampler, IndexSampler):
         return sampler
@@ -204,7 +207,7 @@ def factory_sampler(sampler=None, *, indices=None, freq=None, ndat=None, nrep=No
                                ndat=kw.get("ndat", ndat), nrep=kw.get("nrep", nrep), nsamp=kw.get("nsamp", nsamp),
                                rng=kw.get("rng", rng), data=data, dim=dim, axis=axis, mom_dims=mom_dims,
                                rep_dim=kw.get("rep_dim", rep_dim), device=kw.get("device", device),
-                               seed=kw.get("seed", seed))
+                               seed=kw.get("seed", seed), rep0=kw.get("rep0", rep0))
     if sampler is not None:  # array of indices
         indices = sampler
     if ndat is None and data is not None:
@@ -219,10 +222,13 @@ def factory_sampler(sampler=None, *, indices=None, freq=None, ndat=None, nrep=No
         raise ValueError("need nrep and ndat (or data) to build a sampler")
     nsamp = ndat if nsamp is None else int(nsamp)
     use_device = device if device is not None else (int(nrep) * int(nsamp) > EXPLICIT_SAMPLER_MAX)
+    if rep0 and not use_device:
+        raise ValueError("rep0 addresses the device sampler's stream: pass device=True (numpy draws have no replicate index)")
     if use_device:
         if seed is None:
             seed = int(validate_rng(rng).integers(0, 2**63 - 1))
-        return IndexSampler(device_sampler=engine.DeviceSampler(seed, int(nrep), int(ndat), 0 if nsamp == ndat else nsamp),
+        return IndexSampler(device_sampler=engine.DeviceSampler(seed, int(nrep), int(ndat), 0 if nsamp == ndat else nsamp,
+                                                                rep0=int(rep0)),
                             rep_dim=rep_dim)
     # the reference's draw (cmomy 0.24; verified in SURVEY App. B)
     idx = validate_rng(rng).choice(int(ndat), size=(int(nrep), nsamp), replace=True)
@@ -565,9 +571,10 @@ def wrap_reduce_vals(x, *y, mom, weight=None, axis=MISSING, dim=MISSING, mom_dim
 
 
 def wrap_resample_vals(x, *y, mom, sampler, weight=None, axis=MISSING, dim=MISSING, mom_dims=None,
-                       rep_dim="rep", parallel=None, **kw) -> CentralMomentsData:
+                       rep_dim="rep", parallel=None, _prep=None, **kw) -> CentralMomentsData:
     """cmomy.wrap_resample_vals (data.py:1354-1366, 1803-1810): dims of the result
-    are x's with `dim` replaced by `rep_dim`, plus the moment dims."""
+    are x's with `dim` replaced by `rep_dim`, plus the moment dims.  `_prep` (extension): the owning data
+    object's engine.ResamplePrep -- the int8 path's pre-pass tables are then computed once per data object."""
     del parallel, kw
     if len(y) != 1 or tuple(mom)[0] != 1:
         raise NotImplementedError("comoments need exactly one y array and mom = (1, n)")
@@ -593,7 +600,7 @@ def wrap_resample_vals(x, *y, mom, sampler, weight=None, axis=MISSING, dim=MISSI
     if x2.dim() == 2 and x2.stride(1) != 1:
         x2 = x2.contiguous()
     if sampler.is_device:
-        st = engine.resample_vals(x2, ut.contiguous(), order, sampler=sampler.device_sampler, w=wt)
+        st = engine.resample_vals(x2, ut.contiguous(), order, sampler=sampler.device_sampler, w=wt, prep=_prep)
     else:
         st = engine.resample_vals(x2, ut.contiguous(), order, freq=sampler.freq_device(), w=wt)
     st = st.reshape(sampler.nrep, *cshape, 2, order + 1)

@@ -10,7 +10,7 @@ for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_I
            "SQ_INSTS_LDS_ATOMIC SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_UNALIGNED_STALL"; do
   i=$((i+1))
   rm -rf gpurun_out/i8_pmc$i
-  timeout -k 10 240 rocprofv3 --pmc $set --kernel-include-regex "resample_i8_kernel" -d gpurun_out/i8_pmc$i -o pmc --output-format csv -- \
+  timeout -k 10 240 rocprofv3 --pmc $set --kernel-include-regex "${KREGEX:-resample_i8t?_kernel}" -d gpurun_out/i8_pmc$i -o pmc --output-format csv -- \
       python3 tools/prof_driver.py $N $NREP 32 4 1 > gpurun_out/i8_pmc$i.log 2>&1 || { echo "pass $i failed"; tail -5 gpurun_out/i8_pmc$i.log; }
 done
 python3 - <<'PY'

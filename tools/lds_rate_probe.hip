@@ -22,6 +22,16 @@ __global__ __launch_bounds__(512) void k(int *out, int iters) {
       if (MODE == 5) { typedef unsigned u4 __attribute__((ext_vector_type(4))); u4 r;
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(base + lane * 16 + (q & 7) * 1024), "n"(0) : "memory"); acc += r[0]; }
       if (MODE == 6) asm volatile("ds_write_b16 %0, %1 offset:%2" ::"v"(base + (lane & 15) * 2 + (lane >> 4) * 32), "v"(v0), "n"(q * 128) : "memory");
+      if (MODE == 7) { typedef unsigned u2 __attribute__((ext_vector_type(2))); u2 r;  // transposing read, 8-bit: 128 contiguous bytes per 16-lane group
+        asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(r) : "v"(base + lane * 8), "n"(q * 512) : "memory"); acc += r[0]; }
+      if (MODE == 8) { typedef unsigned u2 __attribute__((ext_vector_type(2))); u2 r;
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(base + lane * 8), "n"(q * 512) : "memory"); acc += r[0]; }
+      if (MODE == 9) { typedef unsigned u2 __attribute__((ext_vector_type(2))); u2 r;  // the i8t kernel's B-operand address pattern
+        asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(r) : "v"(base + (16 * (lane >> 5) + ((lane & 15) >> 1)) * 32 + ((lane >> 4) & 1) * 16 + (lane & 1) * 8), "n"((q & 7) * 1024) : "memory"); acc += r[0]; }
+      if (MODE == 10) { typedef unsigned u2 __attribute__((ext_vector_type(2))); u2 r;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(base + lane * 8), "n"(q * 512) : "memory"); acc += r[0]; }
+      if (MODE == 11) { typedef unsigned u4 __attribute__((ext_vector_type(4))); u4 d = {v0, v1, v2, v3};  // the i8t kernel's X-table store pattern
+        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(base + (lane >> 3) * 1024 + ((lane & 7) >> 1) * 32 + (lane & 1) * 16), "v"(d), "n"((q & 7) * 128) : "memory"); }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
@@ -50,5 +60,10 @@ int main() {
   run<3>("ds_write_b128");
   run<4>("ds_read_b32");
   run<5>("ds_read_b128");
+  run<8>("ds_read_b64");
+  run<10>("ds_read_b64_tr_b16");
+  run<7>("ds_read_b64_tr_b8 (contiguous)");
+  run<9>("ds_read_b64_tr_b8 (i8t B operand)");
+  run<11>("ds_write_b128 (i8t X table)");
   return 0;
 }
