@@ -21,8 +21,10 @@
 // work; two waves per SIMD fill each other's stalls.)
 //   fragment f = (row set rs, column quad cq): rs = power J0 + rs of the launch; 32 tile columns = columns 4 cq ..
 //   4 cq + 3 x digit slots 0..7.  u-row fragments (dx = 1): tile column = (monomial, digit slot), 4 monomials each.
-//   wave w owns column quad w of every row set (both replicate halves); waves 0..3 one u-row tile each; it slices
-//   the samples 4 w .. 4 w + 3 of every 32-sample chunk.
+//   wave w owns column quad w of every row set (both replicate halves) from the global load to the accumulators;
+//   waves 0..3 also one u-row tile each.  (A first cut shared one X table between the waves with a barrier per k-step
+//   and ds_write_b128 stores: every wave was in the same phase at the same time and the k-step behaved like the SUM of
+//   its LDS, vector and matrix time -- see the kernel's comment for what replaced it.)
 // Count tile: cnt[word g = sample / 4][replicate], one u32 = the u8 counts of 4 samples.  Stage 3 of the sampler runs
 // with ONE LANE PER REPLICATE (lane = replicate, the eight waves split the Philox calls): all 64 lanes of a ds_add hit
 // 64 consecutive words -- no bank conflict by construction (the old layout lost 11 cycles per ds_add to conflicts).
@@ -55,7 +57,7 @@ constexpr int T_CNT_BYTES = (SM_T / 4) * I8_REPS * 4;  // 65536: [256 words][64 
 constexpr int T_FRAG = 1024;                           // [32 samples][4 columns][8 bytes]
 constexpr int T_STEPS = SM_T / 32;
 #ifndef TXM_T_XD
-#define TXM_T_XD 4
+#define TXM_T_XD 2
 #endif
 constexpr int T_XD = TXM_T_XD;  // k-steps between the request of an x chunk and its use (1, 2 or 4: the step loop is unrolled by 4)
 static_assert(T_XD == 1 || T_XD == 2 || T_XD == 4, "ring depth");
@@ -112,53 +114,61 @@ __device__ __forceinline__ void t_fill_call(uint32_t *cntw, uint32_t k0, uint32_
 
 // K = order + 1 is a run-time argument (it only enters the flush addresses); one launch slices the JN powers
 // J0 .. J0 + JN - 1.
+//
+// Wave w owns COLUMN QUAD w (columns 4 w .. 4 w + 3) from the global load to the accumulators: it loads those four
+// columns of every sample, slices them, writes the fixed-point words into ITS OWN LDS region and reads them back
+// transposed.  Nothing but the count tile (and the staged u tile) is shared between waves, so the k-steps need no
+// barrier: the eight waves drift apart and one wave's LDS / vector phases fall into another's matrix phases.
+//   region of a wave: per power two planes [sample 32][column 4] of 4-byte halves (low dword / high dword of the
+//   8-byte word), the planes 640 bytes apart (128 bytes of padding: the two 16-lane groups of a half-wave read the
+//   two planes at once, on disjoint banks).  A lane slices (sample l >> 2, column l & 3) of a 16-sample unit, so a
+//   wave's 64 low dwords are 256 contiguous bytes: ds_write_addtid_b32 (no address register, 128 B/clk -- twice the
+//   rate of ds_write_b128).  The transposing read of a plane hands lane i of a 16-lane group byte column i =
+//   (column i >> 2, digit i & 3): tile column n = 16 plane + 4 column + digit-in-plane.
+//   A region is single-buffered: within a wave LDS operations execute in order, and the words of chunk s + 1 of a power
+//   are written after the MFMAs of chunk s of that power have taken their operands.
+constexpr int T_PLANE = 512, T_PB = 2 * T_PLANE + 128;  // bytes per (wave, power)
 template <int J0, int JN, bool WEIGHTED>
 __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void resample_i8t_kernel(const I8Args a, const int K) {
   static_assert(JN >= 1 && JN <= 5 && J0 + JN <= 8, "power range");
-  static_assert(!WEIGHTED || JN <= 4, "weighted launches stage a second 8 KiB tile: four row sets at most");
   constexpr int NS = JN;             // row sets of the launch = x fragments per wave
   constexpr int UF = (JN + 3) / 4;   // u-row fragments (4 monomials each)
-  constexpr int NF = NS * 8 + UF;
-  constexpr int XBUF = NF * T_FRAG;
+  constexpr int WREG = (NS + 1) * T_PB;  // a wave's region: NS powers + one u-row fragment
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  uint32_t *cntw = reinterpret_cast<uint32_t *>(lds);
-  unsigned char *xt0 = lds + T_CNT_BYTES;
-  unsigned char *xt1 = xt0 + XBUF;
-  uint32_t *fsum = reinterpret_cast<uint32_t *>(xt1 + XBUF);  // [64] draws per replicate in the window
-  uint32_t *cnt_a = fsum + I8_REPS;                           // [64] tile draw counts, double buffered
+  // the X regions come first: ds_write_addtid takes its base from M0[15:0]
+  static_assert(T_WAVES * WREG <= 65536, "X regions within the first 64 KiB");
+  uint32_t *cntw = reinterpret_cast<uint32_t *>(lds + T_WAVES * WREG);
+  uint32_t *fsum = cntw + T_CNT_BYTES / 4;  // [64] draws per replicate in the window
+  uint32_t *cnt_a = fsum + I8_REPS;         // [64] tile draw counts, double buffered
   uint32_t *cnt_b = cnt_a + I8_REPS;
-  // the scaled u deviations (u - pu) / max|u - pu| (and weights w / max|w|) of the 1024 samples whose X words this
-  // tile's k-steps produce: chunks 1 .. 31 of the tile and chunk 0 of the next one -- staged once per tile by the whole
-  // workgroup, so the k-steps load nothing but x
-  double *utile = reinterpret_cast<double *>(cnt_b + I8_REPS);
-  double *wtile = utile + SM_T;  // WEIGHTED only
+  // the sample factors w du^(J0 + jj), jj < JN, of the 1024 samples whose X words this tile's k-steps produce (chunks
+  // 1 .. 31 of the tile and chunk 0 of the next one): staged once per tile by the whole workgroup as JN tiles of 8 KiB,
+  // so that a k-step loads nothing but x and spends one v_fma_f64 + two v_xor_b32 per word -- the powers are LDS
+  // reads (broadcast: four lanes per sample), not vector multiplies
+  double *ptile = reinterpret_cast<double *>(cnt_b + I8_REPS);  // [JN][1024]
 
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int n32 = lane & 31, half = lane >> 5;
+  const uint32_t wreg = (uint32_t)(wave * WREG);  // LDS byte offset of this wave's region (uniform)
 
-  // ---- producer role: wave w slices unit w of every chunk = 4 samples x 32 columns;
-  // lane = (column quad, sample, column pair)
-  const int cqd = lane >> 3, s4 = (lane & 7) >> 1, hf = lane & 1;
-  // (the launcher takes this kernel only for full groups of 32 columns whose rows are 16-byte aligned:
-  // i8t_applicable; everything else stays on txm_resample_i8.hip)
-  const int c0 = 4 * cqd + 2 * hf;
-  const int cc0 = c0, cc1 = c0 + 1;
-  const uint32_t wr_off = (uint32_t)(cqd * T_FRAG + (wave * 4 + s4) * 32 + hf * 16);  // + row set * 8 KiB
-  // per-lane BYTE offsets from a wave-uniform row base (saddr + zext(voffset) form of global_load: no 64-bit
-  // vector address arithmetic in the k-step)
-  const uint32_t xo0 = (uint32_t)((s4 * a.ldx_s + cc0) * 8);
-  // u-row monomials of this wave's 4 samples: lane = (monomial, sample)
-  const int us = lane & 3, um = lane >> 2;
-  const uint32_t uw_off = (uint32_t)((NS * 8 + ((um >> 2) < UF ? (um >> 2) : 0)) * T_FRAG + (wave * 4 + us) * 32 + (um & 3) * 8);
-  // ---- consumer role: wave w owns column quad w of every row set (both replicate halves) and, waves 0 .. 2 UF - 1,
-  // one u-row tile
-  const uint32_t rd_off = (uint32_t)(wave * T_FRAG + (16 * half + ((lane & 15) >> 1)) * 32 + ((lane >> 4) & 1) * 16 +
-                                     (lane & 1) * 8);  // + row set * 8 KiB; second read + 256
+  // ---- producer role: lane = (sample l >> 2 of a 16-sample unit, column l & 3 of the wave's quad)
+  const int ps = lane >> 2, cl = lane & 3;
+  const int col = 4 * wave + cl;
+  const int ccol = col < a.C ? col : 0;  // columns >= C re-read column 0: their sums are never flushed
+  const uint32_t xo = (uint32_t)((ps * a.ldx_s + ccol) * 8);  // byte offset from the unit's (uniform) row base
+  // ---- consumer role
+  // transposing read of (plane g, rows 16 half + 0..7): lane 2 q + p of the 16-lane group supplies row q, bytes 8 p ..
+  const uint32_t rd_off = wreg + (uint32_t)(((lane >> 4) & 1) * (T_PLANE + 128) + (16 * half + ((lane & 15) >> 1)) * 16 +
+                                            (lane & 1) * 8);  // + power * T_PB; second read + 128
   const uint32_t a_off = (uint32_t)((4 * half) * I8_REPS + n32);  // words; + 8 s * 64 + q * 64 (+ 32: second half)
+  // tile column n32 -> (column, digit slot)
+  const int tcl = (n32 >> 2) & 3, tdg = 4 * (n32 >> 4) + (n32 & 3);
+  // u-row tile of waves 0 .. 2 UF - 1: fragment fu (monomials 4 fu .. 4 fu + 3), replicate half uh
   constexpr int NUT = 2 * UF;
   const bool has_ut = wave < NUT;  // wave-uniform
   const int fu = has_ut ? (wave >> 1) : 0, uh = wave & 1;
-  const int urd_delta = __builtin_amdgcn_readfirstlane((NS * 8 + fu - wave) * T_FRAG);  // u-row fragment relative to rd_off
+  const int um = 4 * fu + cl;      // this lane's u-row monomial
+  const int umc = um < JN ? um : 0;
 
   const int b = blockIdx.x;
   const int xcd = b & 7, qq = b >> 3;
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   if (t_end > a.ntiles) t_end = a.ntiles;
 
   const double pu = a.pivot[0];
-  const double px0 = a.pivot[1 + a.col0 + cc0], px1 = a.pivot[1 + a.col0 + cc1];
+  const double px = a.pivot[1 + a.col0 + ccol];
 
   v16i acc[NS][2];
   v16i accu;
@@ -178,9 +188,8 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   for (int e = 0; e < NS; ++e) acc[e][0] = acc[e][1] = (v16i)(0);
   accu = (v16i)(0);
 
-  // table slots that are never written (columns >= C re-read column 0 and ARE written; the unused monomial slots of a
-  // short u-row fragment are not) hold integers that are never flushed: zero them for determinism
-  for (int e = threadIdx.x; e < 2 * XBUF / 16; e += T_BLOCK) reinterpret_cast<uint4 *>(xt0)[e] = make_uint4(0, 0, 0, 0);
+  // zero the regions once (the padding between the planes is never written)
+  for (int e = threadIdx.x; e < T_WAVES * WREG / 16; e += T_BLOCK) reinterpret_cast<uint4 *>(lds)[e] = make_uint4(0, 0, 0, 0);
 
   // stage-3 role: lane = replicate
   const int64_t my_rep = rep0 + lane;
@@ -190,19 +199,19 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   uint32_t fdraws = 0;
 
   struct XIn {
-    double x0, x1;
+    double x[2];  // the two 16-sample units of a chunk
   };
-  // the wave's unit of one chunk: i0 = its first sample (wave-uniform)
+  // the wave's column quad of one chunk: i0 = the chunk's first sample (wave-uniform)
   auto load_x = [&](int64_t i0, XIn &r) {
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) {
 #ifdef TXM_T_NO_LOAD  // ablation build: no memory access
-    r.x0 = (double)i0 * 1e-9 + px0;
-    r.x1 = (double)i0 * 2e-9 + px1;
-    return;
+      r.x[uu] = (double)(i0 + uu) * 1e-9 + px;
+#else
+      const double *xr = a.x + (i0 + 16 * uu) * a.ldx_s + a.col0;
+      r.x[uu] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(xr) + xo);
 #endif
-    const double *xr = a.x + i0 * a.ldx_s + a.col0;
-    const double2 t2 = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(xr) + xo0);
-    r.x0 = t2.x;
-    r.x1 = t2.y;
+    }
   };
 
 #ifdef TXM_I8T_TIMING
@@ -225,61 +234,41 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const double *wt = a.wtab + win * I8_WT_STRIDE;
     const double inv_du = wt[I8_WT_INVDU];
     const double inv_w = WEIGHTED ? wt[I8_WT_INVW] : 1.0;
-    const double sc0 = wt[I8_WT_SC + cc0], sc1 = wt[I8_WT_SC + cc1];
+    const double sc = wt[I8_WT_SC + ccol];
     int64_t tt_end = (win + 1) * WT;
     if (tt_end > t_end) tt_end = t_end;
 
-    // ---- the unit of one chunk: 4 samples x 32 columns x NS powers -> the X table of buffer `nxt`
-    // du / w: `dup` points at the entry of this lane's sample (the staged tiles, or two scalars of the direct path)
-    auto produce_head = [&](const XIn &r, double duv, double wv, double &du, double &p, double &dx0, double &dx1) {
-      du = duv;
-      dx0 = (r.x0 - px0) * sc0;
-      dx1 = (r.x1 - px1) * sc1;
-      p = WEIGHTED ? wv : 1.0;
-#pragma unroll
-      for (int q = 0; q < J0; ++q) p *= du;
-    };
-    auto produce_power = [&](unsigned char *nxt, int jj, double du, double &p, double dx0, double dx1) {
-      if (jj > 0) p *= du;
-      const uint64_t b0 = (uint64_t)__double_as_longlong(fma(p, dx0, T_MAGIC));
-      const uint64_t b1 = (uint64_t)__double_as_longlong(fma(p, dx1, T_MAGIC));
-      uint4 v;
-      v.x = (uint32_t)b0 ^ 0x80808080u;
-      v.y = (uint32_t)(b0 >> 32) ^ 0x00008080u;
-      v.z = (uint32_t)b1 ^ 0x80808080u;
-      v.w = (uint32_t)(b1 >> 32) ^ 0x00008080u;
+    // ---- store the fixed-point words of the wave's two units of one power: low dwords and high dwords as four
+    // 256-byte runs (M0 = the wave's region)
+    auto store_x2 = [&](uint64_t bits0, uint64_t bits1, int off) {
+      const uint32_t lo0 = (uint32_t)bits0 ^ 0x80808080u, hi0 = (uint32_t)(bits0 >> 32) ^ 0x00008080u;
+      const uint32_t lo1 = (uint32_t)bits1 ^ 0x80808080u, hi1 = (uint32_t)(bits1 >> 32) ^ 0x00008080u;
 #ifdef TXM_T_NO_WRITE  // ablation build: the values stay live, nothing is stored
-      asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+      asm volatile("" ::"v"(lo0), "v"(hi0), "v"(lo1), "v"(hi1));
+#elif defined(TXM_T_STORE1)
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%3\n\tds_write_addtid_b32 %1 offset:%4"
+                   : : "v"(lo0), "v"(hi0), "s"(wreg), "n"(off), "n"(off + T_PLANE + 128) : "memory");
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%3\n\tds_write_addtid_b32 %1 offset:%4"
+                   : : "v"(lo1), "v"(hi1), "s"(wreg), "n"(off + 256), "n"(off + 256 + T_PLANE + 128) : "memory");
 #else
-      *reinterpret_cast<uint4 *>(nxt + wr_off + jj * 8 * T_FRAG) = v;
+      // (s_nop: one wait state between an SALU write of M0 and an add-TID LDS instruction)
+      asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                   "ds_write_addtid_b32 %0 offset:%5\n\t"
+                   "ds_write_addtid_b32 %1 offset:%6\n\t"
+                   "ds_write_addtid_b32 %2 offset:%7\n\t"
+                   "ds_write_addtid_b32 %3 offset:%8"
+                   :
+                   : "v"(lo0), "v"(hi0), "v"(lo1), "v"(hi1), "s"(wreg), "n"(off), "n"(off + T_PLANE + 128), "n"(off + 256),
+                     "n"(off + 256 + T_PLANE + 128)
+                   : "memory");
 #endif
     };
-    // the u-row monomials w du^(J0 + m) of this wave's 4 samples (dx = 1): lane = (monomial m, sample)
-    auto produce_urow = [&](unsigned char *nxt, double du, double wv) {
-      double p = WEIGHTED ? wv : 1.0;
-#pragma unroll
-      for (int q = 0; q < J0; ++q) p *= du;
-      if constexpr (JN > 1) {
-        const double d2 = du * du;
-        p *= (um & 1) ? du : 1.0;
-        if constexpr (JN > 2) p *= (um & 2) ? d2 : 1.0;
-        if constexpr (JN > 4) p *= (um & 4) ? d2 * d2 : 1.0;
-      }
-      // (ldexp + add: exact, and no second 64-bit literal for the register allocator to park in scratch -- a scratch
-      // reload in the k-step is a vmcnt(0) wait on the x requests just issued)
-      const uint64_t b0 = (uint64_t)__double_as_longlong(__builtin_ldexp(p, 50) + T_MAGIC);
-      uint2 v;
-      v.x = (uint32_t)b0 ^ 0x80808080u;
-      v.y = (uint32_t)(b0 >> 32) ^ 0x00008080u;
-      if (um < JN) *reinterpret_cast<uint2 *>(nxt + uw_off) = v;
-    };
 
-    // ---- one k-step: chunk s of the current tile on the matrix pipe out of `cur`, the wave's unit of chunk s + 1
-    // produced into `nxt` from the samples in R (loaded one step earlier)
-    // (e0 = entry of the wave's first sample of the produced chunk in the staged tiles; e0 < 0: the direct path of a
-    // window's first chunk -- du / w come in the four scalars)
-    auto kstep = [&](auto produce_c, auto consume_c, const unsigned char *cur, unsigned char *nxt, int s, const XIn &R,
-                     int e0, double d_du = 0.0, double d_w = 1.0, double d_duu = 0.0, double d_wu = 1.0) {
+    // ---- one k-step of a wave: chunk s of the tile on the matrix pipe, the X words of chunk s + 1 sliced in between.
+    // e0 = entry of the produced chunk's first sample in the staged tiles (e0 < 0: the direct path of a window's first
+    // chunk -- du / w of this lane's two samples come in d_du / d_w)
+    auto kstep = [&](auto produce_c, auto consume_c, int s, const XIn &R, int e0, const double (&d_du)[2],
+                     const double (&d_w)[2]) {
 #ifdef TXM_T_NO_PRODUCE  // ablation build
       constexpr bool produce = false;
 #else
@@ -295,46 +284,72 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
           A0[q] = (int)cw[q * I8_REPS];
           A1[q] = (int)cw[q * I8_REPS + 32];
         }
-        Ba = T_TRREAD((lds_v2i)(cur + rd_off));
-        Bb = T_TRREAD((lds_v2i)(cur + rd_off + 256));
+        Ba = T_TRREAD((lds_v2i)(lds + rd_off));
+        Bb = T_TRREAD((lds_v2i)(lds + rd_off + 128));
       }
-      double du = 0.0, p = 0.0, dx0 = 0.0, dx1 = 0.0, duu = d_duu, wu = d_wu;
+      double dx[2] = {0.0, 0.0};
+      const bool staged = e0 >= 0;  // uniform
       if constexpr (produce) {
-        double duv = d_du, wv = d_w;
-        if (e0 >= 0) {  // uniform
-          duv = utile[e0 + s4];
-          duu = utile[e0 + us];
-          if constexpr (WEIGHTED) {
-            wv = wtile[e0 + s4];
-            wu = wtile[e0 + us];
-          }
-        }
-        produce_head(R, duv, wv, du, p, dx0, dx1);
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) dx[uu] = (R.x[uu] - px) * sc;
       }
+      // factor jj of unit uu: a broadcast LDS read (staged) or du / w of the direct path multiplied up
+      const double *pt = ptile + (staged ? e0 : 0) + ps;  // + jj * 1024 + 16 * uu: immediate offsets
+      auto factor = [&](int jj, int uu) {
+        if (!WEIGHTED && J0 == 0 && jj == 0) return 1.0;
+        if (staged) return pt[jj * SM_T + 16 * uu];
+        double pw = WEIGHTED ? d_w[uu] : 1.0;
+        for (int q = 0; q < J0 + jj; ++q) pw *= d_du[uu];
+        return pw;
+      };
       t_static_for<NS>([&](auto fic) {
         constexpr int fi = decltype(fic)::value;
         v2i Na = (v2i)(0), Nb = (v2i)(0);
         if constexpr (consume) {
           if constexpr (fi + 1 < NS) {
-            Na = T_TRREAD((lds_v2i)(cur + rd_off + (fi + 1) * 8 * T_FRAG));
-            Nb = T_TRREAD((lds_v2i)(cur + rd_off + (fi + 1) * 8 * T_FRAG + 256));
+            Na = T_TRREAD((lds_v2i)(lds + rd_off + (fi + 1) * T_PB));
+            Nb = T_TRREAD((lds_v2i)(lds + rd_off + (fi + 1) * T_PB + 128));
           }
           const v4i B = {Ba[0], Ba[1], Bb[0], Bb[1]};
-          t_mfma<(fi < 4)>(acc[fi][0], A0, B);  // 8 tiles in the 128 AGPRs, the fifth row set and the u-row tile in VGPRs
-          t_mfma<(fi < 4)>(acc[fi][1], A1, B);
+          t_mfma<true>(acc[fi][0], A0, B);
+          t_mfma<true>(acc[fi][1], A1, B);
         }
-        if constexpr (produce) produce_power(nxt, fi, du, p, dx0, dx1);
+        if constexpr (produce) {
+          // the words of chunk s + 1, power fi: behind the MFMAs that took chunk s's (the region is single-buffered)
+          store_x2((uint64_t)__double_as_longlong(fma(factor(fi, 0), dx[0], T_MAGIC)),
+                   (uint64_t)__double_as_longlong(fma(factor(fi, 1), dx[1], T_MAGIC)), fi * T_PB);
+        }
         Ba = Na;
         Bb = Nb;
       });
-      if constexpr (produce) produce_urow(nxt, duu, wu);
-      if constexpr (consume) {
-        if (has_ut) {  // wave-uniform
-          Ba = T_TRREAD((lds_v2i)(cur + urd_delta + rd_off));
-          Bb = T_TRREAD((lds_v2i)(cur + urd_delta + rd_off + 256));
+      if (has_ut) {  // wave-uniform: the u-row tile
+        if constexpr (consume) {
+          Ba = T_TRREAD((lds_v2i)(lds + rd_off + NS * T_PB));
+          Bb = T_TRREAD((lds_v2i)(lds + rd_off + NS * T_PB + 128));
           const v4i B = {Ba[0], Ba[1], Bb[0], Bb[1]};
+#ifdef TXM_T_UH_BRANCH
+          if (uh) t_mfma<false>(accu, A1, B);  // wave-uniform
+          else t_mfma<false>(accu, A0, B);
+#else
           const v4i Au = {uh ? A1[0] : A0[0], uh ? A1[1] : A0[1], uh ? A1[2] : A0[2], uh ? A1[3] : A0[3]};
           t_mfma<false>(accu, Au, B);
+#endif
+        }
+        if constexpr (produce) {
+          // monomial um of this lane's sample (dx = 1); the unused monomial slots of a short fragment repeat monomial 0:
+          // their sums are never flushed
+          double pw[2];
+#pragma unroll
+          for (int uu = 0; uu < 2; ++uu) {
+            if (staged) pw[uu] = ptile[umc * SM_T + e0 + 16 * uu + ps];
+            else {
+              pw[uu] = WEIGHTED ? d_w[uu] : 1.0;
+              for (int q = 0; q < J0 + umc; ++q) pw[uu] *= d_du[uu];
+            }
+          }
+          // (ldexp + add: exact, and no second 64-bit literal for the register allocator to park in scratch)
+          store_x2((uint64_t)__double_as_longlong(__builtin_ldexp(pw[0], 50) + T_MAGIC),
+                   (uint64_t)__double_as_longlong(__builtin_ldexp(pw[1], 50) + T_MAGIC), NS * T_PB);
         }
       }
     };
@@ -343,34 +358,33 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     // ---- flush: int32 accumulators of one window -> its slot of the partial sums (stored, never re-read here)
     // D layout of v_mfma_i32_32x32x32_i8: column = lane & 31, row = 8 * (reg / 4) + 4 * (lane >> 5) + reg % 4
-    auto flush_tile = [&](v16i &T, int h, int rs, int cq, int ufrag) {
+    auto flush_tile = [&](v16i &T, int h, int rs, int ufrag) {
       // `opq` is an opaque zero re-created per tile: the addresses below are then computed where they are used; left
       // to itself the compiler hoists them all out of the window loop and spills them
       uint32_t z = 0;
       asm volatile("" : "+v"(z));
       const int64_t opq = (int64_t)z;
-      const int cl = n32 >> 3, dg = n32 & 7;
-      bool valid = dg < I8_NSL;
+      bool valid = tdg < I8_NSL;
       int j;
       double dsc;
       double *base;
       if (ufrag < 0) {
-        const int col = 4 * cq + cl;
-        valid = valid && col < a.C;
+        const int c = 4 * wave + tcl;
+        valid = valid && c < a.C;
         j = J0 + rs;
-        dsc = wt[I8_WT_DSP + j] * wt[I8_WT_DSC + (col < a.C ? col : 0)];
-        // [window][replicate][power][column][digit slot]: the 32 lanes of a row write 256 contiguous bytes
-        base = a.part_x + ((((size_t)win * a.nrep_pad + rep0 + 32 * h + 4 * half) * K + j) * I8_CPAD + col) * 8 + dg + opq;
+        dsc = wt[I8_WT_DSP + j] * wt[I8_WT_DSC + (c < a.C ? c : 0)];
+        // [window][replicate][power][column][digit slot]
+        base = a.part_x + ((((size_t)win * a.nrep_pad + rep0 + 32 * h + 4 * half) * K + j) * I8_CPAD + c) * 8 + tdg + opq;
       } else {
-        const int m = 4 * ufrag + cl;
+        const int m = 4 * ufrag + tcl;
         valid = valid && m < JN;
         j = J0 + (m < JN ? m : 0);
         dsc = wt[I8_WT_DSP + j] * 0x1p-50;
-        base = a.part_u + (((size_t)win * a.nrep_pad + rep0 + 32 * h + 4 * half) * K + j) * 8 + dg + opq;
+        base = a.part_u + (((size_t)win * a.nrep_pad + rep0 + 32 * h + 4 * half) * K + j) * 8 + tdg + opq;
       }
-      dsc *= (double)((int64_t)1 << (8 * (dg < I8_NSL ? dg : 0)));
+      dsc *= (double)((int64_t)1 << (8 * (tdg < I8_NSL ? tdg : 0)));
       const size_t stride = (size_t)K * (ufrag < 0 ? I8_CPAD : 1) * 8;  // one replicate
-      const int bias = dg == I8_NSL - 1 ? T_D6_BIAS : 0;
+      const int bias = tdg == I8_NSL - 1 ? T_D6_BIAS : 0;
       if (valid) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -384,8 +398,9 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     bool first_tile = true;
     uint32_t *cnt_cur = cnt_a, *cnt_nxt = cnt_b;
-    XIn XR[T_XD];  // x of the wave's unit, requested T_XD k-steps ahead: chunk c lives in slot c % T_XD
-    auto load_chunk = [&](int64_t wb, int c, XIn &R) { load_x(wb + c * 32 + wave * 4, R); };
+    XIn XR[T_XD];  // the wave's columns of a chunk, requested T_XD k-steps ahead: chunk c lives in slot c % T_XD
+    auto load_chunk = [&](int64_t wb, int c, XIn &R) { load_x(wb + c * 32, R); };
+    const double no_d[2] = {0.0, 0.0}, no_w[2] = {1.0, 1.0};
 
 #pragma unroll 1
     for (int64_t t = win * WT; t < tt_end; ++t) {
@@ -432,6 +447,8 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       }
       uint32_t ncnt = 0;
       if (wave == 0 && has_next && rep_live) ncnt = a.counts[(size_t)my_rep * a.ntiles + t + 1];
+      // (the last k-step of the previous tile was the count tile's and the staged tiles' last reader: barrier below)
+      __syncthreads();
       for (int e = threadIdx.x; e < T_CNT_BYTES / 16; e += T_BLOCK) reinterpret_cast<uint4 *>(cntw)[e] = make_uint4(0, 0, 0, 0);
       T_TICK(1);
       __syncthreads();
@@ -482,37 +499,43 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
       }
       if (first_tile) {
-        // the X table of chunk 0 (no matrix work yet; its u / w straight from memory), chunks 1 .. 4 requested
-        const int64_t i0 = wbase + wave * 4;
-        const double d_du = (a.u[i0 + s4] - pu) * inv_du, d_duu = (a.u[i0 + us] - pu) * inv_du;
-        double d_w = 1.0, d_wu = 1.0;
-        if constexpr (WEIGHTED) {
-          d_w = a.w[i0 + s4] * inv_w;
-          d_wu = a.w[i0 + us] * inv_w;
+        // the X words of chunk 0 (no matrix work yet; its u / w straight from memory), chunks 1 .. T_XD requested
+        double d_du[2], d_w[2] = {1.0, 1.0};
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) {
+          d_du[uu] = (a.u[wbase + 16 * uu + ps] - pu) * inv_du;
+          if constexpr (WEIGHTED) d_w[uu] = a.w[wbase + 16 * uu + ps] * inv_w;
         }
-        kstep(YES, NO, xt1, xt0, 0, XR[0], -1, d_du, d_w, d_duu, d_wu);
+        kstep(YES, NO, 0, XR[0], -1, d_du, d_w);
 #pragma unroll
         for (int c = 1; c <= T_XD; ++c) load_chunk(wbase, c, XR[c % T_XD]);
         first_tile = false;
       }
-      // park the staged tiles (the previous tile's last k-step was their last reader)
+      // park the staged tiles
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int e = (int)threadIdx.x + q * T_BLOCK;
-        utile[e] = (su[q] - pu) * inv_du;
-        if constexpr (WEIGHTED) wtile[e] = sw[q] * inv_w;
+        const double du = (su[q] - pu) * inv_du;
+        double pw = WEIGHTED ? sw[q] * inv_w : 1.0;
+#pragma unroll
+        for (int k = 0; k < J0; ++k) pw *= du;
+#pragma unroll
+        for (int jj = 0; jj < JN; ++jj) {
+          ptile[jj * SM_T + e] = pw;
+          pw *= du;
+        }
       }
       if (wave == 0) cnt_nxt[lane] = ncnt;
       T_TICK(3);
       __syncthreads();
       T_TICK(4);
 
-      // ---- 32 k-steps, four per trip.  Step s contracts chunk s, produces chunk s + 1 from the ring slot (s + 1) % T_XD
-      // (x requested T_XD steps ago: an HBM miss is ~2 k-steps long) and requests chunk s + 1 + T_XD into that slot.
-      // Chunk 32 is the next tile's chunk 0 (a buffer nobody reads when there is no next tile).
-      auto target = [&](int c, int64_t &wb, int &cl) {
-        if (c < T_STEPS) { wb = wbase; cl = c; }
-        else { wb = wnext; cl = has_next ? c - T_STEPS : T_STEPS - 1; }
+      // ---- 32 k-steps, four per trip, NO barrier between them.  Step s contracts chunk s, slices chunk s + 1 from
+      // the ring slot (s + 1) % T_XD (x requested T_XD steps ago) and requests chunk s + 1 + T_XD into that slot.
+      // Chunk 32 is the next tile's chunk 0 (words nobody reads when there is no next tile).
+      auto target = [&](int c, int64_t &wb, int &cl2) {
+        if (c < T_STEPS) { wb = wbase; cl2 = c; }
+        else { wb = wnext; cl2 = has_next ? c - T_STEPS : T_STEPS - 1; }
       };
 #pragma unroll 1
       for (int s = 0; s < T_STEPS; s += 4) {
@@ -522,15 +545,14 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
           XIn &R = XR[(e + 1) % T_XD];
           const XIn cur_x = R;
           int64_t wb;
-          int cl;
-          target(sq + 1 + T_XD, wb, cl);
-          load_chunk(wb, cl, R);
-          kstep(YES, YES, (e & 1) ? xt1 : xt0, (e & 1) ? xt0 : xt1, sq, cur_x, sq * 32 + wave * 4);
+          int cl2;
+          target(sq + 1 + T_XD, wb, cl2);
+          load_chunk(wb, cl2, R);
+          kstep(YES, YES, sq, cur_x, sq * 32, no_d, no_w);
           T_TICK(5);
-          __syncthreads();
-          T_TICK(6);
         }
       }
+      T_TICK(6);
       {
         uint32_t *tmp = cnt_cur;
         cnt_cur = cnt_nxt;
@@ -544,10 +566,10 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     __syncthreads();
 #pragma unroll
     for (int fi = 0; fi < NS; ++fi) {
-      flush_tile(acc[fi][0], 0, fi, wave, -1);
-      flush_tile(acc[fi][1], 1, fi, wave, -1);
+      flush_tile(acc[fi][0], 0, fi, -1);
+      flush_tile(acc[fi][1], 1, fi, -1);
     }
-    if (has_ut) flush_tile(accu, uh, 0, 0, fu);  // wave-uniform
+    if (has_ut) flush_tile(accu, uh, 0, fu);  // wave-uniform
     accu = (v16i)(0);
     __syncthreads();  // fsum is rewritten by the next window
     T_TICK(7);
@@ -566,26 +588,23 @@ template <int J0, int JN, bool WEIGHTED>
 static int launch_pass_t(const I8Args &a, int K, size_t prog_bytes, hipStream_t st) {
   if (a.progress != nullptr) TXM_HIP(hipMemsetAsync(a.progress, 0, prog_bytes, st));
   const dim3 grid((unsigned)(a.n_chunks * a.n_rbg)), block(T_BLOCK);
-  constexpr int nf = JN * 8 + (JN + 3) / 4;
-  const size_t lds = (size_t)T_CNT_BYTES + 2u * nf * T_FRAG + 3u * I8_REPS * sizeof(uint32_t) +
-                     (WEIGHTED ? 2u : 1u) * SM_T * sizeof(double);
+  const size_t lds = (size_t)T_WAVES * (JN + 1) * T_PB + T_CNT_BYTES + 3u * I8_REPS * sizeof(uint32_t) +
+                     (size_t)JN * SM_T * sizeof(double);
   TXM_SET_MAX_LDS((&resample_i8t_kernel<J0, JN, WEIGHTED>), lds);
   hipLaunchKernelGGL((resample_i8t_kernel<J0, JN, WEIGHTED>), grid, block, lds, st, a, K);
   TXM_LAUNCH_CHECK();
   return TXM_OK;
 }
 
-// what this kernel takes: full groups of 32 columns (C a multiple of 32), rows 16-byte aligned -- its lanes load
-// two columns as one 16-byte word.  Everything else stays on txm_resample_i8.hip (one kernel family per call, so that
-// all column groups of a state round their u-row sums the same way).
+// what this kernel takes: everything the one-power-per-column int8 path serves (8-byte loads: no alignment demand;
+// columns past C re-read column 0 and are never flushed)
 bool i8t_applicable(const double *x, int64_t ldx_s, int64_t C) {
-  return C % I8_CPAD == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && ldx_s % 2 == 0;
+  (void)x; (void)ldx_s; (void)C;
+  return true;
 }
 
-// one power per observable column (C > 16, or order 0): every order 0..7.  Unweighted: five row sets per pass, orders
-// 5..7 in two passes over the sampler stream (the matrix pipe paces a pass, so the split is by fragments: 3 + 3, 4 + 3,
-// 4 + 4 row sets).  Weighted launches stage a second 8 KiB tile (the weights) in LDS and hold four row sets at most:
-// order 4 takes 3 + 2.
+// one power per observable column (C > 16, or order 0): every order 0..7; five row sets per pass, orders 5..7 in two
+// passes over the sampler stream (the matrix pipe paces a pass, so the split is by fragments: 3 + 3, 4 + 3, 4 + 4).
 int launch_resample_i8t(const I8Args &a, int K, bool weighted, size_t prog_bytes, hipStream_t st) {
   int rc = TXM_OK;
 #define T_PASS(J0_, JN_) (weighted ? launch_pass_t<J0_, JN_, true>(a, K, prog_bytes, st) : launch_pass_t<J0_, JN_, false>(a, K, prog_bytes, st))
@@ -594,10 +613,7 @@ int launch_resample_i8t(const I8Args &a, int K, bool weighted, size_t prog_bytes
     case 2: rc = T_PASS(0, 2); break;
     case 3: rc = T_PASS(0, 3); break;
     case 4: rc = T_PASS(0, 4); break;
-    case 5:
-      if (weighted) { rc = launch_pass_t<0, 3, true>(a, K, prog_bytes, st); if (rc == TXM_OK) rc = launch_pass_t<3, 2, true>(a, K, prog_bytes, st); }
-      else rc = launch_pass_t<0, 5, false>(a, K, prog_bytes, st);
-      break;
+    case 5: rc = T_PASS(0, 5); break;
     case 6: rc = T_PASS(0, 3); if (rc == TXM_OK) rc = T_PASS(3, 3); break;
     case 7: rc = T_PASS(0, 4); if (rc == TXM_OK) rc = T_PASS(4, 3); break;
     case 8: rc = T_PASS(0, 4); if (rc == TXM_OK) rc = T_PASS(4, 4); break;

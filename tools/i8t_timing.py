@@ -28,7 +28,7 @@ nwin = -(-ntiles // win)
 g0 = -(-(1 + C) * 8 // 256) * 256
 off = g0 + nwin * 80 * 8
 t = prep.buf[off: off + 2 * 8 * 8 * 8].view(torch.float64).cpu().numpy().reshape(2, 8, 8)
-names = ["throttle", "zero+loads", "bar", "fill", "bar", "kstep", "bar(step)", "flush"]
+names = ["throttle", "stage+bar+zero", "bar", "fill", "bar", "ksteps", "tail", "flush"]
 for b in range(2):
     print("block", ["0", "133"][b])
     for w in range(8):
