@@ -181,11 +181,27 @@ def cpu_baseline(C, order, nrep_full, seconds, ncores):
     }
 
 
+def csrc_sha():
+    """sha256 (16 hex digits) over the kernel sources: ties a committed PMC figure to the code it was measured on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = ROOT / "thermoextrap_amd" / "csrc"
+    for f in sorted(list(d.glob("*.hip")) + list(d.glob("*.h"))):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel_prefix, shape):
     """HBM bytes per launch from the newest committed PMC summary of this workload (separate rocprofv3
-    --pmc passes of this same command, tools/collect_profiles.py) and the file it came from; (None, None)
-    if no committed profile matches this run's shape.  NOT measured in this run."""
+    --pmc passes of this same command, tools/collect_profiles.py) and the file it came from; (None, reason)
+    if no committed profile matches this run's shape AND the kernel sources it was measured on (`csrc_sha` in the
+    summary against the sources of this checkout: a PMC figure for other code is not reported).  NOT measured in this run."""
     import glob
+
+    sha = csrc_sha()
+    stale = None
 
     for f in sorted(glob.glob(str(ROOT / "profiles" / "*_traffic.json")), reverse=True):
         try:
@@ -196,13 +212,16 @@ def pmc_traffic(kernel_prefix, shape):
         got = (wl.get("n_samp", 100_000_000), wl.get("n_obs", 32), wl.get("order", 4), wl.get("nrep", 1000))
         if tuple(int(v) for v in got) != tuple(shape):
             continue
+        if d.get("csrc_sha") != sha:
+            stale = stale or f"profiles/{Path(f).name} was measured on other kernel sources (csrc_sha {d.get('csrc_sha')} != {sha})"
+            continue
         # several instantiations can share the prefix (e.g. the FP64 kernel's empty listed-mode launches): the
         # one that moved the most bytes is the kernel of this workload
         hits = [v.get("hbm_bytes_per_launch") for k, v in d.get("kernels", {}).items() if k.startswith(kernel_prefix)]
         hits = [h for h in hits if h is not None]
         if hits:
-            return max(hits), "profiles/" + Path(f).name
-    return None, None
+            return max(hits), f"profiles/{Path(f).name} (csrc_sha {sha})"
+    return None, stale
 
 
 def main():
@@ -293,14 +312,34 @@ def main():
 
     from thermoextrap_amd import moments as cm
 
+    phase_events = []  # per timed step: (start, after sampler, after bootstrap, after derivs + D2H)
+
+    def mark():
+        if not recording["on"]:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
     def one_bootstrap(n_rep, seed, rep0):
         # one sampler object per step (the tile-count kernel runs here), shared by the moments and the callback's <dx/dq>;
         # replicates rep0 .. rep0 + n_rep of the stream of `seed`: the gathered job equals one rank's result bit for bit
+        e0 = mark()
         smp = cm.factory_sampler({"nrep": n_rep, "device": True, "seed": seed, "rep0": rep0}, data=xv, dim="rec")
-        boot = xem.resample(sampler=smp)
-        results["derivs"] = boot.derivs(norm=False)  # host labelled array (order+1, rep, val)
+        e1 = mark()
         if dxdq is not None:
-            results["dxdq"] = engine.resample_vals(dxdq, u, 0, sampler=smp.device_sampler)[:, :, 1, 0]
+            # the volume callback's per-replicate <dx/dq>: the second sample matrix of the same call (txm_resample_opts.y)
+            st, results["dxdq"] = engine.resample_vals(x, u, order, sampler=smp.device_sampler, y=dxdq,
+                                                       prep=data._cache.setdefault("resample_prep", engine.ResamplePrep()))
+            boot = xem.new_like(data=data.new_like(dxduave=cm.CentralMomentsData(st, mom_ndim=2, dims=("rep", "val", "xmom", "umom")),
+                                                   rec_dim="rep"))
+        else:
+            boot = xem.resample(sampler=smp)
+        e2 = mark()
+        results["derivs"] = boot.derivs(norm=False)  # host labelled array (order+1, rep, val)
+        e3 = mark()
+        if e0 is not None:
+            phase_events.append((e0, e1, e2, e3))
         return boot.data.dxduave.device_values
 
     def step(i):
@@ -330,13 +369,19 @@ def main():
     ms_per_step = 1e3 * dt / args.steps
     value = (1 if replicas else world) * N / (dt / args.steps)
     nrep_rank = len(txd.shard_range(nrep, rank, world)) if replicas else nrep
-    main_calls = [a.elapsed_time(b) for a, b in boot_events[:: (2 if dxdq is not None else 1)]]
+    main_calls = [a.elapsed_time(b) for a, b in boot_events]
     t_boot = sum(main_calls) / max(len(main_calls), 1)
-    t_dxdq = None
-    if dxdq is not None:
-        d = [a.elapsed_time(b) for a, b in boot_events[1::2]]
-        t_dxdq = sum(d) / max(len(d), 1)
-    info = engine.resample_info(N, C, nrep_rank, order)
+    info = engine.resample_info()
+    nph = max(len(phase_events), 1)
+    ph = [sum(ev[i].elapsed_time(ev[i + 1]) for ev in phase_events) / nph for i in range(3)]
+    step_breakdown = {
+        "sampler_tile_counts": ph[0],
+        "bootstrap_call": ph[1],   # txm_resample_vals through the API: (pre-pass unless reused) + contraction + finalize
+        "prepass_reused": bool(info.get("prep_reused")),
+        "derivs_and_d2h": ph[2],
+        "host_and_gather": max(ms_per_step - sum(ph), 0.0),
+        "how": "HIP events on the launch stream inside the timed steps; host_and_gather = wall clock per step minus the events",
+    }
 
     # ---- separate event timings of the other kernels of a step (same stream) -------
     def timed(fn, reps):
@@ -399,21 +444,30 @@ def main():
         # passes as (row sets, u-row monomials): one power per column, five powers per pass (txm_resample_i8.hip:
         # launch_resample_i8), or -- narrow states -- four (C <= 8) / two (C <= 16) powers per observable column
         if C <= 16 and K >= 2:
+            # narrow states (txm_resample_i8.hip): four (C <= 8) / two (C <= 16) powers per observable column; per
+            # workgroup and k-step 4 tiles per pair row (two digits x two replicate halves), 2 per plain fragment
             pk = 4 if C <= 8 else 2
             jn = -(-K // pk)
-            passes = [(jn, min(K, jn * pk))]
+            n_mfma = 4 * 3 * jn + 2 * (jn + -(-8 * min(K, jn * pk) // 32))
+            kname = "txm::resample_i8_kernel"
+            kdesc = ("bootstrap contraction on the int8 matrix pipe by exact 7-digit fixed-point slicing, several powers "
+                     "per observable column, Philox stage 3 fused")
         else:
-            passes = [(jn, jn) for jn in {1: [1], 2: [2], 3: [3], 4: [4], 5: [5], 6: [5, 1], 7: [5, 2], 8: [5, 3]}[K]]
-        # v_mfma_i32_32x32x32_i8 per workgroup and k-step (32 samples x 64 replicates), all passes: 4 tiles per pair
-        # row (two digits x two replicate halves), 2 per plain fragment (digit 6 of a row set, packed u-row columns)
-        n_mfma = sum(4 * 3 * jn + 2 * (jn + -(-8 * kl // 32)) for jn, kl in passes)
+            # one power per column (txm_resample_i8t.hip): per workgroup (8 waves x 64 replicates) and k-step of 32
+            # samples, every wave contracts its column quad of every row set for both replicate halves (2 JN MFMAs) and
+            # 2 ceil(JN / 4) waves one u-row tile; orders 5..7 take two passes over the sampler stream
+            passes = {1: [1], 2: [2], 3: [3], 4: [4], 5: [5], 6: [3, 3], 7: [4, 3], 8: [4, 4]}[K]
+            n_mfma = sum(16 * jn + 2 * -(-jn // 4) for jn in passes)
+            kname = "txm::resample_i8t_kernel"
+            kdesc = ("bootstrap contraction on the int8 matrix pipe: 51-bit fixed-point words sliced once per sample, "
+                     "byte-transposed by the LDS transposing read (ds_read_b64_tr_b8: 8 digit slots per word, 7 used), "
+                     "exact int32 accumulation, Philox stage 3 fused")
         ksteps = -(-nrep_rank // 64) * (-(-N // 1024) * 32) * -(-C // 32)   # replicate groups x k-steps x column groups
         i8_ops = 2.0 * 32 * 32 * 32 * n_mfma * ksteps
         tops = i8_ops / (t_boot * 1e-3) / 1e12
-        tr, src = pmc_traffic("txm::resample_i8_kernel", shape)
+        tr, src = pmc_traffic(kname, shape)
         roofline = {
-            "kernel": "txm::resample_i8_kernel (bootstrap contraction on the int8 matrix pipe by exact 7-digit "
-                      "fixed-point slicing, Philox stage 3 fused) + window-scale/guard, memset and finalize kernels",
+            "kernel": f"{kname} ({kdesc}) + pre-pass (unless reused) and finalize kernels",
             "bound": "mfma-i8", "pipe": "int8",
             "achieved": tops, "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": tops / INT8_PEAK_TOPS,
             "traffic": tr, "traffic_source": src,
@@ -426,8 +480,8 @@ def main():
             "guard_windows": info["windows"], "guard_windows_fp64": info["windows_fp64"],
             "note": "achieved = EXECUTED v_mfma_i32_32x32x32_i8 operations per second against the dense int8 peak "
                     "(2x bf16 = 5 POP/s); fp64_equiv_tflops = the algorithmic FP64 flops 2*N*nrep*K*(N_obs+1) per "
-                    "second -- a speed, not a fraction of any roof.  The kernel is bound by the VALU + LDS-write work "
-                    "of slicing the data operand, not by the matrix pipe (DESIGN.md 4.2b)",
+                    "second -- a speed, not a fraction of any roof.  12.5 % of the executed MFMA columns are the dead "
+                    "eighth digit slot of the 8-byte word (DESIGN.md 4.2b)",
         }
         if t_fp64 is not None:
             roofline_fp64 = fp64_block(t_fp64, "txm::resample_kernel (the same shape forced onto the FP64 MFMA kernel, "
@@ -449,6 +503,20 @@ def main():
         "samples_per_s": N / (t_red * 1e-3),
     }
 
+    # which GPU every rank ran on (evidence of the rank count under RCCL: one distinct device per rank)
+    ranks_seen = None
+    try:
+        props = torch.cuda.get_device_properties(torch.cuda.current_device())
+        ident = f"{getattr(props, 'uuid', '')}|{getattr(props, 'pci_bus_id', '')}|{torch.cuda.current_device()}"
+        if world > 1:
+            objs = [None] * world
+            dist.all_gather_object(objs, ident)
+            ranks_seen = objs
+        else:
+            ranks_seen = [ident]
+    except Exception as exc:  # noqa: BLE001
+        ranks_seen = [f"unavailable: {exc}"]
+
     if rank == 0:
         par = f"replicate-slabs x{world} (nrep/{world} per GPU, same state point)" if replicas else f"state-points x{world}"
         rec = {
@@ -469,11 +537,12 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.config}: central-comoment bootstrap, N_samp={N:.0e}, N_obs={C}, order={order}, nrep={nrep}, "
-                            "exact multinomial device sampler" + (", + order-0 bootstrap of dx/dq" if dxdq is not None else ""),
+                            "exact multinomial device sampler" + (", + per-replicate <dx/dq> on the same draw" if dxdq is not None else ""),
                 "n_samp": N, "n_obs": C, "order": order, "nrep": nrep,
                 "parallelism": par,
             },
             "replicate_samples_per_s": value * nrep,
+            "ranks_seen": ranks_seen,
             "sampler_ms": t_samp,
             "roofline": roofline,
             "roofline_reduce": roofline_reduce,
@@ -482,8 +551,7 @@ def main():
             rec["roofline_fp64_path"] = roofline_fp64
         if parity is not None:
             rec["parity_check"] = parity
-        if t_dxdq is not None:
-            rec["dxdq_bootstrap_ms"] = t_dxdq
+        rec["step_breakdown_ms"] = step_breakdown
         if world == 1 and not args.no_cpu_baseline:
             nthr = args.cpu_threads or min(os.cpu_count() or 1, 16)
             rec["cpu_baseline"] = cpu_baseline(C, order, nrep, args.cpu_seconds, nthr)

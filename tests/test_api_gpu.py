@@ -239,6 +239,13 @@ def test_predict_taylor_modes_definition(xtrap):
         engine.predict_taylor(torch.zeros((17, 3), dtype=torch.float64, device="cuda"), da)
     with pytest.raises(ValueError):
         engine.predict_taylor(dev, da, "mean")
+    # more alpha values than one launch's 16-bit grid axis carries (round-2 advice): sliced, same numbers
+    many = np.linspace(-1.0, 1.0, 70_001)
+    small = torch.as_tensor(d[:4, :2, :3].copy()).cuda()
+    got = engine.predict_taylor(small, many, "sum").cpu().numpy()
+    pw2 = many[:, None] ** np.arange(4)[None, :]
+    want = np.einsum("ak,kij->aij", pw2 * fac[None, :4], d[:4, :2, :3])
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-13)
 
 
 def test_dataset_observables(fixture, xtrap):

@@ -224,6 +224,22 @@ def test_c3_sixteen_states_x_is_u_fullsize(txm, eng, orc):
         assert (np.abs(got[s] - want_s) / (np.abs(want_s) + scs)).max() < 1e-12
 
 
+def test_gp_input_with_a_sampler_the_batched_path_does_not_take(txm, eng):
+    """input_GP_from_states with an {"indices": ...} mapping: StateCollection.resample runs its per-state loop for it, so
+    there is no batch to evaluate in one launch -- the builder must fall back to the per-state function (round-2 advice:
+    it used to fail with a TypeError on the missing batch)."""
+    xtrap = txm
+    S, N, C, order, nrep = 3, 1500, 2, 2, 6
+    coll, xs, us, _ = _collection(xtrap, S, N, C, order, 77)
+    idx = np.random.default_rng(3).integers(0, N, size=(nrep, N))
+    x_all, y_all, cov_all = xtrap.gpr_input.input_GP_from_states(coll, sampler={"indices": idx})
+    n_ord = order + 1
+    assert x_all.shape == (S * n_ord, 2) and y_all.shape == (S * n_ord, C) and cov_all.shape == (C, S * n_ord, S * n_ord)
+    one = xtrap.gpr_input.input_GP_from_state(coll[1], sampler={"indices": idx})
+    np.testing.assert_allclose(cov_all[:, n_ord:2 * n_ord, n_ord:2 * n_ord], one[2], rtol=1e-12)
+    np.testing.assert_allclose(y_all[n_ord:2 * n_ord], one[1], rtol=1e-13)
+
+
 def test_c5_sixty_four_states_gp_input_fullsize(txm, eng):
     """BASELINE config 5: 64 state points, order 3, nrep = 100: bootstrap of all states in one launch, derivatives in
     one evaluation, covariance over replicates in one launch; checked against np.cov of the per-state replicate

@@ -553,8 +553,8 @@ __global__ __launch_bounds__(256) void resample_finalize_kernel(
   for (int q = 0; q < 2 * K; ++q) o[q] = st[q];
 }
 
-// finalize of the int8 path: one slot of partial sums per scaling window, [window][replicate][power][column][8 digit
-// slots] (u-row: [window][replicate][power][8]); windows in ascending order, digits in ascending order -- a fixed order
+// finalize of the int8 path: one slot of partial sums per scaling window, [window][replicate][power][8 digit slots]
+// [column] (u-row: [window][replicate][power][8]); windows in ascending order, digits in ascending order -- a fixed order
 // that does not depend on the launch geometry.  Windows the precision guard flagged hold nothing: they were contracted
 // by the FP64 kernel, whose sums are added behind (same pivot).
 template <int K>
@@ -564,25 +564,49 @@ __global__ __launch_bounds__(256) void resample_finalize_i8_kernel(
     const double *__restrict__ pivot, double *__restrict__ out, int64_t c_off, int64_t C_total,
     const double *__restrict__ fb_x, const double *__restrict__ fb_u, int fb_chunks, int64_t fb_cpad,
     const uint32_t *__restrict__ n_list) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nrep * C) return;
-  const int64_t r = e / C, c = e % C;
+  // one workgroup per replicate: thread = (column c, window segment seg of 8).  Segment seg adds the windows
+  // seg, seg + 8, ... in ascending order, then the eight segments are added in order: a fixed tree that depends on the
+  // number of windows (i.e. on N) only.  (One thread per output walking all windows was latency-bound on short series
+  // with few outputs: 1600 threads x 611 windows at BASELINE config 2.)
+  constexpr int NSEG = 8;
+  __shared__ double sh[NSEG][32][2 * K];
+  const int64_t r = blockIdx.x;
+  const int c = threadIdx.x & 31, seg = threadIdx.x >> 5;
   double S0[K], S1[K];
 #pragma unroll
   for (int j = 0; j < K; ++j) S0[j] = S1[j] = 0.0;
-  for (int64_t w = 0; w < nwin; ++w) {
-    if (wflag[w] != 0u) continue;
-    const double *pu_ = part_u + ((size_t)w * nrep_pad + r) * K * 8;
-    const double *px_ = part_x + (((size_t)w * nrep_pad + r) * K * I8_CPAD + c) * 8;
+  if (c < C) {
+    for (int64_t w = seg; w < nwin; w += NSEG) {
+      if (wflag[w] != 0u) continue;
+      const double *pu_ = part_u + ((size_t)w * nrep_pad + r) * K * 8;
+      const double *px_ = part_x + ((size_t)w * nrep_pad + r) * K * 8 * I8_CPAD + c;
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-      const double4 ua = *reinterpret_cast<const double4 *>(pu_ + j * 8), ub = *reinterpret_cast<const double4 *>(pu_ + j * 8 + 4);
-      const double4 xa = *reinterpret_cast<const double4 *>(px_ + (size_t)j * I8_CPAD * 8),
-                    xb = *reinterpret_cast<const double4 *>(px_ + (size_t)j * I8_CPAD * 8 + 4);
-      S0[j] += ((((((ua.x + ua.y) + ua.z) + ua.w) + ub.x) + ub.y) + ub.z);  // digit slots 0..6, ascending
-      S1[j] += ((((((xa.x + xa.y) + xa.z) + xa.w) + xb.x) + xb.y) + xb.z);
+      for (int j = 0; j < K; ++j) {
+        const double4 ua = *reinterpret_cast<const double4 *>(pu_ + j * 8), ub = *reinterpret_cast<const double4 *>(pu_ + j * 8 + 4);
+        const double *q = px_ + (size_t)j * 8 * I8_CPAD;
+        S0[j] += ((((((ua.x + ua.y) + ua.z) + ua.w) + ub.x) + ub.y) + ub.z);  // digit slots 0..6, ascending
+        S1[j] += ((((((q[0] + q[I8_CPAD]) + q[2 * I8_CPAD]) + q[3 * I8_CPAD]) + q[4 * I8_CPAD]) + q[5 * I8_CPAD]) + q[6 * I8_CPAD]);
+      }
     }
   }
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    sh[seg][c][j] = S0[j];
+    sh[seg][c][K + j] = S1[j];
+  }
+  __syncthreads();
+  if (seg != 0 || c >= C) return;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    S0[j] = sh[0][c][j];
+    S1[j] = sh[0][c][K + j];
+  }
+  for (int g = 1; g < NSEG; ++g)
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      S0[j] += sh[g][c][j];
+      S1[j] += sh[g][c][K + j];
+    }
   // windows the precision guard handed to the FP64 kernel (same pivot: the sums simply add)
   if (n_list[0] != 0u)
     for (int ch = 0; ch < fb_chunks; ++ch) {
@@ -599,6 +623,7 @@ __global__ __launch_bounds__(256) void resample_finalize_i8_kernel(
   double *o = out + (r * C_total + c_off + c) * 2 * K;
 #pragma unroll
   for (int q = 0; q < 2 * K; ++q) o[q] = st[q];
+  (void)nrep;
 }
 
 struct ResamplePlan {
@@ -1027,9 +1052,8 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
         const int rc2 = run_listed(f, q.fb, K, w != nullptr, st);
         if (rc2 != TXM_OK) return rc2;
       }
-      const int64_t ne = nrep * b.C;
 #define TXM_I8_FIN(KK)                                                                                 \
-  hipLaunchKernelGGL((resample_finalize_i8_kernel<KK>), dim3((unsigned)cdiv(ne, 256)), dim3(256), 0, st, \
+  hipLaunchKernelGGL((resample_finalize_i8_kernel<KK>), dim3((unsigned)nrep), dim3(256), 0, st,          \
                      b.part_x, b.part_u, q.nwin, b.wflag, q.nrep_pad, nrep, b.C, piv, out, col0, C,        \
                      f.part_x, f.part_u, q.fb.n_chunks, q.fb.C_pad, b.n_list)
       switch (K) {

@@ -45,7 +45,7 @@ struct I8Args {
   // partial sums: ONE SLOT PER SCALING WINDOW, written once (no read-modify-write, no zeroing; the finalize kernel
   // skips the windows the guard flagged and adds the rest in window order, so a replicate's sums do not depend on the
   // launch geometry)
-  double *part_x;          // [nwin][nrep_pad][K][32 columns][8 digit slots]
+  double *part_x;          // [nwin][nrep_pad][K][8 digit slots][32 columns]
   double *part_u;          // [nwin][nrep_pad][K][8 digit slots]
   int n_chunks, n_rbg;
   int64_t tiles_per_chunk; // multiple of win_tiles

@@ -584,13 +584,13 @@ __global__ __launch_bounds__(I8_BLOCK) void resample_i8_kernel(const I8Args a) {
     }
     double dsc = wt[I8_WT_DSP + j] * (urow_f >= 0 ? 0x1p-50 : wt[I8_WT_DSC + col]);
     dsc *= (double)((int64_t)1 << (8 * i));
-    // one slot per scaling window: [window][replicate][power][column][digit slot] (u-row: [window][replicate][power]
-    // [digit slot]), stored once and added up by the finalize kernel in window order -- a replicate's sums do not depend
+    // one slot per scaling window: [window][replicate][power][digit slot][column] (u-row: [window][replicate][power]
+    // [digit slot]; the 32 lanes of a tile row write 256 contiguous bytes), stored once and added up by the finalize kernel in window order -- a replicate's sums do not depend
     // on how the launch was cut into chunks (txm_resample_i8t.hip has the same layout)
     double *base;
     int64_t stride;
     if (urow_f < 0) {
-      base = a.part_x + ((((size_t)fwin * a.nrep_pad + rep0 + 32 * h + 4 * half) * K + j) * I8_CPAD + col) * 8 + i + opq;
+      base = a.part_x + ((((size_t)fwin * a.nrep_pad + rep0 + 32 * h + 4 * half) * K + j) * 8 + i) * I8_CPAD + col + opq;
       stride = (int64_t)K * I8_CPAD * 8;
     } else {
       base = a.part_u + (((size_t)fwin * a.nrep_pad + rep0 + 32 * h + 4 * half) * K + j) * 8 + i + opq;

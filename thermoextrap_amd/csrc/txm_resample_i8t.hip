@@ -29,7 +29,7 @@
 // with ONE LANE PER REPLICATE (lane = replicate, the eight waves split the Philox calls): all 64 lanes of a ds_add hit
 // 64 consecutive words -- no bank conflict by construction (the old layout lost 11 cycles per ds_add to conflicts).
 // Partial sums: one slot per SCALING WINDOW (a fixed block of samples: the window size depends on N only),
-// part[window][replicate][power][column][digit slot], stored once -- no read-modify-write, no zeroing -- and added up
+// part[window][replicate][power][digit slot][column], stored once -- no read-modify-write, no zeroing -- and added up
 // by the finalize kernel in window order.  A replicate's result therefore does not depend on how many replicates,
 // chunks or workgroups the launch had: rows [a, b) of a bootstrap equal the (b - a)-replicate call with rep0 = a
 // bit for bit (multi-GPU slabs, txm_sampler_spec.rep0).
@@ -373,8 +373,8 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         valid = valid && c < a.C;
         j = J0 + rs;
         dsc = wt[I8_WT_DSP + j] * wt[I8_WT_DSC + (c < a.C ? c : 0)];
-        // [window][replicate][power][column][digit slot]
-        base = a.part_x + ((((size_t)win * a.nrep_pad + rep0 + 32 * h + 4 * half) * K + j) * I8_CPAD + c) * 8 + tdg + opq;
+        // [window][replicate][power][digit slot][column]
+        base = a.part_x + ((((size_t)win * a.nrep_pad + rep0 + 32 * h + 4 * half) * K + j) * 8 + tdg) * I8_CPAD + c + opq;
       } else {
         const int m = 4 * ufrag + tcl;
         valid = valid && m < JN;

@@ -548,8 +548,12 @@ def predict_taylor(derivs: torch.Tensor, dalphas, mode: str = "sum") -> torch.Te
         raise ValueError("predict_taylor: empty input")
     shape = (na, *d.shape[1:]) if mode == "sum" else (na, n_ord, *d.shape[1:])
     out = torch.empty(shape, dtype=F64, device="cuda")
-    check(L.txm_predict_taylor(_ptr(d), n_ord, M, _ptr(da), na, TAYLOR_MODES[mode], _ptr(out), _stream()),
-          "txm_predict_taylor")
+    # the kernel carries alpha on a 16-bit grid axis: more than 65535 alpha values go in slices (same launch shape)
+    step = 65535
+    for a0 in range(0, na, step):
+        a1 = min(na, a0 + step)
+        check(L.txm_predict_taylor(_ptr(d), n_ord, M, _ptr(da[a0:a1]), a1 - a0, TAYLOR_MODES[mode], _ptr(out[a0:a1]),
+                                   _stream()), "txm_predict_taylor")
     return out
 
 

@@ -89,11 +89,14 @@ def input_GP_from_states(states, n_rep=100, log_scale=False, sampler=None):  # n
     coll = states if isinstance(states, StateCollection) else StateCollection(list(states))
     spec = sampler if sampler is not None else {"nrep": n_rep}
     S = len(coll)
-    if coll._batch_eligible() is None or not isinstance(spec, dict):
+    # the one-launch path needs what StateCollection.resample batches: states of one shape and a {"nrep": n, ...}
+    # mapping (an {"indices": ...} / {"freq": ...} mapping goes through the per-state loop there, and here)
+    is_spec = isinstance(spec, dict) and "nrep" in spec and "indices" not in spec and "freq" not in spec
+    boot = coll.resample(spec) if (coll._batch_eligible() is not None and is_spec) else None
+    if boot is None or getattr(boot, "_batch", None) is None:
         parts = [input_GP_from_state(st, n_rep=n_rep, log_scale=log_scale, sampler=sampler) for st in coll]
     else:
         order = coll.order
-        boot = coll.resample(spec)
         vals, _ = boot._derivs_batched(order=order, norm=False, _device=True)      # (order+1, S, nrep, n_out)
         n_ord, _, nrep, n_out = vals.shape
         cov = engine.cov_over_rep(vals.permute(0, 2, 1, 3).reshape(n_ord, nrep, S * n_out))  # (S*n_out, n_ord, n_ord)

@@ -64,7 +64,10 @@ workload = {"n_samp": 100_000_000, "n_obs": 32, "order": 4, "nrep": 1000}
 for a in sys.argv[2:]:  # e.g. n_samp=1e8 order=6
     k, v = a.split("=")
     workload[k] = int(float(v))
-json.dump({"tag": tag, "workload": workload,
+sys.path.insert(0, str(root))
+from bench import csrc_sha  # noqa: E402
+
+json.dump({"tag": tag, "workload": workload, "csrc_sha": csrc_sha(),
            "command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline (one rocprofv3 --pmc pass per counter)",
            "note": "FETCH_SIZE x2 correction per MI355X_MICROARCH.md (calibrated for 16 B/lane streams; "
            "the bootstrap kernel's 8 B/lane x loads are uncalibrated, so its figure is an upper bound)",
