@@ -357,38 +357,55 @@ int orc_indices_to_freq(const int64_t *idx, int64_t nrep, int64_t nsamp, int64_t
  * definition (data.py:1233-1236 docstring of from_data).
  * freq may be NULL (plain reduce) or a [N] row of counts.
  * ------------------------------------------------------------------------- */
+static void truth_cov_one(const double *x, int64_t ldx_s, int64_t ldx_c, const double *u, const double *w,
+                          const int64_t *freq, int64_t N, int64_t c, int order, double *o) {
+  const int K = order + 1;
+  long double W = 0, sx = 0, su = 0;
+  for (int64_t i = 0; i < N; ++i) {
+    long double wi = (w ? w[i] : 1.0L) * (freq ? (long double)freq[i] : 1.0L);
+    W += wi;
+    sx += wi * x[i * ldx_s + c * ldx_c];
+    su += wi * u[i];
+  }
+  long double mx = sx / W, mu = su / W;
+  long double acc[2][MAXK];
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < K; ++b) acc[a][b] = 0;
+  for (int64_t i = 0; i < N; ++i) {
+    long double wi = (w ? w[i] : 1.0L) * (freq ? (long double)freq[i] : 1.0L);
+    if (wi == 0) continue;
+    long double dx = x[i * ldx_s + c * ldx_c] - mx, du = u[i] - mu, p = wi;
+    for (int b = 0; b < K; ++b) {
+      acc[0][b] += p;
+      acc[1][b] += p * dx;
+      p *= du;
+    }
+  }
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < K; ++b) o[a * K + b] = (double)(acc[a][b] / W);
+  o[0] = (double)W;
+  o[K] = (double)mx;
+  if (K > 1) o[1] = (double)mu;
+}
+
 void orc_truth_cov(const double *x, int64_t ldx_s, int64_t ldx_c, const double *u,
                    const double *w, const int64_t *freq, int64_t N, int64_t C, int order,
                    double *out) {
   const int K = order + 1;
-  for (int64_t c = 0; c < C; ++c) {
-    long double W = 0, sx = 0, su = 0;
-    for (int64_t i = 0; i < N; ++i) {
-      long double wi = (w ? w[i] : 1.0L) * (freq ? (long double)freq[i] : 1.0L);
-      W += wi;
-      sx += wi * x[i * ldx_s + c * ldx_c];
-      su += wi * u[i];
-    }
-    long double mx = sx / W, mu = su / W;
-    long double acc[2][MAXK];
-    for (int a = 0; a < 2; ++a)
-      for (int b = 0; b < K; ++b) acc[a][b] = 0;
-    for (int64_t i = 0; i < N; ++i) {
-      long double wi = (w ? w[i] : 1.0L) * (freq ? (long double)freq[i] : 1.0L);
-      if (wi == 0) continue;
-      long double dx = x[i * ldx_s + c * ldx_c] - mx, du = u[i] - mu, p = wi;
-      for (int b = 0; b < K; ++b) {
-        acc[0][b] += p;
-        acc[1][b] += p * dx;
-        p *= du;
-      }
-    }
-    double *o = out + c * 2 * K;
-    for (int a = 0; a < 2; ++a)
-      for (int b = 0; b < K; ++b) o[a * K + b] = (double)(acc[a][b] / W);
-    o[0] = (double)W;
-    o[K] = (double)mx;
-    if (K > 1) o[1] = (double)mu;
+  for (int64_t c = 0; c < C; ++c) truth_cov_one(x, ldx_s, ldx_c, u, w, freq, N, c, order, out + c * 2 * K);
+}
+
+/* R frequency rows at once, out [R][C][2][K]; the (row, column) pairs are independent: threads over them (the
+   arithmetic of one pair is exactly orc_truth_cov's) */
+void orc_truth_cov_multi(const double *x, int64_t ldx_s, int64_t ldx_c, const double *u, const double *w,
+                         const int64_t *freq, int64_t R, int64_t N, int64_t C, int order, int nthreads,
+                         double *out) {
+  const int K = order + 1;
+  const int64_t tasks = R * C;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
+  for (int64_t t = 0; t < tasks; ++t) {
+    const int64_t r = t / C, c = t % C;
+    truth_cov_one(x, ldx_s, ldx_c, u, w, freq + r * N, N, c, order, out + (r * C + c) * 2 * K);
   }
 }
 

@@ -217,6 +217,24 @@ def truth_cov(x, u, order, w=None, freq_row=None):
     return out[0] if squeeze else out
 
 
+def truth_cov_multi(x, u, order, freq_rows, w=None, nthreads=0):
+    """truth_cov for R frequency rows at once: (R, C, 2, K); (row, column) pairs on `nthreads` threads (0: all cores).
+    The arithmetic of every pair is exactly truth_cov's."""
+    import os
+
+    x2 = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(len(u), -1))
+    u = _f64(u)
+    fr = np.ascontiguousarray(freq_rows, dtype=np.int64)
+    R, N = fr.shape
+    C = x2.shape[1]
+    out = np.zeros((R, C, 2, order + 1))
+    wp = _d(_f64(w)) if w is not None else None
+    nt = nthreads or min(os.cpu_count() or 1, R * C)
+    lib().orc_truth_cov_multi(_d(x2), ct.c_int64(C), ct.c_int64(1), _d(u), wp, _i(fr), ct.c_int64(R), ct.c_int64(N),
+                              ct.c_int64(C), ct.c_int(order), ct.c_int(nt), _d(out))
+    return out
+
+
 def truth_1d(u, mom, w=None, freq_row=None):
     u = _f64(u)
     out = np.zeros(mom + 1)

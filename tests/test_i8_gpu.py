@@ -193,7 +193,12 @@ def test_guard_sends_outlier_windows_to_fp64(eng, orc, C):
     with eng.forced_path("int8"):
         g1 = eng.resample_vals(xc, uc, order, sampler=s)
         g2 = eng.resample_vals(xc, uc, order, sampler=s, pivot=piv)
-    assert err(g2, g1, sc_clean[None]) < 5e-6
+    # the pivot-shifted monomials are up to (1 + 2)^4 (1 + 3) ~ 3e2 times the central ones and the window scale grows with
+    # them: the model bound is ~3e2 x the int8 path's 1e-13 x the cancellation of the back-shift (another ~3e2) ~ 1e-8
+    # (round 2 asserted 5e-6 without having measured; measured on MI355X, printed: see the log line)
+    e_far = err(g2, g1, sc_clean[None])
+    print(f"far-pivot error (int8 path): {e_far:.3e}")
+    assert e_far < 1e-8
 
 
 @pytest.mark.parametrize("kind", ["student_t3", "lognormal_u", "weights_1e-8", "all_windows_flagged"])

@@ -97,7 +97,9 @@ __device__ __forceinline__ void t_fill_call(uint32_t *cntw, uint32_t k0, uint32_
                                             uint32_t n, uint32_t lane4) {
   // lane = replicate: counter word 2 differs per lane, words 0, 1, 3 are wave-uniform
   const uint32_t first = c * 12u;
-  const Philox4 o = philox4x32_10(t, c, rs, 3u, k0, k1);
+  // (XOR3: the two XORs of a Philox round as one v_bitop3_b32 -- 3 % of the kernel here; it lost in the old kernel's
+  // fused fill, txm_sampler.h)
+  const Philox4 o = philox4x32_10<true>(t, c, rs, 3u, k0, k1);
 #pragma unroll
   for (int wi = 0; wi < 4; ++wi) {
     const uint32_t word = o.w[wi];
@@ -192,6 +194,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   for (int e = threadIdx.x; e < T_WAVES * WREG / 16; e += T_BLOCK) reinterpret_cast<uint4 *>(lds)[e] = make_uint4(0, 0, 0, 0);
 
   // stage-3 role: lane = replicate
+  // (static priority for waves 4..7 was measured: +3 % time; nothing to arbitrate without a barrier per k-step)
   const int64_t my_rep = rep0 + lane;
   const bool rep_live = my_rep < a.nrep;
   const uint32_t rstream = a.rep_base + (uint32_t)my_rep;
