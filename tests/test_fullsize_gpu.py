@@ -298,7 +298,9 @@ def test_second_matrix_vs_oracle_fullsize(eng, orc):
     """<dx/dq> of the volume callback at the c4 size (reference volume.py:121-134: dxdqv[sampler.indices].mean per
     replicate): the per-replicate means of a second N = 1e8 x 32 matrix from the same call (txm_resample_opts.y),
     int8 dispatch, against the oracle's extended-precision weighted mean on the materialised frequency rows of eight
-    seeded replicates x four seeded columns; and bitwise against a separate order-0 bootstrap of that matrix."""
+    seeded replicates x four seeded columns.  At order 2 the matrix rides the int8 kernel's one pass as an extra row set
+    (two trips over the sampler stream per c4 step instead of three); a separate order-0 bootstrap of the same matrix
+    slices the same integers, so the two agree to the last few ulps of the mean (asserted at 1e-14 of its scale)."""
     N, C, nrep, order, seed = 100_000_000, 32, 1000, 2, 424243
     x, u = synth(N, C, 37)
     y, _ = synth(N, C, 38)
@@ -306,7 +308,10 @@ def test_second_matrix_vs_oracle_fullsize(eng, orc):
     st, ym = eng.resample_vals(x, u, order, sampler=smp, y=y)
     assert eng.resample_info()["path"] == "int8" and ym.shape == (nrep, C)
     sep = eng.resample_vals(y, u, 0, sampler=smp)
-    assert torch.equal(ym, sep[:, :, 1, 0])
+    scale = sep[:, :, 1, 0].abs() + y[:1_000_000].std()
+    dsep = ((ym - sep[:, :, 1, 0]).abs() / scale).max().item()
+    print(f"<dx/dq>: fused row set vs separate order-0 bootstrap {dsep:.3e}")
+    assert dsep <= 1e-14, dsep
     reps, cols = _seeded_reps_cols(nrep, C, seed)
     freq = _freq_rows(eng, seed, reps, N)
     yh = y[:, cols].contiguous().cpu().numpy()

@@ -626,6 +626,46 @@ __global__ __launch_bounds__(256) void resample_finalize_i8_kernel(
   (void)nrep;
 }
 
+// the second sample matrix: per-replicate weighted means  out_y[r][c] = py[c] + S1y / S0  from the per-window slots
+// written by the y row set (same fixed tree as above), the sum of weights S0 from the u-row slots (power 0)
+__global__ __launch_bounds__(256) void resample_finalize_y_kernel(
+    const double *__restrict__ part_y, const double *__restrict__ part_u, int K, int64_t nwin,
+    const uint32_t *__restrict__ wflag, int64_t nrep_pad, int64_t C, const double *__restrict__ ypivot,
+    double *__restrict__ out_y, int64_t c_off, int64_t C_total, const double *__restrict__ fb_y,
+    const double *__restrict__ fb_u, int fb_chunks, int64_t fb_cpad, const uint32_t *__restrict__ n_list) {
+  constexpr int NSEG = 8;
+  __shared__ double sh[NSEG][32][2];
+  const int64_t r = blockIdx.x;
+  const int c = threadIdx.x & 31, seg = threadIdx.x >> 5;
+  double S0 = 0.0, S1 = 0.0;
+  if (c < C) {
+    for (int64_t w = seg; w < nwin; w += NSEG) {
+      if (wflag[w] != 0u) continue;
+      const double *pu_ = part_u + ((size_t)w * nrep_pad + r) * K * 8;
+      const double *q = part_y + ((size_t)w * nrep_pad + r) * 8 * I8_CPAD + c;
+      const double4 ua = *reinterpret_cast<const double4 *>(pu_), ub = *reinterpret_cast<const double4 *>(pu_ + 4);
+      S0 += ((((((ua.x + ua.y) + ua.z) + ua.w) + ub.x) + ub.y) + ub.z);
+      S1 += ((((((q[0] + q[I8_CPAD]) + q[2 * I8_CPAD]) + q[3 * I8_CPAD]) + q[4 * I8_CPAD]) + q[5 * I8_CPAD]) + q[6 * I8_CPAD]);
+    }
+  }
+  sh[seg][c][0] = S0;
+  sh[seg][c][1] = S1;
+  __syncthreads();
+  if (seg != 0 || c >= C) return;
+  S0 = sh[0][c][0];
+  S1 = sh[0][c][1];
+  for (int g = 1; g < NSEG; ++g) {
+    S0 += sh[g][c][0];
+    S1 += sh[g][c][1];
+  }
+  if (n_list[0] != 0u)
+    for (int ch = 0; ch < fb_chunks; ++ch) {
+      S0 += fb_u[((size_t)ch * nrep_pad + r) * K];
+      S1 += fb_y[((size_t)ch * nrep_pad + r) * fb_cpad + c];
+    }
+  out_y[r * C_total + c_off + c] = ypivot[1 + c_off + c] + S1 * (1.0 / S0);  // as pivot_sums_to_state forms a mean
+}
+
 struct ResamplePlan {
   int nblk, colgroups, n_rbg, n_chunks;
   int64_t tiles_per_chunk, nrep_pad, C_pad, ntiles;
@@ -667,6 +707,9 @@ struct I8Plan {
   // precision-guard fallback: the FP64 kernel's plan / partial sums for one column group
   int sub_tiles;
   size_t off_fbx, off_fbu, off_prog, prog_bytes, off_stats, off_prep;
+  // second sample matrix (txm_resample_opts.y) carried by the int8 kernel: its per-window partial sums, the FP64
+  // fallback's sums for it, the sums themselves [nrep][C] (2 doubles each) and its pre-pass tables inside the prep block
+  size_t off_py, off_fby, prep_ypiv, prep_ywt, prep_yflag;
   // the pre-pass block ("prep": what depends on the data and the shape, not on the sampler):
   //   [pivot (1 + C)] then per 32-column group [window table | guard flags | fallback run list | n_list (256 B)]
   size_t prep_wt, prep_flag, prep_list, prep_nlist, prep_group0, prep_group_stride, prep_total;
@@ -698,8 +741,11 @@ static I8Plan plan_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   p.prep_flag = p.prep_wt + align_up((size_t)p.nwin * I8_WT_STRIDE * sizeof(double) + 2048, 256);  // + timing slots of debug builds
   p.prep_list = p.prep_flag + align_up((size_t)p.nwin * sizeof(uint32_t), 256);
   p.prep_nlist = p.prep_list + align_up((size_t)p.nwin * (size_t)(p.win_tiles / p.sub_tiles) * sizeof(uint32_t), 256);
-  p.prep_group_stride = p.prep_nlist + 256;
-  p.prep_group0 = align_up((size_t)(1 + C) * sizeof(double), 256);
+  p.prep_ywt = p.prep_nlist + 256;
+  p.prep_yflag = p.prep_ywt + align_up((size_t)p.nwin * I8_WT_STRIDE * sizeof(double), 256);
+  p.prep_group_stride = p.prep_yflag + align_up((size_t)p.nwin * sizeof(uint32_t), 256);
+  p.prep_ypiv = align_up((size_t)(1 + C) * sizeof(double), 256);
+  p.prep_group0 = 2 * p.prep_ypiv;
   p.prep_total = p.prep_group0 + (size_t)p.ngroups * p.prep_group_stride;
   // workspace
   p.off_px = 0;
@@ -707,10 +753,12 @@ static I8Plan plan_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   p.fb = plan_resample(N, C < I8_CPAD ? C : I8_CPAD, nrep, K);
   p.off_fbx = p.off_pu + align_up((size_t)p.nwin * p.nrep_pad * K * 8 * sizeof(double), 256);
   p.off_fbu = p.off_fbx + align_up((size_t)p.fb.n_chunks * p.fb.nrep_pad * p.fb.C_pad * K * sizeof(double), 256);
-  p.off_prog = p.off_fbu + align_up((size_t)p.fb.n_chunks * p.fb.nrep_pad * K * sizeof(double), 256);
+  p.off_prog = p.off_fbu + align_up((size_t)p.fb.n_chunks * p.fb.nrep_pad * (K + 1) * sizeof(double), 256);  // + the y run's
   p.prog_bytes = (size_t)p.n_chunks * 64 * sizeof(uint32_t);
   p.off_stats = p.off_prog + align_up(p.prog_bytes, 256);
-  p.off_prep = p.off_stats + align_up((size_t)cdiv(p.ntiles, p.win_tiles < 16 ? p.win_tiles : 16) * 100 * sizeof(double), 256);
+  p.off_py = p.off_stats + align_up((size_t)cdiv(p.ntiles, p.win_tiles < 16 ? p.win_tiles : 16) * 100 * sizeof(double), 256);
+  p.off_fby = p.off_py + align_up((size_t)p.nwin * p.nrep_pad * 8 * I8_CPAD * sizeof(double), 256);
+  p.off_prep = p.off_fby + align_up((size_t)p.fb.n_chunks * p.fb.nrep_pad * p.fb.C_pad * sizeof(double), 256);
   p.total = p.off_prep + align_up(p.prep_total, 256);
   return p;
 }
@@ -967,10 +1015,15 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
                               int order, int64_t nrep, const int64_t *freq, const txm_sampler_spec *spec,
                               const uint32_t *counts, const double *pivot, double *out, int path, void *prep,
                               size_t prep_bytes, bool prep_valid, int64_t *info, void *ws, size_t ws_bytes,
-                              hipStream_t st) {
+                              hipStream_t st, const double *y = nullptr, int64_t ldy_s = 0, double *out_y = nullptr,
+                              bool *y_done = nullptr) {
+  // y / out_y: the second sample matrix of txm_resample_opts.  Carried by this call when the int8 kernel can take it
+  // as a row set of its last pass (*y_done = true); otherwise left to the caller (a separate order-0 bootstrap).
   const bool explicit_ = freq != nullptr;
   const int K = order + 1;
+  if (y_done) *y_done = false;
   if (!explicit_ && use_i8(N, C, nrep, K, path)) {
+    const bool with_y = y != nullptr && i8t_carries_y(C, K);
     const I8Plan q = plan_i8(N, C, nrep, K);
     if (ws_bytes < q.total) {
       set_error("resample_vals: workspace too small (%zu < %zu)", ws_bytes, q.total);
@@ -990,6 +1043,7 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
       have_tables = prep_valid;
     }
     double *piv = (double *)pb;
+    double *ypiv = (double *)(pb + q.prep_ypiv);
     if (!have_tables) {
       if (pivot) {
         TXM_HIP(hipMemcpyAsync(piv, pivot, sizeof(double) * (size_t)(1 + C), hipMemcpyDeviceToDevice, st));
@@ -997,6 +1051,13 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
         hipLaunchKernelGGL(pivot_kernel, dim3((unsigned)(1 + C)), dim3(256), 0, st, x, ldx_s, (int64_t)1,
                            u, (int64_t)1, N, piv);
         TXM_LAUNCH_CHECK();
+      }
+      if (with_y) {
+        hipLaunchKernelGGL(pivot_kernel, dim3((unsigned)(1 + C)), dim3(256), 0, st, y, ldy_s, (int64_t)1, u, (int64_t)1,
+                           N, ypiv);
+        TXM_LAUNCH_CHECK();
+        // one u pivot for the call (the monomial scales of both matrices are built on it)
+        TXM_HIP(hipMemcpyAsync(ypiv, piv, sizeof(double), hipMemcpyDeviceToDevice, st));
       }
     }
     I8Args b;
@@ -1016,6 +1077,10 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
     b.nrep_pad = q.nrep_pad;
     b.win_tiles = q.win_tiles;
     b.sub_tiles = q.sub_tiles;
+    b.y = with_y ? y : nullptr;
+    b.ldy_s = ldy_s;
+    b.ypivot = ypiv;
+    b.part_y = (double *)((char *)ws + q.off_py);
     b.progress = (throttle_on() && q.n_rbg > 1) ? (uint32_t *)((char *)ws + q.off_prog) : nullptr;
     // the FP64 kernel in listed mode: contracts the windows the precision guard flags (none on ordinary data)
     ResampleArgs f;
@@ -1038,6 +1103,8 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
       b.wflag = (uint32_t *)(pg + q.prep_flag);
       b.list = (uint32_t *)(pg + q.prep_list);
       b.n_list = (uint32_t *)(pg + q.prep_nlist);
+      b.ywtab = (double *)(pg + q.prep_ywt);
+      b.yflag = (uint32_t *)(pg + q.prep_yflag);
       f.list = b.list; f.n_list = b.n_list;
       b.col0 = col0;
       b.C = C - col0 < I8_CPAD ? C - col0 : I8_CPAD;
@@ -1068,7 +1135,21 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
       }
 #undef TXM_I8_FIN
       TXM_LAUNCH_CHECK();
+      if (with_y) {
+        // the windows the guard flagged (for either matrix): the FP64 kernel in listed mode on y, order 0
+        ResampleArgs fy = f;
+        fy.x = y + col0; fy.ldx_s = ldy_s; fy.pivot = ypiv;
+        fy.part_x = (double *)((char *)ws + q.off_fby);
+        fy.part_u = f.part_u + (size_t)q.fb.n_chunks * q.fb.nrep_pad * K;  // scratch behind x's u-row sums (unused by the finalize)
+        const int rc3 = run_listed(fy, q.fb, 1, w != nullptr, st);
+        if (rc3 != TXM_OK) return rc3;
+        hipLaunchKernelGGL(resample_finalize_y_kernel, dim3((unsigned)nrep), dim3(256), 0, st, b.part_y, b.part_u, K, q.nwin,
+                           b.wflag, q.nrep_pad, b.C, ypiv, out_y, col0, C, fy.part_x, f.part_u, q.fb.n_chunks, q.fb.C_pad,
+                           b.n_list);
+        TXM_LAUNCH_CHECK();
+      }
     }
+    if (with_y && y_done) *y_done = true;
     // a reused prep block keeps its n_list words; a fresh one inside ws is what txm_resample_vals_info reads back
     if (prep != nullptr)
       TXM_HIP(hipMemcpyAsync((char *)ws + q.off_prep, pb, q.prep_total, hipMemcpyDeviceToDevice, st));
@@ -1151,9 +1232,10 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
   hipStream_t st = (hipStream_t)stream;
   const size_t main_bytes = txm_resample_vals_ws_bytes(N, C, nrep, order) - y_extra_bytes(N, C, nrep);
   const size_t avail = ws_bytes < main_bytes ? ws_bytes : main_bytes;
+  bool y_done = false;
   int rc = resample_vals_impl(x, ldx_s, u, w, N, C, order, nrep, freq, spec, counts, pivot, out, o.path, o.prep,
-                              o.prep_bytes, o.prep_valid != 0, o.info, ws, avail, st);
-  if (rc != TXM_OK || o.y == nullptr) return rc;
+                              o.prep_bytes, o.prep_valid != 0, o.info, ws, avail, st, o.y, o.ldy_s, o.out_y, &y_done);
+  if (rc != TXM_OK || o.y == nullptr || y_done) return rc;
   // second sample matrix: an order-0 bootstrap on the same sampler draw, then its mean column
   if (ws_bytes < main_bytes + y_extra_bytes(N, C, nrep)) {
     set_error("resample_vals: workspace too small for opts.y (%zu < %zu)", ws_bytes, main_bytes + y_extra_bytes(N, C, nrep));

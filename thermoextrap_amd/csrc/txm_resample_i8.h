@@ -47,6 +47,14 @@ struct I8Args {
   // launch geometry)
   double *part_x;          // [nwin][nrep_pad][K][8 digit slots][32 columns]
   double *part_u;          // [nwin][nrep_pad][K][8 digit slots]
+  // optional second sample matrix (txm_resample_opts.y): order-0 sums sum_i f w (y_c - py_c) of its 32 columns, carried
+  // as one more row set of the LAST pass of the transposing-read kernel (nullptr: none)
+  const double *y;
+  int64_t ldy_s;
+  const double *ypivot;    // [1 + all columns]: {pivot_u, pivot_y[...]}
+  double *ywtab;           // [nwin][I8_WT_STRIDE]: the window table of y (column scales of y)
+  uint32_t *yflag;         // [nwin] guard flags of y, OR-ed into wflag by the pre-pass
+  double *part_y;          // [nwin][nrep_pad][8 digit slots][32 columns]
   int n_chunks, n_rbg;
   int64_t tiles_per_chunk; // multiple of win_tiles
   int64_t win_tiles;       // sampler tiles per scaling window: 256, 64, 16 or 4
@@ -74,6 +82,8 @@ int launch_resample_i8(const I8Args &a, int K, bool weighted, size_t prog_bytes,
 // the same contraction with the B operands built by the LDS transposing read (txm_resample_i8t.hip): one power per
 // observable column, every order the int8 path serves
 int launch_resample_i8t(const I8Args &a, int K, bool weighted, size_t prog_bytes, hipStream_t st);
+// true when a call of this shape carries a second sample matrix inside its last pass (else the caller bootstraps it on its own)
+bool i8t_carries_y(int64_t C, int K);
 bool i8t_applicable(const double *x, int64_t ldx_s, int64_t C);  // C = all columns of the call
 
 }  // namespace txm

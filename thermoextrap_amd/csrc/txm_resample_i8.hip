@@ -1052,6 +1052,11 @@ static bool pack_i8_on() {
 
 // the pre-pass: per-window scale table, guard flags and the FP64 fallback list.  Depends on (x, u, w, pivot, shape)
 // only -- a caller that bootstraps the same data again passes the tables back in (txm_resample_opts.prep)
+__global__ void i8_or_flags_kernel(uint32_t *__restrict__ wflag, const uint32_t *__restrict__ yflag, int64_t nwin) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < nwin) wflag[w] |= yflag[w];
+}
+
 int launch_i8_prepass(const I8Args &a, int K, hipStream_t st) {
   // sub-blocks of <= 16 tiles; a window is 1 sub-block (4- and 16-tile windows) or win_tiles / 16 of them
   const int64_t sub_tiles = a.win_tiles < I8_STAT_TILES ? a.win_tiles : I8_STAT_TILES;
@@ -1068,6 +1073,23 @@ int launch_i8_prepass(const I8Args &a, int K, hipStream_t st) {
   hipLaunchKernelGGL(i8_table_kernel, dim3((unsigned)a.nwin), dim3(64), 0, st, a.stats, nsub, nsub_total, a.N, a.C,
                      a.win_tiles * SM_T, a.w != nullptr, K - 1, a.wtab, a.wflag);
   TXM_LAUNCH_CHECK();
+  if (a.y != nullptr) {
+    // the second matrix: its own column scales (order-0 monomial w dy), its guard flags OR-ed into the call's -- a
+    // window either runs on the int8 kernel for both matrices or on the FP64 kernel for both
+    const bool vy = ((reinterpret_cast<uintptr_t>(a.y + a.col0) & 15) == 0) && (a.ldy_s % 2 == 0);
+    if (vy)
+      hipLaunchKernelGGL(i8_stats_kernel<true>, dim3((unsigned)nsub_total), dim3(256), 0, st, a.y, a.ldy_s, a.u, a.w,
+                         a.N, a.C, a.col0, sub_tiles * SM_T, nsub == 1 ? 1 : 0, a.ypivot, 0, a.stats);
+    else
+      hipLaunchKernelGGL(i8_stats_kernel<false>, dim3((unsigned)nsub_total), dim3(256), 0, st, a.y, a.ldy_s, a.u, a.w,
+                         a.N, a.C, a.col0, sub_tiles * SM_T, nsub == 1 ? 1 : 0, a.ypivot, 0, a.stats);
+    TXM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(i8_table_kernel, dim3((unsigned)a.nwin), dim3(64), 0, st, a.stats, nsub, nsub_total, a.N, a.C,
+                       a.win_tiles * SM_T, a.w != nullptr, 0, a.ywtab, a.yflag);
+    TXM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(i8_or_flags_kernel, dim3((unsigned)cdiv(a.nwin, 256)), dim3(256), 0, st, a.wflag, a.yflag, a.nwin);
+    TXM_LAUNCH_CHECK();
+  }
   TXM_HIP(hipMemsetAsync(a.n_list, 0, 256, st));
   hipLaunchKernelGGL(i8_list_kernel, dim3(1), dim3(256), 0, st, a.wflag, a.nwin, a.win_tiles, a.sub_tiles, a.list,
                      a.n_list);

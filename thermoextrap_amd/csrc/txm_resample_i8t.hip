@@ -133,10 +133,13 @@ __device__ __forceinline__ void t_fill_call(uint32_t *cntw, uint32_t k0, uint32_
 //   [sample][column][8 B] region -- 17 % fewer instructions per k-step, 10 % MORE time: 40.4 vs 36.8 ms at N = 2e7.  The
 //   store path of the wide writes costs more than the issue slots they save.)
 constexpr int T_PLANE = 512, T_PB = 2 * T_PLANE + 128;  // bytes per (wave, power)
-template <int J0, int JN, bool WEIGHTED>
+// YS: the launch carries one more row set, the order-0 monomial w * dy of a SECOND sample matrix y (I8Args::y: the
+// volume callback's dx/dq, txm_resample_opts.y) -- its per-replicate sums ride on the same count tile and k-steps.
+template <int J0, int JN, bool WEIGHTED, bool YS = false>
 __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void resample_i8t_kernel(const I8Args a, const int K) {
-  static_assert(JN >= 1 && JN <= 5 && J0 + JN <= 8, "power range");
-  constexpr int NS = JN;             // row sets of the launch = x fragments per wave
+  static_assert(JN >= 1 && JN + (YS ? 1 : 0) <= 5 && J0 + JN <= 8, "power range");
+  constexpr int NS = JN + (YS ? 1 : 0);  // row sets of the launch = x fragments per wave
+  constexpr int NPT = JN + ((YS && WEIGHTED && J0 > 0) ? 1 : 0);  // staged factor tiles (the y row set needs plain w)
   constexpr int UF = (JN + 3) / 4;   // u-row fragments (4 monomials each)
   constexpr int WREG = (NS + 1) * T_PB;  // a wave's region: NS powers + one u-row fragment
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // 1 .. 31 of the tile and chunk 0 of the next one): staged once per tile by the whole workgroup as JN tiles of 8 KiB,
   // so that a k-step loads nothing but x and spends one v_fma_f64 + two v_xor_b32 per word -- the powers are LDS
   // reads (broadcast: four lanes per sample), not vector multiplies
-  double *ptile = reinterpret_cast<double *>(cnt_b + I8_REPS);  // [JN][1024]
+  double *ptile = reinterpret_cast<double *>(cnt_b + I8_REPS);  // [NPT][1024]
 
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int n32 = lane & 31, half = lane >> 5;
@@ -161,6 +164,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const int col = 4 * wave + cl;
   const int ccol = col < a.C ? col : 0;  // columns >= C re-read column 0: their sums are never flushed
   const uint32_t xo = (uint32_t)((ps * a.ldx_s + ccol) * 8);  // byte offset from the unit's (uniform) row base
+  const uint32_t yo = YS ? (uint32_t)((ps * a.ldy_s + ccol) * 8) : 0u;
   // ---- consumer role
   // transposing read of (plane g, rows 16 half + 0..7): lane 2 q + p of the 16-lane group supplies row q, bytes 8 p ..
   const uint32_t rd_off = wreg + (uint32_t)(((lane >> 4) & 1) * (T_PLANE + 128) + (16 * half + ((lane & 15) >> 1)) * 16 +
@@ -186,6 +190,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
   const double pu = a.pivot[0];
   const double px = a.pivot[1 + a.col0 + ccol];
+  const double py = YS ? a.ypivot[1 + a.col0 + ccol] : 0.0;
 
   v16i acc[NS][2];
   v16i accu;
@@ -205,7 +210,8 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   uint32_t fdraws = 0;
 
   struct XIn {
-    double x[2];  // the two 16-sample units of a chunk
+    double x[2];             // the two 16-sample units of a chunk
+    double y[YS ? 2 : 1];    // ... of the second matrix
   };
   // the wave's column quad of one chunk: i0 = the chunk's first sample (wave-uniform)
   auto load_x = [&](int64_t i0, XIn &r) {
@@ -213,9 +219,14 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     for (int uu = 0; uu < 2; ++uu) {
 #ifdef TXM_T_NO_LOAD  // ablation build: no memory access
       r.x[uu] = (double)(i0 + uu) * 1e-9 + px;
+      if constexpr (YS) r.y[uu] = (double)(i0 + uu) * 2e-9 + py;
 #else
       const double *xr = a.x + (i0 + 16 * uu) * a.ldx_s + a.col0;
       r.x[uu] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(xr) + xo);
+      if constexpr (YS) {
+        const double *yr = a.y + (i0 + 16 * uu) * a.ldy_s + a.col0;
+        r.y[uu] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(yr) + yo);
+      }
 #endif
     }
   };
@@ -241,6 +252,8 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const double inv_du = wt[I8_WT_INVDU];
     const double inv_w = WEIGHTED ? wt[I8_WT_INVW] : 1.0;
     const double sc = wt[I8_WT_SC + ccol];
+    const double *wty = YS ? a.ywtab + win * I8_WT_STRIDE : wt;
+    const double scy = YS ? wty[I8_WT_SC + ccol] : 0.0;
     int64_t tt_end = (win + 1) * WT;
     if (tt_end > t_end) tt_end = t_end;
 
@@ -293,11 +306,14 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         Ba = T_TRREAD((lds_v2i)(lds + rd_off));
         Bb = T_TRREAD((lds_v2i)(lds + rd_off + 128));
       }
-      double dx[2] = {0.0, 0.0};
+      double dx[2] = {0.0, 0.0}, dy[2] = {0.0, 0.0};
       const bool staged = e0 >= 0;  // uniform
       if constexpr (produce) {
 #pragma unroll
-        for (int uu = 0; uu < 2; ++uu) dx[uu] = (R.x[uu] - px) * sc;
+        for (int uu = 0; uu < 2; ++uu) {
+          dx[uu] = (R.x[uu] - px) * sc;
+          if constexpr (YS) dy[uu] = (R.y[uu] - py) * scy;
+        }
       }
       // factor jj of unit uu: a broadcast LDS read (staged) or du / w of the direct path multiplied up
       const double *pt = ptile + (staged ? e0 : 0) + ps;  // + jj * 1024 + 16 * uu: immediate offsets
@@ -307,6 +323,12 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         double pw = WEIGHTED ? d_w[uu] : 1.0;
         for (int q = 0; q < J0 + jj; ++q) pw *= d_du[uu];
         return pw;
+      };
+      // the y row set's factor: the plain weight (order 0)
+      auto factor_y = [&](int uu) {
+        if (!WEIGHTED) return 1.0;
+        if (!staged) return d_w[uu];
+        return J0 == 0 ? pt[16 * uu] : pt[JN * SM_T + 16 * uu];  // tile 0 is w du^0 when J0 == 0, else the extra tile
       };
       t_static_for<NS>([&](auto fic) {
         constexpr int fi = decltype(fic)::value;
@@ -322,8 +344,12 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
         if constexpr (produce) {
           // the words of chunk s + 1, power fi: behind the MFMAs that took chunk s's (the region is single-buffered)
-          store_x2((uint64_t)__double_as_longlong(fma(factor(fi, 0), dx[0], T_MAGIC)),
-                   (uint64_t)__double_as_longlong(fma(factor(fi, 1), dx[1], T_MAGIC)), fi * T_PB);
+          if constexpr (YS && fi == JN)
+            store_x2((uint64_t)__double_as_longlong(fma(factor_y(0), dy[0], T_MAGIC)),
+                     (uint64_t)__double_as_longlong(fma(factor_y(1), dy[1], T_MAGIC)), fi * T_PB);
+          else
+            store_x2((uint64_t)__double_as_longlong(fma(factor(fi, 0), dx[0], T_MAGIC)),
+                     (uint64_t)__double_as_longlong(fma(factor(fi, 1), dx[1], T_MAGIC)), fi * T_PB);
         }
         Ba = Na;
         Bb = Nb;
@@ -374,7 +400,16 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       int j;
       double dsc;
       double *base;
-      if (ufrag < 0) {
+      size_t stride = (size_t)K * (ufrag < 0 ? I8_CPAD : 1) * 8;  // one replicate
+      if (ufrag < 0 && YS && rs == JN) {
+        // the second matrix: [window][replicate][digit slot][column], scale = max|w| x its own column scale
+        const int c = 4 * wave + tcl;
+        valid = valid && c < a.C;
+        j = 0;
+        dsc = wty[I8_WT_DSP + 0] * wty[I8_WT_DSC + (c < a.C ? c : 0)];
+        base = a.part_y + (((size_t)win * a.nrep_pad + rep0 + 32 * h + 4 * half) * 8 + tdg) * I8_CPAD + c + opq;
+        stride = (size_t)8 * I8_CPAD;
+      } else if (ufrag < 0) {
         const int c = 4 * wave + tcl;
         valid = valid && c < a.C;
         j = J0 + rs;
@@ -389,7 +424,6 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         base = a.part_u + (((size_t)win * a.nrep_pad + rep0 + 32 * h + 4 * half) * K + j) * 8 + tdg + opq;
       }
       dsc *= (double)((int64_t)1 << (8 * (tdg < I8_NSL ? tdg : 0)));
-      const size_t stride = (size_t)K * (ufrag < 0 ? I8_CPAD : 1) * 8;  // one replicate
       const int bias = tdg == I8_NSL - 1 ? T_D6_BIAS : 0;
       if (valid) {
 #pragma unroll
@@ -523,6 +557,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const int e = (int)threadIdx.x + q * T_BLOCK;
         const double du = (su[q] - pu) * inv_du;
         double pw = WEIGHTED ? sw[q] * inv_w : 1.0;
+        if constexpr (NPT > JN) ptile[JN * SM_T + e] = pw;  // plain w for the y row set
 #pragma unroll
         for (int k = 0; k < J0; ++k) pw *= du;
 #pragma unroll
@@ -590,14 +625,15 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 }
 
 // ---------------------------------------------------------------------------
-template <int J0, int JN, bool WEIGHTED>
+template <int J0, int JN, bool WEIGHTED, bool YS = false>
 static int launch_pass_t(const I8Args &a, int K, size_t prog_bytes, hipStream_t st) {
   if (a.progress != nullptr) TXM_HIP(hipMemsetAsync(a.progress, 0, prog_bytes, st));
   const dim3 grid((unsigned)(a.n_chunks * a.n_rbg)), block(T_BLOCK);
-  const size_t lds = (size_t)T_WAVES * (JN + 1) * T_PB + T_CNT_BYTES + 3u * I8_REPS * sizeof(uint32_t) +
-                     (size_t)JN * SM_T * sizeof(double);
-  TXM_SET_MAX_LDS((&resample_i8t_kernel<J0, JN, WEIGHTED>), lds);
-  hipLaunchKernelGGL((resample_i8t_kernel<J0, JN, WEIGHTED>), grid, block, lds, st, a, K);
+  constexpr int ns = JN + (YS ? 1 : 0), npt = JN + ((YS && WEIGHTED && J0 > 0) ? 1 : 0);
+  const size_t lds = (size_t)T_WAVES * (ns + 1) * T_PB + T_CNT_BYTES + 3u * I8_REPS * sizeof(uint32_t) +
+                     (size_t)npt * SM_T * sizeof(double);
+  TXM_SET_MAX_LDS((&resample_i8t_kernel<J0, JN, WEIGHTED, YS>), lds);
+  hipLaunchKernelGGL((resample_i8t_kernel<J0, JN, WEIGHTED, YS>), grid, block, lds, st, a, K);
   TXM_LAUNCH_CHECK();
   return TXM_OK;
 }
@@ -611,21 +647,37 @@ bool i8t_applicable(const double *x, int64_t ldx_s, int64_t C) {
 
 // one power per observable column (C > 16, or order 0): every order 0..7; five row sets per pass, orders 5..7 in two
 // passes over the sampler stream (the matrix pipe paces a pass, so the split is by fragments: 3 + 3, 4 + 3, 4 + 4).
+// A second sample matrix (a.y) rides as one more row set of the LAST pass wherever that pass has four power row sets at
+// most -- every order but 4 (i8t_carries_y).
+bool i8t_carries_y(int64_t C, int K) {
+  const bool narrow = C <= 16 && K >= 2;  // narrow states run txm_resample_i8.hip's power-packed kernel
+  return !narrow && K != 5 && K >= 1 && K <= 8;
+}
+
 int launch_resample_i8t(const I8Args &a, int K, bool weighted, size_t prog_bytes, hipStream_t st) {
   int rc = TXM_OK;
+  const bool ys = a.y != nullptr;
+  if (ys && K == 5) {
+    set_error("resample_i8t: a second matrix cannot ride on a five-power pass");
+    return TXM_ERR_INVALID;
+  }
 #define T_PASS(J0_, JN_) (weighted ? launch_pass_t<J0_, JN_, true>(a, K, prog_bytes, st) : launch_pass_t<J0_, JN_, false>(a, K, prog_bytes, st))
+#define T_LAST(J0_, JN_)                                                                                                   \
+  (ys ? (weighted ? launch_pass_t<J0_, JN_, true, true>(a, K, prog_bytes, st) : launch_pass_t<J0_, JN_, false, true>(a, K, prog_bytes, st)) \
+      : T_PASS(J0_, JN_))
   switch (K) {
-    case 1: rc = T_PASS(0, 1); break;
-    case 2: rc = T_PASS(0, 2); break;
-    case 3: rc = T_PASS(0, 3); break;
-    case 4: rc = T_PASS(0, 4); break;
+    case 1: rc = T_LAST(0, 1); break;
+    case 2: rc = T_LAST(0, 2); break;
+    case 3: rc = T_LAST(0, 3); break;
+    case 4: rc = T_LAST(0, 4); break;
     case 5: rc = T_PASS(0, 5); break;
-    case 6: rc = T_PASS(0, 3); if (rc == TXM_OK) rc = T_PASS(3, 3); break;
-    case 7: rc = T_PASS(0, 4); if (rc == TXM_OK) rc = T_PASS(4, 3); break;
-    case 8: rc = T_PASS(0, 4); if (rc == TXM_OK) rc = T_PASS(4, 4); break;
+    case 6: rc = T_PASS(0, 3); if (rc == TXM_OK) rc = T_LAST(3, 3); break;
+    case 7: rc = T_PASS(0, 4); if (rc == TXM_OK) rc = T_LAST(4, 3); break;
+    case 8: rc = T_PASS(0, 4); if (rc == TXM_OK) rc = T_LAST(4, 4); break;
     default: set_error("resample_i8t: order out of range"); return TXM_ERR_INVALID;
   }
 #undef T_PASS
+#undef T_LAST
   return rc;
 }
 

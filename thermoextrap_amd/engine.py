@@ -309,11 +309,21 @@ def resample_vals(
             raise ValueError(f"out must be a contiguous ({nrep}, {C}, 2, {order + 1}) tensor, got {tuple(out.shape)}")
     opts = ResampleOpts()
     opts.path = _call_path(path, N, C, nrep, order)
+    ymean = y2 = None
+    if y is not None:
+        _check_f64_cuda(y, "y")
+        y2 = y.unsqueeze(1) if y.dim() == 1 else y
+        if tuple(y2.shape) != (N, C):
+            raise ValueError(f"y must have the shape of x, ({N}, {C}); got {tuple(y2.shape)}")
+        if y2.stride(1) != 1 or (N > 1 and y2.stride(0) < C):
+            y2 = y2.contiguous()
+        ymean = torch.empty((nrep, C), dtype=F64, device="cuda")
+        opts.y, opts.ldy_s, opts.out_y = y2.data_ptr(), max(y2.stride(0) if N > 1 else C, C), ymean.data_ptr()
     key = None
     if prep is not None and freq is None:
         takes_i8 = opts.path == 1 or (opts.path == -1 and L.txm_resample_path(N, C, nrep, order) == 1)
         if takes_i8:
-            key = (_tkey(x2), ls, _tkey(u), _tkey(w), _tkey(pivot), N, C, nrep, order)
+            key = (_tkey(x2), ls, _tkey(u), _tkey(w), _tkey(pivot), _tkey(y2), N, C, nrep, order)
             buf, valid = prep.bind(key, L.txm_resample_prep_bytes(N, C, nrep, order))
             opts.prep, opts.prep_bytes, opts.prep_valid = buf.data_ptr(), buf.numel(), int(valid)
     if info is None:  # the words resample_info() reads back: one block per (device, stream)
@@ -324,16 +334,6 @@ def resample_vals(
     if not (info.is_cuda and info.dtype == torch.int64 and info.numel() >= 4 and info.is_contiguous()):
         raise TypeError("info must be a contiguous int64 CUDA tensor with >= 4 elements")
     opts.info = info.data_ptr()
-    ymean = None
-    if y is not None:
-        _check_f64_cuda(y, "y")
-        y2 = y.unsqueeze(1) if y.dim() == 1 else y
-        if tuple(y2.shape) != (N, C):
-            raise ValueError(f"y must have the shape of x, ({N}, {C}); got {tuple(y2.shape)}")
-        if y2.stride(1) != 1 or (N > 1 and y2.stride(0) < C):
-            y2 = y2.contiguous()
-        ymean = torch.empty((nrep, C), dtype=F64, device="cuda")
-        opts.y, opts.ldy_s, opts.out_y = y2.data_ptr(), max(y2.stride(0) if N > 1 else C, C), ymean.data_ptr()
     ws = workspace(L.txm_resample_vals_ws_bytes(N, C, nrep, order))
     check(
         L.txm_resample_vals(_ptr(x2), ls, 1, _ptr(u), _ptr(w), N, C, order, nrep, _ptr(freq), spec_p, counts_p,

@@ -21,4 +21,27 @@ for f in sorted(glob.glob("gpurun_out/i8_pmc*/**/*counter_collection.csv", recur
         agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 for k, v in agg.items():
     print(f"{k:32s} {sum(v)/len(v):.4e}  (n={len(v)})")
+import json, os, sys
+sys.path.insert(0, ".")
+from bench import csrc_sha
+c = {k: sum(v) / len(v) for k, v in agg.items()}
+tag = os.environ.get("PMC_TAG")
+if tag and c:
+    q = 4.0  # SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)
+    d = {"tag": tag, "kernel_regex": os.environ.get("KREGEX", "resample_i8t?_kernel"), "csrc_sha": csrc_sha(),
+         "workload": {"n_samp": int(float(os.environ.get("PMC_N", "2e7"))), "n_obs": 32, "order": 4, "nrep": int(os.environ.get("PMC_NREP", "1000"))},
+         "command": "bash tools/i8_pmc.sh N NREP (four rocprofv3 --pmc passes of tools/prof_driver.py, one launch each; counters summed over the chip)",
+         "counters": c,
+         "derived": {
+             "valu_instructions_per_mfma": c.get("SQ_INSTS_VALU", 0) / max(c.get("SQ_INSTS_MFMA", 1), 1),
+             "wave_cycles_waiting_fraction (SQ_WAIT_ANY / SQ_WAVE_CYCLES)": c.get("SQ_WAIT_ANY", 0) / max(c.get("SQ_WAVE_CYCLES", 1), 1),
+             "wave_cycles_issue_stalled_fraction (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES)": c.get("SQ_WAIT_INST_ANY", 0) / max(c.get("SQ_WAVE_CYCLES", 1), 1),
+             "lds_bank_conflict_cycles_per_cu": c.get("SQ_LDS_BANK_CONFLICT", 0) / 256,
+             "lds_bank_conflict_ms_per_cu_at_2.4GHz": c.get("SQ_LDS_BANK_CONFLICT", 0) / 256 / 2.4e6,
+             "lds_idx_active_cycles_per_cu": c.get("SQ_LDS_IDX_ACTIVE", 0) / 256,
+             "mfma_busy_cycles_per_simd": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024,
+             "valu_issue_cycles_per_simd (4 x SQ_ACTIVE_INST_VALU / 1024)": q * c.get("SQ_ACTIVE_INST_VALU", 0) / 1024,
+         }}
+    json.dump(d, open(f"profiles/{tag}.json", "w"), indent=1)
+    print("wrote", f"profiles/{tag}.json")
 PY
