@@ -523,10 +523,16 @@ __global__ __launch_bounds__(256) void resample_finalize_kernel(
     const double *__restrict__ part_x, const double *__restrict__ part_u, int n_chunks,
     int64_t nrep_pad, int64_t C_pad, int64_t nrep, int64_t C, const double *__restrict__ pivot,
     double *__restrict__ out, int64_t c_off = 0, int64_t C_total = 0) {
-  // C columns of this launch are the columns c_off .. c_off + C - 1 of the C_total output columns
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nrep * C) return;
-  const int64_t r = e / C, c = e % C;
+  // C columns of this launch are the columns c_off .. c_off + C - 1 of the C_total output columns.
+  // Thread = (output e of the block's 32, chunk segment seg of 8): segment seg adds the chunks seg, seg + 8, ... in
+  // ascending order, then the eight segments are added in order -- a fixed tree (one thread per output walking all
+  // chunks was a chain of dependent-latency loads: 0.3 ms for 400 outputs x 1024 chunks).
+  constexpr int NSEG = 8, NOUT = 256 / NSEG;
+  __shared__ double sh[NSEG][NOUT][2 * K];
+  const int eo = threadIdx.x % NOUT, seg = threadIdx.x / NOUT;
+  const int64_t e = (int64_t)blockIdx.x * NOUT + eo;
+  const bool live = e < nrep * C;
+  const int64_t r = live ? e / C : 0, c = live ? e % C : 0;
   if (C_total == 0) C_total = C;
   // batched mode: blockIdx.y = state; every per-state array follows the previous state's
   const int64_t sidx = blockIdx.y;
@@ -537,15 +543,29 @@ __global__ __launch_bounds__(256) void resample_finalize_kernel(
   double S0[K], S1[K];
 #pragma unroll
   for (int j = 0; j < K; ++j) S0[j] = S1[j] = 0.0;
-  for (int ch = 0; ch < n_chunks; ++ch) {
-    const double *pu_ = part_u + ((size_t)ch * nrep_pad + r) * K;
-    const double *px_ = part_x + (((size_t)ch * nrep_pad + r) * C_pad + c) * K;
+  if (live)
+    for (int ch = seg; ch < n_chunks; ch += NSEG) {
+      const double *pu_ = part_u + ((size_t)ch * nrep_pad + r) * K;
+      const double *px_ = part_x + (((size_t)ch * nrep_pad + r) * C_pad + c) * K;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        S0[j] += pu_[j];
+        S1[j] += px_[j];
+      }
+    }
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    sh[seg][eo][j] = S0[j];
+    sh[seg][eo][K + j] = S1[j];
+  }
+  __syncthreads();
+  if (seg != 0 || !live) return;
+  for (int g = 1; g < NSEG; ++g)
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      S0[j] += pu_[j];
-      S1[j] += px_[j];
+      S0[j] += sh[g][eo][j];
+      S1[j] += sh[g][eo][K + j];
     }
-  }
   double st[2 * K];
   pivot_sums_to_state<K>(S0, S1, pivot[0], pivot[1 + c_off + c], st);
   double *o = out + (r * C_total + c_off + c) * 2 * K;
@@ -563,49 +583,46 @@ __global__ __launch_bounds__(256) void resample_finalize_i8_kernel(
     const uint32_t *__restrict__ wflag, int64_t nrep_pad, int64_t nrep, int64_t C,
     const double *__restrict__ pivot, double *__restrict__ out, int64_t c_off, int64_t C_total,
     const double *__restrict__ fb_x, const double *__restrict__ fb_u, int fb_chunks, int64_t fb_cpad,
-    const uint32_t *__restrict__ n_list) {
-  // one workgroup per replicate: thread = (column c, window segment seg of 8).  Segment seg adds the windows
-  // seg, seg + 8, ... in ascending order, then the eight segments are added in order: a fixed tree that depends on the
-  // number of windows (i.e. on N) only.  (One thread per output walking all windows was latency-bound on short series
-  // with few outputs: 1600 threads x 611 windows at BASELINE config 2.)
-  constexpr int NSEG = 8;
-  __shared__ double sh[NSEG][32][2 * K];
+    const uint32_t *__restrict__ n_list, const int cpad) {
+  // cpad = columns of a row of part_x (32; 4 or 8 where the narrow-state kernel wrote it)
+  // one workgroup per replicate: thread = (column c < cpad, window segment seg of 256 / cpad).  Segment seg adds the
+  // windows seg, seg + nseg, ... in ascending order, then the segments are added in order: a fixed tree that depends on
+  // the number of windows (i.e. on N) and on the state's width only, not on the launch geometry.  (One thread per output
+  // walking all windows was latency-bound on short series with few outputs: 1600 threads x 611 windows at BASELINE
+  // config 2; so were 8 segments for an 8-column state.)
+  __shared__ double sh[256][2 * K];
+  const int nseg = 256 / cpad;
   const int64_t r = blockIdx.x;
-  const int c = threadIdx.x & 31, seg = threadIdx.x >> 5;
+  const int c = threadIdx.x % cpad, seg = threadIdx.x / cpad;
   double S0[K], S1[K];
 #pragma unroll
   for (int j = 0; j < K; ++j) S0[j] = S1[j] = 0.0;
   if (c < C) {
-    for (int64_t w = seg; w < nwin; w += NSEG) {
+    for (int64_t w = seg; w < nwin; w += nseg) {
       if (wflag[w] != 0u) continue;
       const double *pu_ = part_u + ((size_t)w * nrep_pad + r) * K * 8;
-      const double *px_ = part_x + ((size_t)w * nrep_pad + r) * K * 8 * I8_CPAD + c;
+      const double *px_ = part_x + ((size_t)w * nrep_pad + r) * K * 8 * cpad + c;
 #pragma unroll
       for (int j = 0; j < K; ++j) {
         const double4 ua = *reinterpret_cast<const double4 *>(pu_ + j * 8), ub = *reinterpret_cast<const double4 *>(pu_ + j * 8 + 4);
-        const double *q = px_ + (size_t)j * 8 * I8_CPAD;
+        const double *q = px_ + (size_t)j * 8 * cpad;
         S0[j] += ((((((ua.x + ua.y) + ua.z) + ua.w) + ub.x) + ub.y) + ub.z);  // digit slots 0..6, ascending
-        S1[j] += ((((((q[0] + q[I8_CPAD]) + q[2 * I8_CPAD]) + q[3 * I8_CPAD]) + q[4 * I8_CPAD]) + q[5 * I8_CPAD]) + q[6 * I8_CPAD]);
+        S1[j] += ((((((q[0] + q[cpad]) + q[2 * cpad]) + q[3 * cpad]) + q[4 * cpad]) + q[5 * cpad]) + q[6 * cpad]);
       }
     }
   }
 #pragma unroll
   for (int j = 0; j < K; ++j) {
-    sh[seg][c][j] = S0[j];
-    sh[seg][c][K + j] = S1[j];
+    sh[threadIdx.x][j] = S0[j];
+    sh[threadIdx.x][K + j] = S1[j];
   }
   __syncthreads();
   if (seg != 0 || c >= C) return;
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    S0[j] = sh[0][c][j];
-    S1[j] = sh[0][c][K + j];
-  }
-  for (int g = 1; g < NSEG; ++g)
+  for (int g = 1; g < nseg; ++g)
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      S0[j] += sh[g][c][j];
-      S1[j] += sh[g][c][K + j];
+      S0[j] += sh[g * cpad + c][j];
+      S1[j] += sh[g * cpad + c][K + j];
     }
   // windows the precision guard handed to the FP64 kernel (same pivot: the sums simply add)
   if (n_list[0] != 0u)
@@ -972,7 +989,7 @@ static int run_resample(ResampleArgs a, const ResamplePlan &p, bool weighted, bo
 #undef TXM_RS_LAUNCH
   TXM_LAUNCH_CHECK();
   const int64_t ne = a.nrep * a.C;
-  hipLaunchKernelGGL((resample_finalize_kernel<K>), dim3((unsigned)cdiv(ne, 256), (unsigned)S), dim3(256), 0, st,
+  hipLaunchKernelGGL((resample_finalize_kernel<K>), dim3((unsigned)cdiv(ne, 32), (unsigned)S), dim3(256), 0, st,
                      a.part_x, a.part_u, p.n_chunks, p.nrep_pad, p.C_pad, a.nrep, a.C, a.pivot, out);
   TXM_LAUNCH_CHECK();
   return TXM_OK;
@@ -1062,6 +1079,7 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
     }
     I8Args b;
     b.x = x; b.ldx_s = ldx_s; b.u = u; b.w = w; b.N = N; b.nrep = nrep; b.C_call = C;
+    b.cpad = i8_cpad(C, K);
     b.counts = counts;
     b.k0 = (uint32_t)spec->seed;
     b.k1 = (uint32_t)(spec->seed >> 32);
@@ -1122,7 +1140,7 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
 #define TXM_I8_FIN(KK)                                                                                 \
   hipLaunchKernelGGL((resample_finalize_i8_kernel<KK>), dim3((unsigned)nrep), dim3(256), 0, st,          \
                      b.part_x, b.part_u, q.nwin, b.wflag, q.nrep_pad, nrep, b.C, piv, out, col0, C,        \
-                     f.part_x, f.part_u, q.fb.n_chunks, q.fb.C_pad, b.n_list)
+                     f.part_x, f.part_u, q.fb.n_chunks, q.fb.C_pad, b.n_list, b.cpad)
       switch (K) {
         case 1: TXM_I8_FIN(1); break;
         case 2: TXM_I8_FIN(2); break;

@@ -45,7 +45,8 @@ struct I8Args {
   // partial sums: ONE SLOT PER SCALING WINDOW, written once (no read-modify-write, no zeroing; the finalize kernel
   // skips the windows the guard flagged and adds the rest in window order, so a replicate's sums do not depend on the
   // launch geometry)
-  double *part_x;          // [nwin][nrep_pad][K][8 digit slots][32 columns]
+  double *part_x;          // [nwin][nrep_pad][K][8 digit slots][cpad columns]
+  int cpad;                // columns of a row of part_x: 32, or 4 / 8 where the narrow-state kernel runs (i8_cpad)
   double *part_u;          // [nwin][nrep_pad][K][8 digit slots]
   // optional second sample matrix (txm_resample_opts.y): order-0 sums sum_i f w (y_c - py_c) of its 32 columns, carried
   // as one more row set of the LAST pass of the transposing-read kernel (nullptr: none)
@@ -85,5 +86,9 @@ int launch_resample_i8t(const I8Args &a, int K, bool weighted, size_t prog_bytes
 // true when a call of this shape carries a second sample matrix inside its last pass (else the caller bootstraps it on its own)
 bool i8t_carries_y(int64_t C, int K);
 bool i8t_applicable(const double *x, int64_t ldx_s, int64_t C);  // C = all columns of the call
+// narrow states (C <= 8 observables): column quads of the transposing-read kernel's quad-sharing variant (1 or 2), 0 = the
+// shape is not served by it; i8_cpad = the columns of a row of I8Args::part_x for the shape (4, 8 or 32)
+int i8t_narrow_nq(int64_t C_call, int K);
+int i8_cpad(int64_t C_call, int K);
 
 }  // namespace txm

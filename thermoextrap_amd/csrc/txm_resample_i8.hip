@@ -1107,6 +1107,8 @@ static bool i8t_on() {
 
 int launch_resample_i8(const I8Args &a, int K, bool weighted, size_t prog_bytes, hipStream_t st) {
   int rc = TXM_OK;
+  // narrow state on the transposing-read kernel (the waves of a column quad split the powers)
+  if (i8t_on() && i8t_narrow_nq(a.C_call, K) != 0) return launch_resample_i8t(a, K, weighted, prog_bytes, st);
   // narrow state: four powers per observable column (two row sets at most).  Not for the narrow tail group of a wide
   // state: its u-row sums would round differently from the other groups' (the monomials are formed in another order)
   if (a.C <= 8 && a.col0 == 0 && K >= 2 && pack_i8_on()) {

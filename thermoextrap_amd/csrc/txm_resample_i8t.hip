@@ -59,8 +59,14 @@ constexpr int T_STEPS = SM_T / 32;
 #ifndef TXM_T_XD
 #define TXM_T_XD 2
 #endif
-constexpr int T_XD = TXM_T_XD;  // k-steps between the request of an x chunk and its use (1, 2 or 4: the step loop is unrolled by 4)
-static_assert(T_XD == 1 || T_XD == 2 || T_XD == 4, "ring depth");
+constexpr int T_XD = TXM_T_XD;  // k-steps between the request of an x chunk and its use (the step loop is unrolled by max(4, depth))
+#ifndef TXM_T_XDN
+#define TXM_T_XDN 8
+#endif
+// ... of the narrow-state variant: its k-steps are short (a few MFMAs per wave), so the same memory latency is more
+// k-steps (measured at BASELINE config 2: depth 2 left the k-steps waiting for x -- 850 cycles each for 3 MFMAs)
+constexpr int T_XDN = TXM_T_XDN;
+static_assert((T_XD == 1 || T_XD == 2 || T_XD == 4 || T_XD == 8) && (T_XDN == 1 || T_XDN == 2 || T_XDN == 4 || T_XDN == 8), "ring depth");
 // 1.5 * 2^52 + 0x80 in each of the six low mantissa bytes (the digits come out biased by 128; byte 6 holds
 // 0x38 + digit 6, taken out at flush time as 56 * draws; byte 7 is the sign/exponent byte: the dead slot)
 constexpr double T_MAGIC = 6755399441055744.0 + 141289400074368.0;
@@ -135,10 +141,19 @@ __device__ __forceinline__ void t_fill_call(uint32_t *cntw, uint32_t k0, uint32_
 constexpr int T_PLANE = 512, T_PB = 2 * T_PLANE + 128;  // bytes per (wave, power)
 // YS: the launch carries one more row set, the order-0 monomial w * dy of a SECOND sample matrix y (I8Args::y: the
 // volume callback's dx/dq, txm_resample_opts.y) -- its per-replicate sums ride on the same count tile and k-steps.
-template <int J0, int JN, bool WEIGHTED, bool YS = false>
+//
+// NQ < 8: a NARROW state (C <= 4 NQ observables, NQ = 1 or 2 column quads).  The 8 / NQ waves that share a column
+// quad split the powers between them: wave w owns quad w % NQ and the powers g, g + GS, g + 2 GS ... (g = w / NQ,
+// GS = 8 / NQ) -- ceil(JN / GS) row sets per wave instead of JN, every MFMA column in use, all orders in one pass.
+// The u-row tiles go to the last waves (the ones with the fewest power rows).
+template <int J0, int JN, bool WEIGHTED, bool YS = false, int NQ = 8>
 __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void resample_i8t_kernel(const I8Args a, const int K) {
-  static_assert(JN >= 1 && JN + (YS ? 1 : 0) <= 5 && J0 + JN <= 8, "power range");
-  constexpr int NS = JN + (YS ? 1 : 0);  // row sets of the launch = x fragments per wave
+  static_assert(NQ == 8 || NQ == 2 || NQ == 1, "column quads");
+  constexpr int GS = 8 / NQ;                  // waves per column quad = stride of a wave's powers
+  constexpr int NSW = (JN + GS - 1) / GS;     // power row sets per wave
+  static_assert(JN >= 1 && NSW + (YS ? 1 : 0) <= 5 && J0 + JN <= 8, "power range");
+  static_assert(NQ == 8 || (!YS && J0 == 0), "narrow states: one pass, no second matrix");
+  constexpr int NS = NSW + (YS ? 1 : 0);  // row sets of the launch = x fragments per wave
   constexpr int NPT = JN + ((YS && WEIGHTED && J0 > 0) ? 1 : 0);  // staged factor tiles (the y row set needs plain w)
   constexpr int UF = (JN + 3) / 4;   // u-row fragments (4 monomials each)
   constexpr int WREG = (NS + 1) * T_PB;  // a wave's region: NS powers + one u-row fragment
@@ -161,7 +176,11 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
   // ---- producer role: lane = (sample l >> 2 of a 16-sample unit, column l & 3 of the wave's quad)
   const int ps = lane >> 2, cl = lane & 3;
-  const int col = 4 * wave + cl;
+  const int quad = NQ == 8 ? wave : wave % NQ;  // the wave's column quad
+  const int g = NQ == 8 ? 0 : wave / NQ;        // ... and its first power (relative to J0)
+  const int col = 4 * quad + cl;
+  // row set fi of this wave = power J0 + g + fi GS; past the launch's powers: an idle row set (wave-uniform)
+  auto row_live = [&](int fi) { return NQ == 8 || g + fi * GS < JN; };
   const int ccol = col < a.C ? col : 0;  // columns >= C re-read column 0: their sums are never flushed
   const uint32_t xo = (uint32_t)((ps * a.ldx_s + ccol) * 8);  // byte offset from the unit's (uniform) row base
   const uint32_t yo = YS ? (uint32_t)((ps * a.ldy_s + ccol) * 8) : 0u;
@@ -174,8 +193,9 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const int tcl = (n32 >> 2) & 3, tdg = 4 * (n32 >> 4) + (n32 & 3);
   // u-row tile of waves 0 .. 2 UF - 1: fragment fu (monomials 4 fu .. 4 fu + 3), replicate half uh
   constexpr int NUT = 2 * UF;
-  const bool has_ut = wave < NUT;  // wave-uniform
-  const int fu = has_ut ? (wave >> 1) : 0, uh = wave & 1;
+  const int uw = NQ == 8 ? wave : wave - (T_WAVES - NUT);
+  const bool has_ut = uw >= 0 && uw < NUT;  // wave-uniform
+  const int fu = has_ut ? (uw >> 1) : 0, uh = uw & 1;
   const int um = 4 * fu + cl;      // this lane's u-row monomial
   const int umc = um < JN ? um : 0;
 
@@ -316,40 +336,46 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
       }
       // factor jj of unit uu: a broadcast LDS read (staged) or du / w of the direct path multiplied up
-      const double *pt = ptile + (staged ? e0 : 0) + ps;  // + jj * 1024 + 16 * uu: immediate offsets
-      auto factor = [&](int jj, int uu) {
-        if (!WEIGHTED && J0 == 0 && jj == 0) return 1.0;
-        if (staged) return pt[jj * SM_T + 16 * uu];
+      const double *pt = ptile + (staged ? e0 : 0) + ps + g * SM_T;  // + fi * GS * 1024 + 16 * uu: immediate offsets
+      auto factor = [&](int fi, int uu) {  // row set fi = power J0 + g + fi GS
+        if (NQ == 8 && !WEIGHTED && J0 == 0 && fi == 0) return 1.0;
+        if (staged) return pt[fi * GS * SM_T + 16 * uu];
         double pw = WEIGHTED ? d_w[uu] : 1.0;
-        for (int q = 0; q < J0 + jj; ++q) pw *= d_du[uu];
+        for (int q = 0; q < J0 + g + fi * GS; ++q) pw *= d_du[uu];
         return pw;
       };
       // the y row set's factor: the plain weight (order 0)
       auto factor_y = [&](int uu) {
         if (!WEIGHTED) return 1.0;
         if (!staged) return d_w[uu];
-        return J0 == 0 ? pt[16 * uu] : pt[JN * SM_T + 16 * uu];  // tile 0 is w du^0 when J0 == 0, else the extra tile
+        return J0 == 0 ? pt[16 * uu] : pt[JN * SM_T + 16 * uu];  // tile 0 is w du^0 when J0 == 0, else the extra tile (NQ = 8: g = 0)
       };
       t_static_for<NS>([&](auto fic) {
         constexpr int fi = decltype(fic)::value;
         v2i Na = (v2i)(0), Nb = (v2i)(0);
         if constexpr (consume) {
           if constexpr (fi + 1 < NS) {
-            Na = T_TRREAD((lds_v2i)(lds + rd_off + (fi + 1) * T_PB));
-            Nb = T_TRREAD((lds_v2i)(lds + rd_off + (fi + 1) * T_PB + 128));
+            if (row_live(fi + 1)) {  // wave-uniform (always for NQ = 8)
+              Na = T_TRREAD((lds_v2i)(lds + rd_off + (fi + 1) * T_PB));
+              Nb = T_TRREAD((lds_v2i)(lds + rd_off + (fi + 1) * T_PB + 128));
+            }
           }
-          const v4i B = {Ba[0], Ba[1], Bb[0], Bb[1]};
-          t_mfma<true>(acc[fi][0], A0, B);
-          t_mfma<true>(acc[fi][1], A1, B);
         }
-        if constexpr (produce) {
-          // the words of chunk s + 1, power fi: behind the MFMAs that took chunk s's (the region is single-buffered)
-          if constexpr (YS && fi == JN)
-            store_x2((uint64_t)__double_as_longlong(fma(factor_y(0), dy[0], T_MAGIC)),
-                     (uint64_t)__double_as_longlong(fma(factor_y(1), dy[1], T_MAGIC)), fi * T_PB);
-          else
-            store_x2((uint64_t)__double_as_longlong(fma(factor(fi, 0), dx[0], T_MAGIC)),
-                     (uint64_t)__double_as_longlong(fma(factor(fi, 1), dx[1], T_MAGIC)), fi * T_PB);
+        if (row_live(fi)) {
+          if constexpr (consume) {
+            const v4i B = {Ba[0], Ba[1], Bb[0], Bb[1]};
+            t_mfma<true>(acc[fi][0], A0, B);
+            t_mfma<true>(acc[fi][1], A1, B);
+          }
+          if constexpr (produce) {
+            // the words of chunk s + 1, row set fi: behind the MFMAs that took chunk s's (the region is single-buffered)
+            if constexpr (YS && fi == JN)
+              store_x2((uint64_t)__double_as_longlong(fma(factor_y(0), dy[0], T_MAGIC)),
+                       (uint64_t)__double_as_longlong(fma(factor_y(1), dy[1], T_MAGIC)), fi * T_PB);
+            else
+              store_x2((uint64_t)__double_as_longlong(fma(factor(fi, 0), dx[0], T_MAGIC)),
+                       (uint64_t)__double_as_longlong(fma(factor(fi, 1), dx[1], T_MAGIC)), fi * T_PB);
+          }
         }
         Ba = Na;
         Bb = Nb;
@@ -400,22 +426,23 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       int j;
       double dsc;
       double *base;
-      size_t stride = (size_t)K * (ufrag < 0 ? I8_CPAD : 1) * 8;  // one replicate
+      size_t stride = (size_t)K * (ufrag < 0 ? a.cpad : 1) * 8;  // one replicate
+      const int64_t cpad = a.cpad;  // columns of a partial-sum row: 32, or 4 NQ for a narrow state
       if (ufrag < 0 && YS && rs == JN) {
         // the second matrix: [window][replicate][digit slot][column], scale = max|w| x its own column scale
-        const int c = 4 * wave + tcl;
+        const int c = 4 * quad + tcl;
         valid = valid && c < a.C;
         j = 0;
         dsc = wty[I8_WT_DSP + 0] * wty[I8_WT_DSC + (c < a.C ? c : 0)];
-        base = a.part_y + (((size_t)win * a.nrep_pad + rep0 + 32 * h + 4 * half) * 8 + tdg) * I8_CPAD + c + opq;
-        stride = (size_t)8 * I8_CPAD;
+        base = a.part_y + (((size_t)win * a.nrep_pad + rep0 + 32 * h + 4 * half) * 8 + tdg) * cpad + c + opq;
+        stride = (size_t)8 * cpad;
       } else if (ufrag < 0) {
-        const int c = 4 * wave + tcl;
-        valid = valid && c < a.C;
-        j = J0 + rs;
+        const int c = 4 * quad + tcl;
+        valid = valid && c < a.C && row_live(rs);
+        j = J0 + (row_live(rs) ? g + rs * GS : 0);
         dsc = wt[I8_WT_DSP + j] * wt[I8_WT_DSC + (c < a.C ? c : 0)];
         // [window][replicate][power][digit slot][column]
-        base = a.part_x + ((((size_t)win * a.nrep_pad + rep0 + 32 * h + 4 * half) * K + j) * 8 + tdg) * I8_CPAD + c + opq;
+        base = a.part_x + ((((size_t)win * a.nrep_pad + rep0 + 32 * h + 4 * half) * K + j) * 8 + tdg) * cpad + c + opq;
       } else {
         const int m = 4 * ufrag + tcl;
         valid = valid && m < JN;
@@ -438,7 +465,8 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     bool first_tile = true;
     uint32_t *cnt_cur = cnt_a, *cnt_nxt = cnt_b;
-    XIn XR[T_XD];  // the wave's columns of a chunk, requested T_XD k-steps ahead: chunk c lives in slot c % T_XD
+    constexpr int XD = NQ == 8 ? T_XD : T_XDN, UNR = XD > 4 ? XD : 4;
+    XIn XR[XD];  // the wave's columns of a chunk, requested XD k-steps ahead: chunk c lives in slot c % XD
     auto load_chunk = [&](int64_t wb, int c, XIn &R) { load_x(wb + c * 32, R); };
     const double no_d[2] = {0.0, 0.0}, no_w[2] = {1.0, 1.0};
 
@@ -539,7 +567,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
       }
       if (first_tile) {
-        // the X words of chunk 0 (no matrix work yet; its u / w straight from memory), chunks 1 .. T_XD requested
+        // the X words of chunk 0 (no matrix work yet; its u / w straight from memory), chunks 1 .. XD requested
         double d_du[2], d_w[2] = {1.0, 1.0};
 #pragma unroll
         for (int uu = 0; uu < 2; ++uu) {
@@ -548,7 +576,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
         kstep(YES, NO, 0, XR[0], -1, d_du, d_w);
 #pragma unroll
-        for (int c = 1; c <= T_XD; ++c) load_chunk(wbase, c, XR[c % T_XD]);
+        for (int c = 1; c <= XD; ++c) load_chunk(wbase, c, XR[c % XD]);
         first_tile = false;
       }
       // park the staged tiles
@@ -572,22 +600,22 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       T_TICK(4);
 
       // ---- 32 k-steps, four per trip, NO barrier between them.  Step s contracts chunk s, slices chunk s + 1 from
-      // the ring slot (s + 1) % T_XD (x requested T_XD steps ago) and requests chunk s + 1 + T_XD into that slot.
+      // the ring slot (s + 1) % XD (x requested XD steps ago) and requests chunk s + 1 + XD into that slot.
       // Chunk 32 is the next tile's chunk 0 (words nobody reads when there is no next tile).
       auto target = [&](int c, int64_t &wb, int &cl2) {
         if (c < T_STEPS) { wb = wbase; cl2 = c; }
         else { wb = wnext; cl2 = has_next ? c - T_STEPS : T_STEPS - 1; }
       };
 #pragma unroll 1
-      for (int s = 0; s < T_STEPS; s += 4) {
+      for (int s = 0; s < T_STEPS; s += UNR) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < UNR; ++e) {
           const int sq = s + e;
-          XIn &R = XR[(e + 1) % T_XD];
+          XIn &R = XR[(e + 1) % XD];
           const XIn cur_x = R;
           int64_t wb;
           int cl2;
-          target(sq + 1 + T_XD, wb, cl2);
+          target(sq + 1 + XD, wb, cl2);
           load_chunk(wb, cl2, R);
           kstep(YES, YES, sq, cur_x, sq * 32, no_d, no_w);
           T_TICK(5);
@@ -625,15 +653,15 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 }
 
 // ---------------------------------------------------------------------------
-template <int J0, int JN, bool WEIGHTED, bool YS = false>
+template <int J0, int JN, bool WEIGHTED, bool YS = false, int NQ = 8>
 static int launch_pass_t(const I8Args &a, int K, size_t prog_bytes, hipStream_t st) {
   if (a.progress != nullptr) TXM_HIP(hipMemsetAsync(a.progress, 0, prog_bytes, st));
   const dim3 grid((unsigned)(a.n_chunks * a.n_rbg)), block(T_BLOCK);
-  constexpr int ns = JN + (YS ? 1 : 0), npt = JN + ((YS && WEIGHTED && J0 > 0) ? 1 : 0);
+  constexpr int gs = 8 / NQ, ns = (JN + gs - 1) / gs + (YS ? 1 : 0), npt = JN + ((YS && WEIGHTED && J0 > 0) ? 1 : 0);
   const size_t lds = (size_t)T_WAVES * (ns + 1) * T_PB + T_CNT_BYTES + 3u * I8_REPS * sizeof(uint32_t) +
                      (size_t)npt * SM_T * sizeof(double);
-  TXM_SET_MAX_LDS((&resample_i8t_kernel<J0, JN, WEIGHTED, YS>), lds);
-  hipLaunchKernelGGL((resample_i8t_kernel<J0, JN, WEIGHTED, YS>), grid, block, lds, st, a, K);
+  TXM_SET_MAX_LDS((&resample_i8t_kernel<J0, JN, WEIGHTED, YS, NQ>), lds);
+  hipLaunchKernelGGL((resample_i8t_kernel<J0, JN, WEIGHTED, YS, NQ>), grid, block, lds, st, a, K);
   TXM_LAUNCH_CHECK();
   return TXM_OK;
 }
@@ -650,13 +678,51 @@ bool i8t_applicable(const double *x, int64_t ldx_s, int64_t C) {
 // A second sample matrix (a.y) rides as one more row set of the LAST pass wherever that pass has four power row sets at
 // most -- every order but 4 (i8t_carries_y).
 bool i8t_carries_y(int64_t C, int K) {
-  const bool narrow = C <= 16 && K >= 2;  // narrow states run txm_resample_i8.hip's power-packed kernel
+  const bool narrow = C <= 16 && K >= 2;  // narrow states: the quad-sharing variant / txm_resample_i8.hip's power-packed kernel
   return !narrow && K != 5 && K >= 1 && K <= 8;
+}
+
+// narrow states (C <= 8 observables in the whole call, orders 1..7): the quad-sharing variant, one pass for every order.
+// 0: not a narrow-state shape.  TXM_I8T_NARROW=0 keeps txm_resample_i8.hip's power-packed kernel (A/B timing).
+int i8t_narrow_nq(int64_t C_call, int K) {
+  static const bool on = [] {
+    const char *e = getenv("TXM_I8T_NARROW"), *t = getenv("TXM_I8T");
+    return !(e && e[0] == '0') && !(t && t[0] == '0');
+  }();
+  if (!on || C_call > 8 || K < 2 || K > 8) return 0;
+  return C_call <= 4 ? 1 : 2;
+}
+int i8_cpad(int64_t C_call, int K) {
+  const int nq = i8t_narrow_nq(C_call, K);
+  return nq ? 4 * nq : I8_CPAD;
+}
+
+template <int NQ>
+static int launch_narrow_t(const I8Args &a, int K, bool weighted, size_t prog_bytes, hipStream_t st) {
+#define T_NARROW(JN_) (weighted ? launch_pass_t<0, JN_, true, false, NQ>(a, K, prog_bytes, st) : launch_pass_t<0, JN_, false, false, NQ>(a, K, prog_bytes, st))
+  switch (K) {
+    case 2: return T_NARROW(2);
+    case 3: return T_NARROW(3);
+    case 4: return T_NARROW(4);
+    case 5: return T_NARROW(5);
+    case 6: return T_NARROW(6);
+    case 7: return T_NARROW(7);
+    case 8: return T_NARROW(8);
+    default: set_error("resample_i8t: order out of range"); return TXM_ERR_INVALID;
+  }
+#undef T_NARROW
 }
 
 int launch_resample_i8t(const I8Args &a, int K, bool weighted, size_t prog_bytes, hipStream_t st) {
   int rc = TXM_OK;
   const bool ys = a.y != nullptr;
+  if (const int nq = i8t_narrow_nq(a.C_call, K)) {
+    if (ys) {
+      set_error("resample_i8t: no second matrix on the narrow-state kernel");
+      return TXM_ERR_INVALID;
+    }
+    return nq == 1 ? launch_narrow_t<1>(a, K, weighted, prog_bytes, st) : launch_narrow_t<2>(a, K, weighted, prog_bytes, st);
+  }
   if (ys && K == 5) {
     set_error("resample_i8t: a second matrix cannot ride on a five-power pass");
     return TXM_ERR_INVALID;

@@ -10,7 +10,7 @@ from bench import make_data
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20_000_000
 order = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 nrep = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
-C = 32
+C = int(sys.argv[4]) if len(sys.argv) > 4 else 32
 txa.require_gpu(0)
 x, u = make_data(N, C, 0, torch)
 s = eng.DeviceSampler(1, nrep, N)
