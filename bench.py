@@ -439,29 +439,24 @@ def main():
     live = "HIP events around every txm_resample_vals call of the timed steps (window pre-pass + guard list + memset + contraction + finalize)"
     roofline_fp64 = None
     if path == "int8":
-        # executed int8 operations: what the 8 waves of a workgroup issue per k-step (txm_resample_i8.hip: two
-        # pair rows x 4 tiles + one plain fragment x 2 tiles per wave, minus the slots past the last row)
-        # passes as (row sets, u-row monomials): one power per column, five powers per pass (txm_resample_i8.hip:
-        # launch_resample_i8), or -- narrow states -- four (C <= 8) / two (C <= 16) powers per observable column
+        # executed int8 operations (txm_resample_i8t.hip): per workgroup (8 waves x 64 replicates) and k-step of 32
+        # samples, every (column quad, power) fragment is contracted for both replicate halves (2 MFMAs) and every u-row
+        # fragment (4 monomials) for both halves.  C > 16: 8 quads per 32-column group, orders 5..7 in two passes over the
+        # sampler stream; narrow states (C <= 16): 1, 2 or 4 quads whose waves split the powers, one pass (four quads:
+        # orders 6, 7 in two)
         if C <= 16 and K >= 2:
-            # narrow states (txm_resample_i8.hip): four (C <= 8) / two (C <= 16) powers per observable column; per
-            # workgroup and k-step 4 tiles per pair row (two digits x two replicate halves), 2 per plain fragment
-            pk = 4 if C <= 8 else 2
-            jn = -(-K // pk)
-            n_mfma = 4 * 3 * jn + 2 * (jn + -(-8 * min(K, jn * pk) // 32))
-            kname = "txm::resample_i8_kernel"
-            kdesc = ("bootstrap contraction on the int8 matrix pipe by exact 7-digit fixed-point slicing, several powers "
-                     "per observable column, Philox stage 3 fused")
+            nq = 1 if C <= 4 else 2 if C <= 8 else 4
+            passes = [4, K - 4] if (nq == 4 and K >= 7) else [K]
+            what = f"narrow state, {nq} column quad(s) whose waves split the powers; "
         else:
-            # one power per column (txm_resample_i8t.hip): per workgroup (8 waves x 64 replicates) and k-step of 32
-            # samples, every wave contracts its column quad of every row set for both replicate halves (2 JN MFMAs) and
-            # 2 ceil(JN / 4) waves one u-row tile; orders 5..7 take two passes over the sampler stream
+            nq = 8
             passes = {1: [1], 2: [2], 3: [3], 4: [4], 5: [5], 6: [3, 3], 7: [4, 3], 8: [4, 4]}[K]
-            n_mfma = sum(16 * jn + 2 * -(-jn // 4) for jn in passes)
-            kname = "txm::resample_i8t_kernel"
-            kdesc = ("bootstrap contraction on the int8 matrix pipe: 51-bit fixed-point words sliced once per sample, "
-                     "byte-transposed by the LDS transposing read (ds_read_b64_tr_b8: 8 digit slots per word, 7 used), "
-                     "exact int32 accumulation, Philox stage 3 fused")
+            what = ""
+        n_mfma = sum(2 * nq * jn + 2 * -(-jn // 4) for jn in passes)
+        kname = "txm::resample_i8t_kernel"
+        kdesc = (what + "bootstrap contraction on the int8 matrix pipe: 51-bit fixed-point words sliced once per sample, "
+                 "byte-transposed by the LDS transposing read (ds_read_b64_tr_b8: 8 digit slots per word, 7 used), "
+                 "exact int32 accumulation, Philox stage 3 fused")
         ksteps = -(-nrep_rank // 64) * (-(-N // 1024) * 32) * -(-C // 32)   # replicate groups x k-steps x column groups
         i8_ops = 2.0 * 32 * 32 * 32 * n_mfma * ksteps
         tops = i8_ops / (t_boot * 1e-3) / 1e12

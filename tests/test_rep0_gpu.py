@@ -188,6 +188,19 @@ def test_second_matrix_means_equal_separate_order0_bootstrap(eng, orc):
                     sep = eng.resample_vals(y, u, 0, sampler=smp, w=ww)[:, :, 1, 0]
                 assert torch.equal(st, st0), (order, path, ww is not None)
                 assert ((ym - sep).abs() <= 1e-13 * (sep.abs() + y.std())).all(), (order, path, ww is not None)
+    # wide states (a 32-column group carrying y plus a tail group) and narrow ones (the quad-sharing kernels bootstrap
+    # y on their own behind the same entry point)
+    for Cw, order in ((40, 2), (40, 5), (8, 3), (12, 2), (3, 4)):
+        xw, uw = _data(N, Cw, 18)
+        yw_, _ = _data(N, Cw, 19)
+        smp = eng.DeviceSampler(13, nrep, N)
+        with eng.forced_path("int8"):
+            st, ymw = eng.resample_vals(xw, uw, order, sampler=smp, y=yw_)
+            assert eng.resample_info()["path"] == "int8"
+            st0 = eng.resample_vals(xw, uw, order, sampler=smp)
+            sep = eng.resample_vals(yw_, uw, 0, sampler=smp)[:, :, 1, 0]
+        assert torch.equal(st, st0), (Cw, order)
+        assert ((ymw - sep).abs() <= 1e-13 * (sep.abs() + yw_.std())).all(), (Cw, order)
     order = 4
     f = eng.DeviceSampler(12, 2, N).freq().cpu().numpy()
     yw = (y.cpu().numpy() * (f[1] * w.cpu().numpy())[:, None]).sum(0) / (f[1] * w.cpu().numpy()).sum()

@@ -86,8 +86,8 @@ int launch_resample_i8t(const I8Args &a, int K, bool weighted, size_t prog_bytes
 // true when a call of this shape carries a second sample matrix inside its last pass (else the caller bootstraps it on its own)
 bool i8t_carries_y(int64_t C, int K);
 bool i8t_applicable(const double *x, int64_t ldx_s, int64_t C);  // C = all columns of the call
-// narrow states (C <= 8 observables): column quads of the transposing-read kernel's quad-sharing variant (1 or 2), 0 = the
-// shape is not served by it; i8_cpad = the columns of a row of I8Args::part_x for the shape (4, 8 or 32)
+// narrow states (C <= 16 observables): column quads of the transposing-read kernel's quad-sharing variant (1, 2 or 4), 0 =
+// the shape is not served by it; i8_cpad = the columns of a row of I8Args::part_x for the shape (4, 8, 16 or 32)
 int i8t_narrow_nq(int64_t C_call, int K);
 int i8_cpad(int64_t C_call, int K);
 

@@ -1,19 +1,18 @@
-// txm_resample_i8t.hip -- the int8 bootstrap contraction with the data operand built by the LDS TRANSPOSING READ of
-// gfx950 (ds_read_b64_tr_b8).  Same sums, same fixed-point slicing and same sampler stream as txm_resample_i8.hip
-// (cmomy.wrap_resample_vals as called from thermoextrap data.py:1803-1810, 1354-1366):
+// txm_resample_i8t.hip -- the bootstrap contraction on the int8 matrix pipe, the data operand built by the LDS
+// TRANSPOSING READ of gfx950 (ds_read_b64_tr_b8).  The sums (cmomy.wrap_resample_vals as called from thermoextrap
+// data.py:1803-1810, 1354-1366; fixed-point slicing, scaling windows and the precision guard: txm_resample_i8.hip):
 //        S1[r][c][j] = sum_i f[r][i] w_i du_i^j dx_ic        S0[r][j] = sum_i f[r][i] w_i du_i^j
 //
-// Why another kernel.  In txm_resample_i8.hip every monomial X = rint(m 2^50) is cut into its seven int8 digits by
-// the VALU (v_perm, v_xor), stored digit by digit into MFMA-ready fragments in LDS (22 stores per wave and k-step)
-// and de-interleaved again by the consumer: the k-step is bound by the LDS write path and by the vector issue of that
-// byte shuffling, the matrix pipe idles at 24 %.  Here the 8-byte fixed-point word is stored AS IT IS -- one
-// ds_write_b128 per lane, power and pair of columns: [fragment][sample][4 columns][8 bytes] -- and the byte transpose
-// is done by the LDS hardware on the way back: one ds_read_b64_tr_b8 hands every lane of a 16-lane group one BYTE
-// COLUMN of 8 rows x 16 bytes, i.e. digit (lane & 7) of column (lane >> 3) for 8 consecutive samples -- exactly one
-// half of an MFMA B operand whose 32 columns are (4 observable columns) x (8 digit slots).  Slot 7 (the exponent byte
-// of the magic-constant double) is a dead column: 12.5 % more MFMAs, no vector instruction at all between the LDS and
-// the matrix pipe.  Per monomial the VALU work is one v_fma_f64 and two v_xor_b32 (bias removal), against ~10
-// instructions before; the kernel is now paced by the matrix pipe.
+// The design in one paragraph.  The round-1/2 kernel cut every monomial X = rint(m 2^50) into its seven int8 digits on
+// the VALU (v_perm, v_xor), stored them digit by digit into MFMA-ready fragments in LDS (22 stores per wave and k-step)
+// and de-interleaved them again on the read side: its k-step was bound by the LDS write path and by the vector issue of
+// that byte shuffling, the matrix pipe idled at 24 %.  Here the 8-byte fixed-point word is stored AS IT IS -- its low
+// and high dwords into two planes [sample][4 columns] -- and the byte transpose is done by the LDS hardware on the way
+// back: one ds_read_b64_tr_b8 hands every lane of a 16-lane group one BYTE COLUMN of 8 rows x 16 bytes, i.e. digit
+// (i & 3) of column (i >> 2) of a plane for 8 consecutive samples -- one half of an MFMA B operand whose 32 tile columns
+// are (4 observable columns) x (8 digit slots).  Slot 7 (the exponent byte of the magic-constant double) is a dead
+// column: 12.5 % more MFMAs, no vector instruction at all between the LDS and the matrix pipe.  Per monomial the VALU work
+// is one v_fma_f64 and two v_xor_b32 (bias removal), against ~10 instructions before.
 //
 // Workgroup = 8 waves (two per SIMD, 256 registers: up to 11 int32 accumulator tiles of 32 x 32 per wave) x 64
 // replicates x one group of 32 observable columns.  (One wave per SIMD with 21 tiles was built first: an in-order wave
@@ -22,12 +21,13 @@
 //   fragment f = (row set rs, column quad cq): rs = power J0 + rs of the launch; 32 tile columns = columns 4 cq ..
 //   4 cq + 3 x digit slots 0..7.  u-row fragments (dx = 1): tile column = (monomial, digit slot), 4 monomials each.
 //   wave w owns column quad w of every row set (both replicate halves) from the global load to the accumulators;
-//   waves 0..3 also one u-row tile each.  (A first cut shared one X table between the waves with a barrier per k-step
-//   and ds_write_b128 stores: every wave was in the same phase at the same time and the k-step behaved like the SUM of
-//   its LDS, vector and matrix time -- see the kernel's comment for what replaced it.)
+//   2 ceil(JN / 4) of the waves also one u-row tile each.  Narrow states (C <= 16): the waves that share a column quad
+//   split the powers (template parameter NQ, see the kernel).
+//   (A first cut shared one X table between the waves with a barrier per k-step: every wave was in the same phase at
+//   the same time and the k-step behaved like the SUM of its LDS, vector and matrix time.)
 // Count tile: cnt[word g = sample / 4][replicate], one u32 = the u8 counts of 4 samples.  Stage 3 of the sampler runs
 // with ONE LANE PER REPLICATE (lane = replicate, the eight waves split the Philox calls): all 64 lanes of a ds_add hit
-// 64 consecutive words -- no bank conflict by construction (the old layout lost 11 cycles per ds_add to conflicts).
+// 64 consecutive words -- no bank conflict by construction (a [replicate][word] layout lost 11 cycles per ds_add).
 // Partial sums: one slot per SCALING WINDOW (a fixed block of samples: the window size depends on N only),
 // part[window][replicate][power][digit slot][column], stored once -- no read-modify-write, no zeroing -- and added up
 // by the finalize kernel in window order.  A replicate's result therefore does not depend on how many replicates,
@@ -142,17 +142,17 @@ constexpr int T_PLANE = 512, T_PB = 2 * T_PLANE + 128;  // bytes per (wave, powe
 // YS: the launch carries one more row set, the order-0 monomial w * dy of a SECOND sample matrix y (I8Args::y: the
 // volume callback's dx/dq, txm_resample_opts.y) -- its per-replicate sums ride on the same count tile and k-steps.
 //
-// NQ < 8: a NARROW state (C <= 4 NQ observables, NQ = 1 or 2 column quads).  The 8 / NQ waves that share a column
+// NQ < 8: a NARROW state (C <= 4 NQ observables, NQ = 1, 2 or 4 column quads).  The 8 / NQ waves that share a column
 // quad split the powers between them: wave w owns quad w % NQ and the powers g, g + GS, g + 2 GS ... (g = w / NQ,
 // GS = 8 / NQ) -- ceil(JN / GS) row sets per wave instead of JN, every MFMA column in use, all orders in one pass.
 // The u-row tiles go to the last waves (the ones with the fewest power rows).
 template <int J0, int JN, bool WEIGHTED, bool YS = false, int NQ = 8>
 __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void resample_i8t_kernel(const I8Args a, const int K) {
-  static_assert(NQ == 8 || NQ == 2 || NQ == 1, "column quads");
+  static_assert(NQ == 8 || NQ == 4 || NQ == 2 || NQ == 1, "column quads");
   constexpr int GS = 8 / NQ;                  // waves per column quad = stride of a wave's powers
   constexpr int NSW = (JN + GS - 1) / GS;     // power row sets per wave
   static_assert(JN >= 1 && NSW + (YS ? 1 : 0) <= 5 && J0 + JN <= 8, "power range");
-  static_assert(NQ == 8 || (!YS && J0 == 0), "narrow states: one pass, no second matrix");
+  static_assert(NQ == 8 || !YS, "narrow states: no second matrix");
   constexpr int NS = NSW + (YS ? 1 : 0);  // row sets of the launch = x fragments per wave
   constexpr int NPT = JN + ((YS && WEIGHTED && J0 > 0) ? 1 : 0);  // staged factor tiles (the y row set needs plain w)
   constexpr int UF = (JN + 3) / 4;   // u-row fragments (4 monomials each)
@@ -682,15 +682,12 @@ bool i8t_carries_y(int64_t C, int K) {
   return !narrow && K != 5 && K >= 1 && K <= 8;
 }
 
-// narrow states (C <= 8 observables in the whole call, orders 1..7): the quad-sharing variant, one pass for every order.
-// 0: not a narrow-state shape.  TXM_I8T_NARROW=0 keeps txm_resample_i8.hip's power-packed kernel (A/B timing).
+// narrow states (C <= 16 observables in the whole call, orders 1..7): the quad-sharing variant -- one pass for every order
+// with one or two column quads, orders 6 and 7 in two passes with four (LDS: the factor tiles of 7 or 8 powers do not fit
+// next to four row sets per wave).  0: not a narrow-state shape.
 int i8t_narrow_nq(int64_t C_call, int K) {
-  static const bool on = [] {
-    const char *e = getenv("TXM_I8T_NARROW"), *t = getenv("TXM_I8T");
-    return !(e && e[0] == '0') && !(t && t[0] == '0');
-  }();
-  if (!on || C_call > 8 || K < 2 || K > 8) return 0;
-  return C_call <= 4 ? 1 : 2;
+  if (C_call > 16 || K < 2 || K > 8) return 0;
+  return C_call <= 4 ? 1 : C_call <= 8 ? 2 : 4;
 }
 int i8_cpad(int64_t C_call, int K) {
   const int nq = i8t_narrow_nq(C_call, K);
@@ -721,7 +718,19 @@ int launch_resample_i8t(const I8Args &a, int K, bool weighted, size_t prog_bytes
       set_error("resample_i8t: no second matrix on the narrow-state kernel");
       return TXM_ERR_INVALID;
     }
-    return nq == 1 ? launch_narrow_t<1>(a, K, weighted, prog_bytes, st) : launch_narrow_t<2>(a, K, weighted, prog_bytes, st);
+    if (nq == 1) return launch_narrow_t<1>(a, K, weighted, prog_bytes, st);
+    if (nq == 2) return launch_narrow_t<2>(a, K, weighted, prog_bytes, st);
+#define T_N4(J0_, JN_) (weighted ? launch_pass_t<J0_, JN_, true, false, 4>(a, K, prog_bytes, st) : launch_pass_t<J0_, JN_, false, false, 4>(a, K, prog_bytes, st))
+    switch (K) {
+      case 2: return T_N4(0, 2);
+      case 3: return T_N4(0, 3);
+      case 4: return T_N4(0, 4);
+      case 5: return T_N4(0, 5);
+      case 6: return T_N4(0, 6);
+      case 7: rc = T_N4(0, 4); return rc != TXM_OK ? rc : T_N4(4, 3);
+      default: rc = T_N4(0, 4); return rc != TXM_OK ? rc : T_N4(4, 4);
+    }
+#undef T_N4
   }
   if (ys && K == 5) {
     set_error("resample_i8t: a second matrix cannot ride on a five-power pass");

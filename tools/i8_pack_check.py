@@ -1,4 +1,4 @@
-"""int8 kernel with several powers per observable column (narrow states) against the FP64 kernel and, at small size,
+"""int8 kernel on narrow states (the quad-sharing variant) against the FP64 kernel and, at small size,
 the oracle:  python tools/i8_pack_check.py"""
 import sys
 from pathlib import Path
