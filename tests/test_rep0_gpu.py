@@ -52,12 +52,15 @@ def test_sampler_rows_equal_offset_sampler_bit_for_bit(eng, orc, ndat, nsamp):
 
 
 @pytest.mark.parametrize("path,N,C,order,nrep", [("fp64", 40_000, 5, 3, 24), ("fp64", 300_000, 32, 4, 70),
+                                                 ("fp64", 3_000_000, 8, 3, 200), ("fp64", 3_000_000, 40, 2, 130),
                                                  ("int8", 300_000, 32, 4, 200), ("int8", 280_000, 8, 4, 130),
                                                  ("int8", 270_000, 32, 6, 70)])
 def test_resample_rows_equal_offset_call(eng, path, N, C, order, nrep):
     """resample_vals(sampler(seed, n, rep0 = k)) == rows k : k + n of the nrep-replicate call.  The sampler rows are the
-    same bits (previous test); the moment sums of a replicate are formed per fixed block of samples and added in block
-    order, whatever the launch geometry, so the states agree BIT FOR BIT."""
+    same bits (previous test); the moment sums of a replicate are formed per fixed block of samples (int8 path: scaling
+    windows; FP64 kernel: sample chunks whose number depends on N alone) and added in block order, whatever the launch
+    geometry, so the states agree BIT FOR BIT.  (The N = 3e6 FP64 cases are shapes where a chunking chosen "to fill
+    the chip" -- rounds 1 and 2 -- differed between the full call and its slabs.)"""
     x, u = _data(N, C, 5)
     seed = 77
     with eng.forced_path(path):
@@ -95,8 +98,10 @@ def test_state_shards_equal_slices_of_the_unsharded_collection(txm, eng, batched
     whole = coll.resample(spec, batched=batched)
     assert (whole._batch is not None) == (batched is None)
     vals = [torch.as_tensor(st.data.dxduave.device_values) for st in whole.states]
-    for a, b in ((0, 3), (3, 6), (2, 3), (0, 6)):               # the shards of 2 ranks, a single state, everything
-        sub = xtrap.models.StateCollection(coll.states[a:b]).resample(spec, batched=batched, state0=a)
+    # the shards of 2 ranks, single states (a rank that holds one state runs the batched kernels too: what
+    # _resample_sharded asks for with batched=True), everything
+    for a, b in ((0, 3), (3, 6), (2, 3), (0, 1), (0, 6)):
+        sub = xtrap.models.StateCollection(coll.states[a:b]).resample(spec, batched=True if batched is None else False, state0=a)
         for i, st in enumerate(sub.states):
             assert torch.equal(st.data.dxduave.device_values, vals[a + i]), (batched, a, b, i)
     # without the offset the shard [3, 6) would repeat the draws of states 0..2: the round-2 defect

@@ -689,6 +689,16 @@ struct ResamplePlan {
   size_t off_pivot, off_px, off_pu, off_prog, prog_bytes, total;
 };
 
+// tiles per sample chunk: ntiles / div chunks, at least 8 and at most 1024 of them (rounded to octets by the callers)
+static int64_t resample_chunk_tiles(int64_t ntiles, int64_t div) {
+  int64_t nc = ntiles / div;
+  if (nc > 1024) nc = 1024;
+  if (nc < 8) nc = 8;
+  if (nc > ntiles) nc = ntiles;
+  nc = cdiv(nc, 8) * 8;
+  return cdiv(ntiles, nc);
+}
+
 static ResamplePlan plan_resample(int64_t N, int64_t C, int64_t nrep, int K) {
   ResamplePlan p;
   p.nblk = C <= 16 ? 1 : 2;
@@ -697,14 +707,12 @@ static ResamplePlan plan_resample(int64_t N, int64_t C, int64_t nrep, int K) {
   p.n_rbg = (int)cdiv(nrep, RS_WAVES * RS_REPS);
   p.nrep_pad = (int64_t)p.n_rbg * RS_WAVES * RS_REPS;
   p.ntiles = cdiv(N, SM_T);
-  const int64_t target_wgs = (int64_t)num_cus() * 2 * 4;
-  int64_t nc = cdiv(target_wgs, (int64_t)p.n_rbg * p.colgroups);
-  if (nc > p.ntiles) nc = p.ntiles;
-  if (nc < 1) nc = 1;
-  nc = cdiv(nc, 8) * 8;
-  p.tiles_per_chunk = cdiv(p.ntiles, nc);
-  // drop chunk octets that would be entirely empty
-  nc = cdiv(cdiv(p.ntiles, p.tiles_per_chunk), 8) * 8;
+  // Sample chunks: their number is a function of N ALONE (ntiles / 2, between 8 and 1024).  A replicate's sums are formed
+  // per chunk and the chunks are added in a fixed order by resample_finalize_kernel, so with a chunking that does not
+  // look at nrep (it used to: "enough workgroups to fill the chip") the rows [a, b) of a bootstrap equal the (b - a)-
+  // replicate call with rep0 = a BIT FOR BIT on this kernel too, whatever the slab sizes (multi-GPU replicate slabs).
+  p.tiles_per_chunk = resample_chunk_tiles(p.ntiles, 2);
+  const int64_t nc = cdiv(cdiv(p.ntiles, p.tiles_per_chunk), 8) * 8;
   p.n_chunks = (int)nc;
   p.off_pivot = 0;
   p.off_px = align_up((size_t)(1 + C) * sizeof(double), 256);
@@ -1279,13 +1287,10 @@ static BatchPlan plan_batched(int64_t S, int64_t N, int64_t C, int64_t nrep, int
   BatchPlan b;
   ResamplePlan &p = b.one;
   p = plan_resample(N, C, nrep, K);
-  // S states fill the chip together: fewer sample chunks per state
-  const int64_t target_wgs = (int64_t)num_cus() * 2 * 4;
-  int64_t nc = cdiv(target_wgs, (int64_t)p.n_rbg * p.colgroups * S);
-  if (nc > p.ntiles) nc = p.ntiles;
-  if (nc < 1) nc = 1;
-  nc = cdiv(nc, 8) * 8;
-  p.tiles_per_chunk = cdiv(p.ntiles, nc);
+  // S states fill the chip together: fewer sample chunks per state (ntiles / 8) -- again a function of N alone, so that
+  // the states [s0, s1) of a collection give the same bits whichever call (rank) they are part of
+  (void)S;
+  p.tiles_per_chunk = resample_chunk_tiles(p.ntiles, 8);
   p.n_chunks = (int)(cdiv(cdiv(p.ntiles, p.tiles_per_chunk), 8) * 8);
   b.off_tab = 0;
   b.off_pivot = align_up((size_t)S * sizeof(txm_state_ptrs), 256);

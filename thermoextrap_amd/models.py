@@ -349,12 +349,14 @@ class StateCollection(_Params):
         return getattr(self[0], "alpha_name", "alpha")
 
     # ---- batched path: S states of one shape in one set of launches ----------------------
-    def _batch_eligible(self):
+    def _batch_eligible(self, min_states: int = 2):
         """The states' shared (N, column shape) when every state is an ExtrapModel over sample data
-        (DataCentralMomentsVals) of one shape / order / layout with the default callback, else None."""
+        (DataCentralMomentsVals) of one shape / order / layout with the default callback, else None.
+        A single state is worth the batched launch only as a SHARD of a collection (min_states=1): it must run the
+        kernels -- and so give the bits -- the unsharded collection's launch gives it."""
         from .data import DataCallback, DataCentralMomentsVals
 
-        if len(self) < 2:
+        if len(self) < min_states:
             return None
         key = None
         for st in self.states:
@@ -457,7 +459,8 @@ class StateCollection(_Params):
         is_spec = isinstance(sampler, Mapping) and "nrep" in sampler and "indices" not in sampler and "freq" not in sampler
         if sharded:
             return self._resample_sharded(sampler, batched=batched, **kws)
-        if batched is not False and is_spec and not kws and self._batch_eligible() is not None:
+        # (a shard of a collection -- state0 given, or batched=True -- takes the batched launch even with one state)
+        if batched is not False and is_spec and not kws and self._batch_eligible(1 if (state0 or batched) else 2) is not None:
             return self._resample_batched(sampler, state0=state0)
         if batched is True:
             raise ValueError("batched=True needs ExtrapModel states over DataCentralMomentsVals of one shape and a "
@@ -505,6 +508,8 @@ class StateCollection(_Params):
         mine = D.shard_range(len(self), rank, w)
         if len(mine) == 0:
             raise ValueError("more ranks than states: give every rank at least one state")
+        if batched is None and not kws and self._batch_eligible() is not None:
+            batched = True  # every shard on the batched kernels, also a rank that holds one state
         sub = type(self)(states=tuple(self.states[i] for i in mine), kws=self.kws).resample(
             spec, batched=batched, state0=mine[0], **kws)
         slabs = torch.stack([st.data.dxduave.device_values for st in sub.states])
