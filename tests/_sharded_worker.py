@@ -1,0 +1,72 @@
+"""Worker of tests/test_sharded_gpu.py: one rank of a 2-rank gloo group, every rank on cuda:0.
+Checks, on a real device, that what the ranks compute together equals the one-process result BIT FOR BIT:
+  * StateCollection.resample(spec, sharded=True)  (5 states: shards of 3 and 2 -- and of 1 for a 5-rank layout emulated
+    by hand below)                                  vs  StateCollection.resample(spec)
+  * distributed.run_step("replicas", ...)           vs  the full-nrep call, on both bootstrap kernels
+Writes <outdir>/rank<r>.json."""
+import json
+import os
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+import torch
+import torch.distributed as dist
+
+
+def main(outdir):
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    import thermoextrap_amd as xtrap
+    from thermoextrap_amd import distributed as D, engine as eng
+    from thermoextrap_amd.moments import DeviceDataArray
+
+    xtrap.require_gpu(0)
+    res = {"rank": rank, "world": world}
+
+    def data(N, C, seed):
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        u = 174.85 + 5.31 * torch.randn(N, generator=g, dtype=torch.float64, device="cuda")
+        x = 0.2 + 1e-3 * u[:, None] + 0.05 * torch.randn(N, C, generator=g, dtype=torch.float64, device="cuda")
+        return x, u
+
+    # ---- state shards
+    S, N, C, order, nrep = 5, 30_000, 3, 3, 20
+    sts = []
+    for s in range(S):
+        x, u = data(N, C, 700 + s)
+        d = xtrap.DataCentralMomentsVals.from_vals(xv=DeviceDataArray(x, ("rec", "val")), uv=DeviceDataArray(u, ("rec",)),
+                                                   order=order, central=True)
+        sts.append(xtrap.beta.factory_extrapmodel(1.0 + 0.25 * s, d))
+    coll = xtrap.models.StateCollection(sts)
+    spec = {"nrep": nrep, "seed": 99, "device": True}
+    sharded = coll.resample(spec, sharded=True)
+    whole = coll.resample(spec)
+    res["states_equal"] = all(torch.equal(a.data.dxduave.device_values, b.data.dxduave.device_values)
+                              for a, b in zip(sharded.states, whole.states))
+    res["states_batch_equal"] = bool(torch.equal(sharded._batch["big"], whole._batch["big"]))
+    # a spec without a seed: rank 0 draws one and broadcasts it -- every rank must end up with the same collection
+    unseeded = coll.resample({"nrep": nrep, "device": True}, sharded=True)
+    mine = unseeded._batch["big"].cpu()
+    ref = mine.clone()
+    dist.broadcast(ref, src=0)
+    res["unseeded_consistent"] = bool(torch.equal(mine, ref))
+
+    # ---- replicate slabs of one state point, both kernels
+    N2, C2, order2, nrep2 = 290_000, 32, 4, 130
+    x, u = data(N2, C2, 5)
+    for path in ("int8", "fp64"):
+        with eng.forced_path(path):
+            def compute(n, seed, rep0):
+                return eng.resample_vals(x, u, order2, sampler=eng.DeviceSampler(seed, n, N2, rep0=rep0))
+            got = D.run_step("replicas", compute, nrep2, 4321)
+            full = compute(nrep2, 4321, 0)
+        res[f"replicas_equal_{path}"] = bool(torch.equal(got, full))
+    Path(outdir, f"rank{rank}.json").write_text(json.dumps(res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -1,0 +1,33 @@
+"""Two REAL ranks (gloo rendezvous on 127.0.0.1, both on cuda:0) against one process: the round-2 advice asked for a
+2-rank test asserting sharded == unsharded for a fixed seed.  The collective path itself is also covered on the CPU
+(tests/test_distributed_cpu.py); this one runs the product kernels under it."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_ranks_equal_one_process_bit_for_bit(txm, tmp_path):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(ROOT / "tests" / "_sharded_worker.py"), str(tmp_path)]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    for r in range(2):
+        res = json.loads((tmp_path / f"rank{r}.json").read_text())
+        assert res["world"] == 2 and res["rank"] == r
+        for k in ("states_equal", "states_batch_equal", "unseeded_consistent", "replicas_equal_int8", "replicas_equal_fp64"):
+            assert res[k] is True, (r, k, res)

@@ -577,21 +577,22 @@ __global__ __launch_bounds__(256) void resample_finalize_kernel(
 // [column] (u-row: [window][replicate][power][8]); windows in ascending order, digits in ascending order -- a fixed order
 // that does not depend on the launch geometry.  Windows the precision guard flagged hold nothing: they were contracted
 // by the FP64 kernel, whose sums are added behind (same pivot).
-template <int K>
+template <int K, int CPAD>
 __global__ __launch_bounds__(256) void resample_finalize_i8_kernel(
     const double *__restrict__ part_x, const double *__restrict__ part_u, int64_t nwin,
     const uint32_t *__restrict__ wflag, int64_t nrep_pad, int64_t nrep, int64_t C,
     const double *__restrict__ pivot, double *__restrict__ out, int64_t c_off, int64_t C_total,
     const double *__restrict__ fb_x, const double *__restrict__ fb_u, int fb_chunks, int64_t fb_cpad,
-    const uint32_t *__restrict__ n_list, const int cpad) {
-  // cpad = columns of a row of part_x (32; 4 or 8 where the narrow-state kernel wrote it)
+    const uint32_t *__restrict__ n_list) {
+  // CPAD = columns of a row of part_x (32; 4, 8 or 16 where the narrow-state kernel wrote it)
+  constexpr int cpad = CPAD;
   // one workgroup per replicate: thread = (column c < cpad, window segment seg of 256 / cpad).  Segment seg adds the
   // windows seg, seg + nseg, ... in ascending order, then the segments are added in order: a fixed tree that depends on
   // the number of windows (i.e. on N) and on the state's width only, not on the launch geometry.  (One thread per output
   // walking all windows was latency-bound on short series with few outputs: 1600 threads x 611 windows at BASELINE
   // config 2; so were 8 segments for an 8-column state.)
   __shared__ double sh[256][2 * K];
-  const int nseg = 256 / cpad;
+  constexpr int nseg = 256 / cpad;
   const int64_t r = blockIdx.x;
   const int c = threadIdx.x % cpad, seg = threadIdx.x / cpad;
   double S0[K], S1[K];
@@ -1145,10 +1146,17 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
         const int rc2 = run_listed(f, q.fb, K, w != nullptr, st);
         if (rc2 != TXM_OK) return rc2;
       }
-#define TXM_I8_FIN(KK)                                                                                 \
-  hipLaunchKernelGGL((resample_finalize_i8_kernel<KK>), dim3((unsigned)nrep), dim3(256), 0, st,          \
+#define TXM_I8_FIN2(KK, CP)                                                                            \
+  hipLaunchKernelGGL((resample_finalize_i8_kernel<KK, CP>), dim3((unsigned)nrep), dim3(256), 0, st,      \
                      b.part_x, b.part_u, q.nwin, b.wflag, q.nrep_pad, nrep, b.C, piv, out, col0, C,        \
-                     f.part_x, f.part_u, q.fb.n_chunks, q.fb.C_pad, b.n_list, b.cpad)
+                     f.part_x, f.part_u, q.fb.n_chunks, q.fb.C_pad, b.n_list)
+#define TXM_I8_FIN(KK)                                                                                 \
+  do {                                                                                                 \
+    if (b.cpad == 32) TXM_I8_FIN2(KK, 32);                                                             \
+    else if (b.cpad == 16) TXM_I8_FIN2(KK, 16);                                                        \
+    else if (b.cpad == 8) TXM_I8_FIN2(KK, 8);                                                          \
+    else TXM_I8_FIN2(KK, 4);                                                                           \
+  } while (0)
       switch (K) {
         case 1: TXM_I8_FIN(1); break;
         case 2: TXM_I8_FIN(2); break;
