@@ -109,10 +109,16 @@ __device__ __forceinline__ void t_fill_call(uint32_t *cntw, uint32_t k0, uint32_
 #pragma unroll
   for (int wi = 0; wi < 4; ++wi) {
     const uint32_t word = o.w[wi];
-    const uint32_t lo2 = word & 0x00300C03u;  // bits {0, 1} of the three fields: the byte lane
+    // byte lane of every field at once: keep bits {0, 1} of the three fields, so that a plain shift leaves 8 * (f & 3) in
+    // the five bits the shifter reads and zeros below them.  The opaque values keep this selection (mask once; bfe +
+    // lshl_add for the address): 4 instead of 6 vector instructions per draw -- left alone the optimiser re-splits the
+    // shared mask into shift, and, and per field
+    uint32_t lo2 = word & 0x00300C03u;
+    asm volatile("" : "+v"(lo2));
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const uint32_t q = __builtin_amdgcn_ubfe(word, 10 * k + 2, 8);  // field >> 2: the count word of the sample
+      uint32_t q = __builtin_amdgcn_ubfe(word, 10 * k + 2, 8);  // field >> 2: the count word of the sample
+      asm volatile("" : "+v"(q));
       uint32_t inc = 1u << (((k == 0) ? (lo2 << 3) : (lo2 >> (10 * k - 3))) & 31u);
       if (!ALL_VALID) inc = (first + (uint32_t)(wi * 3 + k) < n) ? inc : 0u;
       atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(cntw) + (q << 8) + lane4), inc);
@@ -165,10 +171,11 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   uint32_t *cnt_a = fsum + I8_REPS;         // [64] tile draw counts, double buffered
   uint32_t *cnt_b = cnt_a + I8_REPS;
   // the sample factors w du^(J0 + jj), jj < JN, of the 1024 samples whose X words this tile's k-steps produce (chunks
-  // 1 .. 31 of the tile and chunk 0 of the next one): staged once per tile by the whole workgroup as JN tiles of 8 KiB,
-  // so that a k-step loads nothing but x and spends one v_fma_f64 + two v_xor_b32 per word -- the powers are LDS
-  // reads (broadcast: four lanes per sample), not vector multiplies
-  double *ptile = reinterpret_cast<double *>(cnt_b + I8_REPS);  // [NPT][1024]
+  // 1 .. 31 of the tile and chunk 0 of the next one): staged once per tile by the whole workgroup (JN x 8 KiB), so that
+  // a k-step loads nothing but x and spends one v_fma_f64 + two v_xor_b32 per word -- the powers are LDS reads
+  // (broadcast: four lanes per sample), not vector multiplies.  Entry-major: the factors of a lane's two samples for one
+  // row set are one ds_read2_b64 off a common base (power-major they were two reads and two address adds per row set)
+  double *ptile = reinterpret_cast<double *>(cnt_b + I8_REPS);  // [1024 entries][NPT factors]: a lane's factors of all row sets in one line
 
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int n32 = lane & 31, half = lane >> 5;
@@ -188,7 +195,6 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // transposing read of (plane g, rows 16 half + 0..7): lane 2 q + p of the 16-lane group supplies row q, bytes 8 p ..
   const uint32_t rd_off = wreg + (uint32_t)(((lane >> 4) & 1) * (T_PLANE + 128) + (16 * half + ((lane & 15) >> 1)) * 16 +
                                             (lane & 1) * 8);  // + power * T_PB; second read + 128
-  const uint32_t a_off = (uint32_t)((4 * half) * I8_REPS + n32);  // words; + 8 s * 64 + q * 64 (+ 32: second half)
   // tile column n32 -> (column, digit slot)
   const int tcl = (n32 >> 2) & 3, tdg = 4 * (n32 >> 4) + (n32 & 3);
   // u-row tile of waves 0 .. 2 UF - 1: fragment fu (monomials 4 fu .. 4 fu + 3), replicate half uh
@@ -196,6 +202,11 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const int uw = NQ == 8 ? wave : wave - (T_WAVES - NUT);
   const bool has_ut = uw >= 0 && uw < NUT;  // wave-uniform
   const int fu = has_ut ? (uw >> 1) : 0, uh = uw & 1;
+  // A wave with a u-row tile for replicate half 1 takes the halves in swapped order (operand A0 = ITS u-row half, flushed
+  // as such): the u-row MFMA then needs no per-step selection between the two count operands (four v_cndmask)
+  const int hswap = (has_ut && uh) ? 1 : 0;  // wave-uniform
+  const uint32_t a_off = (uint32_t)((4 * half) * I8_REPS + n32 + 32 * hswap);  // words of operand A0; + 8 s * 64 + q * 64
+  const uint32_t a_off1 = hswap ? (uint32_t)(-32 * 4) : (uint32_t)(32 * 4);   // bytes from A0's words to A1's
   const int um = 4 * fu + cl;      // this lane's u-row monomial
   const int umc = um < JN ? um : 0;
 
@@ -284,13 +295,10 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       const uint32_t lo1 = (uint32_t)bits1 ^ 0x80808080u, hi1 = (uint32_t)(bits1 >> 32) ^ 0x00008080u;
 #ifdef TXM_T_NO_WRITE  // ablation build: the values stay live, nothing is stored
       asm volatile("" ::"v"(lo0), "v"(hi0), "v"(lo1), "v"(hi1));
-#elif defined(TXM_T_STORE1)
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%3\n\tds_write_addtid_b32 %1 offset:%4"
-                   : : "v"(lo0), "v"(hi0), "s"(wreg), "n"(off), "n"(off + T_PLANE + 128) : "memory");
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%3\n\tds_write_addtid_b32 %1 offset:%4"
-                   : : "v"(lo1), "v"(hi1), "s"(wreg), "n"(off + 256), "n"(off + 256 + T_PLANE + 128) : "memory");
 #else
-      // (s_nop: one wait state between an SALU write of M0 and an add-TID LDS instruction)
+      // (s_nop: one wait state between an SALU write of M0 and an add-TID LDS instruction.  M0 as a tracked "{m0}" operand,
+      // set once per window, saves the twelve scalar instructions per k-step and buys nothing: 37.2 vs 36.9 ms, same box --
+      // the scalar unit is not what the k-steps wait for)
       asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\t"
                    "ds_write_addtid_b32 %0 offset:%5\n\t"
                    "ds_write_addtid_b32 %1 offset:%6\n\t"
@@ -318,10 +326,16 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       v2i Ba = (v2i)(0), Bb = (v2i)(0);
       if constexpr (consume) {
         const uint32_t *cw = cntw + s * (8 * I8_REPS) + a_off;
+        // the second replicate half through a base of its own (opaque): the load merger then pairs the words of ONE
+        // half -- ds_read2_b32 (q, q + 1) lands in adjacent registers of the operand -- instead of (half 0, half 1) of one
+        // word, which took eight v_mov per k-step to sort into the two operands
+        uint32_t off1 = a_off1;
+        asm volatile("" : "+v"(off1));
+        const uint32_t *cw1 = reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(cw) + off1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           A0[q] = (int)cw[q * I8_REPS];
-          A1[q] = (int)cw[q * I8_REPS + 32];
+          A1[q] = (int)cw1[q * I8_REPS];
         }
         Ba = T_TRREAD((lds_v2i)(lds + rd_off));
         Bb = T_TRREAD((lds_v2i)(lds + rd_off + 128));
@@ -336,10 +350,20 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
       }
       // factor jj of unit uu: a broadcast LDS read (staged) or du / w of the direct path multiplied up
-      const double *pt = ptile + (staged ? e0 : 0) + ps + g * SM_T;  // + fi * GS * 1024 + 16 * uu: immediate offsets
+      // (the base is an opaque byte offset: the staged tiles sit above 64 KiB, and with the constant folded in every read
+      // got a v_add_u32 of its own for "lane part + 0x1fb00"; an opaque base takes the 16-bit immediate offsets)
+      const uint32_t pt_lds = (uint32_t)(reinterpret_cast<const unsigned char *>(ptile) - lds);  // compile-time constant
+      uint32_t pt_b = pt_lds + (uint32_t)((((staged ? e0 : 0) + ps) * NPT + g) * 8);
+      uint32_t pu_b = pt_lds + (uint32_t)((((staged ? e0 : 0) + ps) * NPT + umc) * 8);
+      asm volatile("" : "+v"(pt_b), "+v"(pu_b));
+      typedef __attribute__((address_space(3))) const double *lds_cd;
+      auto pt_at = [&](uint32_t base, int idx) { return ((lds_cd)(lds + base))[idx]; };  // (cast first: the index is then a 32-bit LDS offset)
       auto factor = [&](int fi, int uu) {  // row set fi = power J0 + g + fi GS
         if (NQ == 8 && !WEIGHTED && J0 == 0 && fi == 0) return 1.0;
-        if (staged) return pt[fi * GS * SM_T + 16 * uu];
+#ifdef TXM_T_NO_FACTOR  // ablation build: no factor read (wrong sums)
+        if (staged) return 0.5 + fi;
+#endif
+        if (staged) return pt_at(pt_b, fi * GS + 16 * NPT * uu);
         double pw = WEIGHTED ? d_w[uu] : 1.0;
         for (int q = 0; q < J0 + g + fi * GS; ++q) pw *= d_du[uu];
         return pw;
@@ -348,7 +372,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       auto factor_y = [&](int uu) {
         if (!WEIGHTED) return 1.0;
         if (!staged) return d_w[uu];
-        return J0 == 0 ? pt[16 * uu] : pt[JN * SM_T + 16 * uu];  // tile 0 is w du^0 when J0 == 0, else the extra tile (NQ = 8: g = 0)
+        return J0 == 0 ? pt_at(pt_b, 16 * NPT * uu) : pt_at(pt_b, JN + 16 * NPT * uu);  // tile 0 is w du^0 when J0 == 0, else the extra tile (NQ = 8: g = 0)
       };
       t_static_for<NS>([&](auto fic) {
         constexpr int fi = decltype(fic)::value;
@@ -385,13 +409,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
           Ba = T_TRREAD((lds_v2i)(lds + rd_off + NS * T_PB));
           Bb = T_TRREAD((lds_v2i)(lds + rd_off + NS * T_PB + 128));
           const v4i B = {Ba[0], Ba[1], Bb[0], Bb[1]};
-#ifdef TXM_T_UH_BRANCH
-          if (uh) t_mfma<false>(accu, A1, B);  // wave-uniform
-          else t_mfma<false>(accu, A0, B);
-#else
-          const v4i Au = {uh ? A1[0] : A0[0], uh ? A1[1] : A0[1], uh ? A1[2] : A0[2], uh ? A1[3] : A0[3]};
-          t_mfma<false>(accu, Au, B);
-#endif
+          t_mfma<false>(accu, A0, B);  // A0 = the wave's u-row half (hswap)
         }
         if constexpr (produce) {
           // monomial um of this lane's sample (dx = 1); the unused monomial slots of a short fragment repeat monomial 0:
@@ -399,7 +417,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
           double pw[2];
 #pragma unroll
           for (int uu = 0; uu < 2; ++uu) {
-            if (staged) pw[uu] = ptile[umc * SM_T + e0 + 16 * uu + ps];
+            if (staged) pw[uu] = pt_at(pu_b, 16 * NPT * uu);
             else {
               pw[uu] = WEIGHTED ? d_w[uu] : 1.0;
               for (int q = 0; q < J0 + umc; ++q) pw[uu] *= d_du[uu];
@@ -585,12 +603,12 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const int e = (int)threadIdx.x + q * T_BLOCK;
         const double du = (su[q] - pu) * inv_du;
         double pw = WEIGHTED ? sw[q] * inv_w : 1.0;
-        if constexpr (NPT > JN) ptile[JN * SM_T + e] = pw;  // plain w for the y row set
+        if constexpr (NPT > JN) ptile[e * NPT + JN] = pw;  // plain w for the y row set
 #pragma unroll
         for (int k = 0; k < J0; ++k) pw *= du;
 #pragma unroll
         for (int jj = 0; jj < JN; ++jj) {
-          ptile[jj * SM_T + e] = pw;
+          ptile[e * NPT + jj] = pw;
           pw *= du;
         }
       }
@@ -635,8 +653,8 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     __syncthreads();
 #pragma unroll
     for (int fi = 0; fi < NS; ++fi) {
-      flush_tile(acc[fi][0], 0, fi, -1);
-      flush_tile(acc[fi][1], 1, fi, -1);
+      flush_tile(acc[fi][0], hswap, fi, -1);
+      flush_tile(acc[fi][1], 1 - hswap, fi, -1);
     }
     if (has_ut) flush_tile(accu, uh, 0, fu);  // wave-uniform
     accu = (v16i)(0);
