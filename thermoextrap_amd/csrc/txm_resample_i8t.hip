@@ -360,9 +360,6 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       auto pt_at = [&](uint32_t base, int idx) { return ((lds_cd)(lds + base))[idx]; };  // (cast first: the index is then a 32-bit LDS offset)
       auto factor = [&](int fi, int uu) {  // row set fi = power J0 + g + fi GS
         if (NQ == 8 && !WEIGHTED && J0 == 0 && fi == 0) return 1.0;
-#ifdef TXM_T_NO_FACTOR  // ablation build: no factor read (wrong sums)
-        if (staged) return 0.5 + fi;
-#endif
         if (staged) return pt_at(pt_b, fi * GS + 16 * NPT * uu);
         double pw = WEIGHTED ? d_w[uu] : 1.0;
         for (int q = 0; q < J0 + g + fi * GS; ++q) pw *= d_du[uu];
