@@ -294,6 +294,42 @@ def test_north_star_bootstrap_vs_oracle_fullsize(eng, orc, order, weighted):
     assert err.max() <= 1e-12, (err.max(), np.unravel_index(err.argmax(), err.shape))
 
 
+@pytest.mark.parametrize("N,C,order,nrep,weighted", [(10_000_000, 8, 4, 200, False), (10_000_000, 16, 6, 200, True),
+                                                      (10_000_000, 3, 5, 256, False)])
+def test_narrow_states_vs_oracle_fullsize(eng, orc, N, C, order, nrep, weighted):
+    """BASELINE config 2 (N = 1e7, 8 observables, order 4, nrep = 200) and two more narrow states on the default dispatch
+    -- the int8 kernel's quad-sharing variant (the waves of a column quad split the powers; 2, 4 and 1 quads, one and two
+    passes) -- against the oracle's extended-precision definition on the frequency rows of seeded replicates x columns,
+    1e-12 of every comoment's natural scale."""
+    seed = 5150 + C
+    x, u = synth(N, C, 31)
+    w = None
+    if weighted:
+        w = torch.empty(N, dtype=torch.float64, device="cuda").uniform_(0.25, 4.0, generator=torch.Generator("cuda").manual_seed(6))
+    assert eng.resample_path(N, C, nrep, order) == "int8"
+    rep = eng.resample_vals(x, u, order, sampler=eng.DeviceSampler(seed, nrep, N), w=w)
+    info = eng.resample_info()
+    assert info["path"] == "int8"
+    reps, cols = _seeded_reps_cols(nrep, C, seed, nr=6, nc=min(C, 3))
+    freq = _freq_rows(eng, seed, reps, N)
+    assert (freq.sum(axis=1) == N).all()
+    xh = x[:, cols].contiguous().cpu().numpy()
+    uh = u.cpu().numpy()
+    wh = None if w is None else w.cpu().numpy()
+    su, sx = float(uh.std()), xh.std(axis=0)
+    K = order + 1
+    sc = np.empty((len(cols), 2, K))
+    for b in range(K):
+        sc[:, 0, b] = su**b
+        sc[:, 1, b] = sx * su**b
+    got = rep[reps][:, cols].cpu().numpy()
+    truth = orc.truth_cov_multi(xh, uh, order, freq, w=wh)
+    err = np.abs(got - truth) / (np.abs(truth) + sc[None])
+    print(f"C={C} order {order}: max scaled error over {len(reps)} replicates x {len(cols)} columns: {err.max():.3e} "
+          f"({info['windows_fp64']} of {info['windows']} windows on the FP64 kernel)")
+    assert err.max() <= 1e-12, (err.max(), np.unravel_index(err.argmax(), err.shape))
+
+
 def test_second_matrix_vs_oracle_fullsize(eng, orc):
     """<dx/dq> of the volume callback at the c4 size (reference volume.py:121-134: dxdqv[sampler.indices].mean per
     replicate): the per-replicate means of a second N = 1e8 x 32 matrix from the same call (txm_resample_opts.y),
