@@ -150,3 +150,14 @@ def test_workspace_and_path_queries_are_pure_host_logic(lib, monkeypatch):
     assert lib.txm_set_resample_path(7) == -1 and b"not a path" in lib.txm_last_error()
     assert lib.txm_set_resample_path(-1) == 0
     assert lib.txm_resample_path(big, 32, 1000, 4) == 1
+
+
+def test_graft_entry_build_runs(lib):
+    """The driver's build check: __graft_entry__.build() compiles (a no-op when the library is current), loads and checks
+    the ABI version the binding expects -- it carried a literal 1 into the round that made the ABI 2."""
+    import importlib
+    import sys
+
+    sys.path.insert(0, str(ROOT))
+    ge = importlib.import_module("__graft_entry__")
+    ge.build()
