@@ -95,38 +95,41 @@ def input_GP_from_states(states, n_rep=100, log_scale=False, sampler=None):  # n
     boot = coll.resample(spec) if (coll._batch_eligible() is not None and is_spec) else None
     if boot is None or getattr(boot, "_batch", None) is None:
         parts = [input_GP_from_state(st, n_rep=n_rep, log_scale=log_scale, sampler=sampler) for st in coll]
-    else:
-        order = coll.order
-        vals, _ = boot._derivs_batched(order=order, norm=False, _device=True)      # (order+1, S, nrep, n_out)
-        n_ord, _, nrep, n_out = vals.shape
-        cov = engine.cov_over_rep(vals.permute(0, 2, 1, 3).reshape(n_ord, nrep, S * n_out))  # (S*n_out, n_ord, n_ord)
-        cov = cov.reshape(S, n_out, n_ord, n_ord).cpu().numpy()
-        # the states' own derivatives: one evaluation over the stacked un-resampled states
-        st0 = coll[0]
-        from . import moments as cm
+        x_all = np.concatenate([p_[0] for p_ in parts], axis=0)
+        y_all = np.concatenate([p_[1] for p_ in parts], axis=0)
+        n_out = parts[0][2].shape[0]
+        n_ord = parts[0][2].shape[1]
+        cov_all = np.zeros((n_out, S * n_ord, S * n_ord))
+        for s_, p_ in enumerate(parts):
+            cov_all[:, s_ * n_ord:(s_ + 1) * n_ord, s_ * n_ord:(s_ + 1) * n_ord] = p_[2]
+        return x_all, y_all, cov_all
+    order = coll.order
+    vals, _ = boot._derivs_batched(order=order, norm=False, _device=True)      # (order+1, S, nrep, n_out)
+    n_ord, _, nrep, n_out = vals.shape
+    cov_d = engine.cov_over_rep(vals.permute(0, 2, 1, 3).reshape(n_ord, nrep, S * n_out))  # (S*n_out, n_ord, n_ord)
+    # the states' own derivatives: one evaluation over the stacked un-resampled states -- launched before anything is
+    # copied back, so that the two small copies below are the step's only synchronisation points
+    st0 = coll[0]
+    from . import moments as cm
 
-        stack = torch.stack([st.data.dxduave.device_values for st in coll])
-        d0 = st0.data
-        one = d0.new_like(dxduave=cm.CentralMomentsData(stack, mom_ndim=2, dims=("rep", *d0.dxduave.dims)), rec_dim="rep")
-        dv, _ = st0.derivatives.derivs(data=one, order=order, norm=False, minus_log=st0.minus_log, _device=True)
-        dv = dv.cpu().numpy()                                                         # (order+1, S, n_out)
-        parts = []
-        for s_, st in enumerate(coll):
-            alphas = st.alpha0 * np.ones((order + 1, 1))
-            if log_scale:
-                alphas = np.log10(alphas)
-            x_data = np.concatenate([alphas, np.arange(order + 1)[:, None]], axis=1)
-            derivs, c = dv[:, s_, :], cov[s_]
-            if log_scale:
-                T = log_scale_matrix(st.alpha0, order)
-                derivs = T @ derivs
-                c = np.einsum("ab,kbc,dc->kad", T, c, T)
-            parts.append((x_data, derivs, c))
-    x_all = np.concatenate([p_[0] for p_ in parts], axis=0)
-    y_all = np.concatenate([p_[1] for p_ in parts], axis=0)
-    n_out = parts[0][2].shape[0]
-    n_ord = parts[0][2].shape[1]
-    cov_all = np.zeros((n_out, S * n_ord, S * n_ord))
-    for s_, p_ in enumerate(parts):
-        cov_all[:, s_ * n_ord:(s_ + 1) * n_ord, s_ * n_ord:(s_ + 1) * n_ord] = p_[2]
+    stack = torch.stack([st.data.dxduave.device_values for st in coll])
+    d0 = st0.data
+    one = d0.new_like(dxduave=cm.CentralMomentsData(stack, mom_ndim=2, dims=("rep", *d0.dxduave.dims)), rec_dim="rep")
+    dv_d, _ = st0.derivatives.derivs(data=one, order=order, norm=False, minus_log=st0.minus_log, _device=True)
+    cov = cov_d.reshape(S, n_out, n_ord, n_ord).cpu().numpy()
+    dv = dv_d.cpu().numpy()                                                       # (order+1, S, n_out)
+    # stacked outputs without a Python loop over the states (64 of them at config 5)
+    alpha0 = np.array([float(st.alpha0) for st in coll])
+    y_s = dv.transpose(1, 0, 2)                                                   # (S, order+1, n_out)
+    if log_scale:
+        T = np.stack([log_scale_matrix(a, order) for a in alpha0])                # (S, n_ord, n_ord)
+        y_s = np.einsum("sab,sbk->sak", T, y_s)
+        cov = np.einsum("sab,skbc,sdc->skad", T, cov, T)
+        alpha0 = np.log10(alpha0)
+    x_all = np.stack([np.repeat(alpha0, n_ord), np.tile(np.arange(n_ord, dtype=float), S)], axis=1)
+    y_all = np.ascontiguousarray(y_s.reshape(S * n_ord, n_out))
+    cov_all = np.zeros((n_out, S, n_ord, S, n_ord))
+    idx = np.arange(S)
+    cov_all[:, idx, :, idx, :] = cov                                              # block diagonal: (S, n_out, n_ord, n_ord)
+    cov_all = cov_all.reshape(n_out, S * n_ord, S * n_ord)
     return x_all, y_all, cov_all
