@@ -244,23 +244,6 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     double x[2];             // the two 16-sample units of a chunk
     double y[YS ? 2 : 1];    // ... of the second matrix
   };
-  // the wave's column quad of one chunk: i0 = the chunk's first sample (wave-uniform)
-  auto load_x = [&](int64_t i0, XIn &r) {
-#pragma unroll
-    for (int uu = 0; uu < 2; ++uu) {
-#ifdef TXM_T_NO_LOAD  // ablation build: no memory access
-      r.x[uu] = (double)(i0 + uu) * 1e-9 + px;
-      if constexpr (YS) r.y[uu] = (double)(i0 + uu) * 2e-9 + py;
-#else
-      const double *xr = a.x + (i0 + 16 * uu) * a.ldx_s + a.col0;
-      r.x[uu] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(xr) + xo);
-      if constexpr (YS) {
-        const double *yr = a.y + (i0 + 16 * uu) * a.ldy_s + a.col0;
-        r.y[uu] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(yr) + yo);
-      }
-#endif
-    }
-  };
 
 #ifdef TXM_I8T_TIMING
   long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -482,7 +465,34 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     uint32_t *cnt_cur = cnt_a, *cnt_nxt = cnt_b;
     constexpr int XD = NQ == 8 ? T_XD : T_XDN, UNR = XD > 4 ? XD : 4;
     XIn XR[XD];  // the wave's columns of a chunk, requested XD k-steps ahead: chunk c lives in slot c % XD
-    auto load_chunk = [&](int64_t wb, int c, XIn &R) { load_x(wb + c * 32, R); };
+    // The rows of the next chunk to request, as RUNNING wave-uniform pointers: chunks follow each other in memory inside a
+    // tile and from tile to tile (all but the slid last tile of the series), so a request is two scalar adds -- the row
+    // base "(tile base + 32 c) * pitch + column" from scratch was a chain of some fifteen dependent scalar instructions
+    // (64-bit multiplies) at the head of every k-step of an in-order wave.
+    const char *xq = nullptr, *yq = nullptr;
+    int64_t xq_step = 0, yq_step = 0;
+    const int64_t xq_u1 = 16 * a.ldx_s * 8, yq_u1 = YS ? 16 * a.ldy_s * 8 : 0;  // second 16-sample unit of a chunk
+    auto load_q = [&](XIn &r) {
+#ifdef TXM_T_NO_LOAD
+      r.x[0] = px + 1e-3; r.x[1] = px - 1e-3;
+      if constexpr (YS) { r.y[0] = py + 1e-3; r.y[1] = py - 1e-3; }
+#else
+      r.x[0] = *reinterpret_cast<const double *>(xq + xo);
+      r.x[1] = *reinterpret_cast<const double *>(xq + xq_u1 + xo);
+      if constexpr (YS) {
+        r.y[0] = *reinterpret_cast<const double *>(yq + yo);
+        r.y[1] = *reinterpret_cast<const double *>(yq + yq_u1 + yo);
+      }
+#endif
+    };
+    auto set_q = [&](int64_t i0) {  // the running pointers at sample i0 (a chunk's first)
+      xq = reinterpret_cast<const char *>(a.x + i0 * a.ldx_s + a.col0);
+      if constexpr (YS) yq = reinterpret_cast<const char *>(a.y + i0 * a.ldy_s + a.col0);
+    };
+    auto step_q = [&]() {
+      xq += xq_step;
+      if constexpr (YS) yq += yq_step;
+    };
     const double no_d[2] = {0.0, 0.0}, no_w[2] = {1.0, 1.0};
 
 #pragma unroll 1
@@ -516,7 +526,11 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       // previous tile), zero the count tile, chunk 0 of the first tile
       if (first_tile) {
         if (wave == 0) cnt_cur[lane] = rep_live ? a.counts[(size_t)my_rep * a.ntiles + t] : 0u;
-        load_chunk(wbase, 0, XR[0]);
+        set_q(wbase);
+        xq_step = 32 * a.ldx_s * 8;
+        if constexpr (YS) yq_step = 32 * a.ldy_s * 8;
+        load_q(XR[0]);
+        step_q();
       }
       // staging requests (in flight during the zeroing and the fill): entries 0 .. 991 = samples wbase + 32 ...,
       // entries 992 .. 1023 = the next tile's first chunk
@@ -591,7 +605,10 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
         kstep(YES, NO, 0, XR[0], -1, d_du, d_w);
 #pragma unroll
-        for (int c = 1; c <= XD; ++c) load_chunk(wbase, c, XR[c % XD]);
+        for (int c = 1; c <= XD; ++c) {
+          load_q(XR[c % XD]);
+          step_q();
+        }
         first_tile = false;
       }
       // park the staged tiles
@@ -617,10 +634,6 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       // ---- 32 k-steps, four per trip, NO barrier between them.  Step s contracts chunk s, slices chunk s + 1 from
       // the ring slot (s + 1) % XD (x requested XD steps ago) and requests chunk s + 1 + XD into that slot.
       // Chunk 32 is the next tile's chunk 0 (words nobody reads when there is no next tile).
-      auto target = [&](int c, int64_t &wb, int &cl2) {
-        if (c < T_STEPS) { wb = wbase; cl2 = c; }
-        else { wb = wnext; cl2 = has_next ? c - T_STEPS : T_STEPS - 1; }
-      };
 #pragma unroll 1
       for (int s = 0; s < T_STEPS; s += UNR) {
 #pragma unroll
@@ -628,10 +641,13 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
           const int sq = s + e;
           XIn &R = XR[(e + 1) % XD];
           const XIn cur_x = R;
-          int64_t wb;
-          int cl2;
-          target(sq + 1 + XD, wb, cl2);
-          load_chunk(wb, cl2, R);
+          load_q(R);  // chunk sq + 1 + XD
+          // the request after chunk 31 is the next tile's chunk 0 (not adjacent when that tile is the slid last one);
+          // no next tile: chunk 31 again, words nobody reads
+          if ((T_STEPS - 2 - XD - e) % UNR == 0 && s == T_STEPS - 2 - XD - e) {
+            if (has_next) set_q(wnext);
+            else { xq_step = 0; yq_step = 0; }
+          } else step_q();
           kstep(YES, YES, sq, cur_x, sq * 32, no_d, no_w);
           T_TICK(5);
         }
