@@ -39,6 +39,7 @@ extern "C" {
 
 #define TXM_ABI_VERSION 2 /* 2: txm_sampler_spec.rep0 */
 #define TXM_MAX_ORDER 8 /* K = order + 1 <= 9 */
+#define TXM_SAMPLER_STREAM_VERSION 3 /* 3: one BTRS binomial per tree node (round 4); txm_sampler_stream_version() */
 
 typedef enum txm_status {
   TXM_OK = 0,
@@ -53,6 +54,7 @@ typedef void *txm_stream;
 
 /* ---- runtime ------------------------------------------------------------ */
 int txm_abi_version(void);
+int txm_sampler_stream_version(void); /* the device sampler stream this build draws (tables are a function of it) */
 const char *txm_last_error(void);
 /* Select the device for the calling thread and check it is a gfx950 part. */
 int txm_init(int device);
@@ -105,17 +107,19 @@ int txm_indices_to_freq(const int64_t *indices, int64_t nrep, int64_t nsamp, int
 /* Device multinomial sampler ("scale mode").  The reference draws
  *   indices = rng.choice(ndat, (nrep, ndat), replace=True)   
  * and histograms them, which needs 16*nrep*ndat bytes of tables.  This
- * generates the SAME DISTRIBUTION of frequency tables (exact multinomial:
- * nsamp draws with replacement per replicate, integer arithmetic only) from a
+ * generates the SAME DISTRIBUTION of frequency tables (multinomial:
+ * nsamp draws with replacement per replicate) from a
  * counter-based Philox4x32-10 stream keyed by (seed, stage, replicate, tile)
  * without ever materialising indices; oracle/philox_oracle.c restates the
  * stream bit for bit.  The sampler object is a plain struct (no hidden state).
- * Stream version 2: the per-tile draw counts come from recursive binomial
- * splitting over a binary tree of tile ranges (one random bit per draw and
- * level, counted with popcounts; splits that are not 1/2 compare all draws
- * with the size ratio bit by bit), the per-sample counts inside a tile from
- * 10-bit fields.  Tables of a given seed differ from version 1 (round 1 of
- * this library); their distribution is the same exact multinomial.
+ * Stream version 3 (round 4; TXM_SAMPLER_STREAM_VERSION): the per-tile draw counts come from recursive binomial
+ * splitting over a count-balanced binary tree of tile ranges -- ONE binomial variate per node, Hormann's BTRS
+ * (transformed rejection with squeeze, O(1) uniforms) restated with IEEE double + - * / floor in a fixed order so
+ * that a CPU and the device produce the same integers, and the version-2 bitwise comparison for nodes with n p < 10;
+ * the per-sample counts inside a tile from 10-bit fields (unchanged).  Tables of a given seed differ from versions
+ * 1 and 2; the distribution is the same multinomial (BTRS: exact in real arithmetic; here to double rounding, 52-bit
+ * uniforms and a < 1e-10 truncation of Stirling's series in the acceptance bound -- the class of
+ * numpy.random.Generator.binomial; versions 1 and 2 were exact in integers at 4 x the cost).
  */
 typedef struct txm_sampler_spec {
   uint64_t seed;

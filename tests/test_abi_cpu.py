@@ -47,6 +47,12 @@ def test_abi_version(lib):
 
     hdr = int(re.search(r"#define TXM_ABI_VERSION (\d+)", (ROOT / "include" / "txmom.h").read_text()).group(1))
     assert lib.txm_abi_version() == hdr == _lib.ABI_VERSION == 2
+    # the sampler stream the library draws == the one the committed vectors pin (tests/golden/sampler_stream_v3.json)
+    import json
+
+    sv = int(re.search(r"#define TXM_SAMPLER_STREAM_VERSION (\d+)", (ROOT / "include" / "txmom.h").read_text()).group(1))
+    golden = json.load(open(ROOT / "tests" / "golden" / f"sampler_stream_v{sv}.json"))
+    assert lib.txm_sampler_stream_version() == sv == _lib.SAMPLER_STREAM_VERSION == golden["stream_version"] == 3
 
 
 def test_struct_layouts_match_the_header():

@@ -200,7 +200,7 @@ def test_device_sampler_bit_exact_vs_cpu_restatement(eng, orc, ndat):
 
 
 def test_device_sampler_large_geometry_bit_exact(eng, orc):
-    """ndat large enough for a 15-level tile tree with workgroup, wave and sub-wave splits and a partial last tile."""
+    """ndat large enough for a 15-level tile tree (heap levels + lane-private subtrees) and a partial last tile."""
     ndat, nrep, seed = 16384 * 1024 + 3 * 1024 + 17, 1, 99
     s = eng.DeviceSampler(seed, nrep, ndat)
     counts = s.counts.cpu().numpy().view(np.uint32)
@@ -210,11 +210,11 @@ def test_device_sampler_large_geometry_bit_exact(eng, orc):
 
 
 @pytest.mark.parametrize("ndat,nrep,nsamp", [
-    (100_000_000, 2, 0),            # the north-star geometry: 17 levels, 16 waves per replicate, every regime
-    ((1 << 27) + 1, 1, 0),          # one sample beyond a power of two: a 18-level tree whose right half holds 1 sample
-    (1 << 24, 1, 0),                # exactly dyadic: no spine node at all
-    (3_000_000, 3, 40_000_000),     # nsamp >> ndat (16-wave launch on a 12-level tree)
-    (50_000_000, 2, 1000),          # nsamp << ndat: almost every node is empty
+    (100_000_000, 2, 0),            # the north-star geometry: 17 levels, a 4096-node heap + 32-leaf lane subtrees
+    ((1 << 27) + 1, 1, 0),          # one sample beyond a power of two: 18 levels, the last tile holds ONE sample
+    (1 << 24, 1, 0),                # exactly dyadic: every split is 1/2
+    (3_000_000, 3, 40_000_000),     # nsamp >> ndat on a 12-level tree
+    (50_000_000, 2, 1000),          # nsamp << ndat: almost every node is empty or takes the bit rule
 ])
 def test_device_sampler_tile_counts_bit_exact_at_size(eng, orc, ndat, nrep, nsamp):
     """Tile counts of the binomial-splitting tree vs the CPU restatement, bit for bit, at full size (the oracle
@@ -228,11 +228,11 @@ def test_device_sampler_tile_counts_bit_exact_at_size(eng, orc, ndat, nrep, nsam
 
 
 def test_device_sampler_matches_committed_stream_vectors(eng):
-    """GPU tables vs tests/golden/sampler_stream_v2.json (no oracle in between)."""
+    """GPU tables vs tests/golden/sampler_stream_v3.json (no oracle in between)."""
     import json
     from pathlib import Path
 
-    g = json.load(open(Path(__file__).parent / "golden" / "sampler_stream_v2.json"))
+    g = json.load(open(Path(__file__).parent / "golden" / "sampler_stream_v3.json"))
     for c in g["cases"]:
         s = eng.DeviceSampler(c["seed"], c["nrep"], c["ndat"], nsamp=c["nsamp"], rep0=c.get("rep0", 0))
         assert s.counts.cpu().numpy().view(np.uint32).tolist() == c["counts"]

@@ -204,9 +204,9 @@ def test_device_sampler_statistics(orc):
 
 @pytest.mark.parametrize("ndat", [5 * 1024 + 300, 11 * 1024, 3 * 1024 + 1])
 def test_device_sampler_tile_counts_are_multinomial(orc, ndat):
-    """Stream v2 draws the tile counts by recursive binomial splitting (bitwise comparison with the size
-    ratio): per-tile mean n*p, variance n*p*(1-p) and pair covariance -n*p_i*p_j over many replicates, the
-    partial last tile and the non-dyadic splits included."""
+    """Stream v3 draws the tile counts by recursive binomial splitting over a count-balanced tree (BTRS per node,
+    the bitwise comparison with the size ratio for small nodes): per-tile mean n*p, variance n*p*(1-p) and pair
+    covariance -n*p_i*p_j over many replicates, the partial last tile and the non-dyadic splits included."""
     nrep = 3000
     c = orc.sampler_tile_counts(77, nrep, ndat).astype(float)
     nt = c.shape[1]
@@ -230,15 +230,64 @@ def test_device_sampler_tile_counts_are_multinomial(orc, ndat):
     assert chi2 < (nt - 1) + 6 * np.sqrt(2 * (nt - 1))
 
 
-def test_sampler_stream_v2_golden(orc):
-    """The stream definition is pinned by committed vectors (tests/golden/sampler_stream_v2.json, generated by
+@pytest.mark.parametrize("ndat,nsamp", [(2048, 0), (1024 + 100, 0), (1024 + 5, 0), (2048, 16 * 2048), (1024 + 300, 37)])
+def test_node_split_matches_the_binomial_pmf(orc, ndat, nsamp):
+    """One tree node, many replicates: the left child's count against the exact Binomial(n, A / (A + B)) pmf
+    (chi-square over bins of expected count >= 8).  The cases take BTRS at p = 1/2 (n = 2048 and n = 32768), BTRS at a
+    small ratio (the 100-sample partial tile: n p = 100), and the bit-comparison rule (n p = 5; n = 37)."""
+    from scipy import stats
+
+    nrep = 120000
+    c = orc.sampler_tile_counts(31337, nrep, ndat, nsamp)
+    n = nsamp or ndat
+    assert c.shape == (nrep, 2) and (c.sum(axis=1) == n).all()
+    left = c[:, 0].astype(np.int64)
+    p = 1024.0 / ndat
+    lo, hi = int(left.min()), int(left.max())
+    ks = np.arange(lo, hi + 1)
+    expect = nrep * stats.binom.pmf(ks, n, p)
+    obs = np.bincount(left - lo, minlength=len(ks)).astype(float)
+    # pool the tails so that every bin expects >= 8
+    keep = expect >= 8
+    i0, i1 = np.argmax(keep), len(keep) - np.argmax(keep[::-1])
+    e = np.concatenate([[nrep * stats.binom.cdf(ks[i0] - 1, n, p)], expect[i0:i1], [nrep * stats.binom.sf(ks[i1 - 1], n, p)]])
+    o = np.concatenate([[obs[:i0].sum()], obs[i0:i1], [obs[i1:].sum()]])
+    e, o = e[e > 0], o[e > 0]
+    chi2 = ((o - e) ** 2 / e).sum()
+    dof = len(e) - 1
+    assert chi2 < dof + 5 * np.sqrt(2 * dof), (chi2, dof)
+    assert abs(left.mean() - n * p) < 5 * np.sqrt(n * p * (1 - p) / nrep)
+
+
+def test_tile_counts_dispersion_at_every_tree_level(orc):
+    """ndat = 300 tiles + a partial one, nsamp = 4 ndat: at every level of the count-balanced tree the node totals have
+    the binomial mean and variance (BTRS runs with n from 1.2e6 down to ~8000)."""
+    ndat, nrep = 300 * 1024 + 77, 600
+    nsamp = 4 * ndat
+    c = orc.sampler_tile_counts(5150, nrep, ndat, nsamp).astype(float)
+    nt = c.shape[1]
+    size = np.full(nt, 1024.0)
+    size[-1] = ndat - 1024 * (nt - 1)
+    k = int(np.ceil(np.log2(nt)))
+    for l in range(1, k + 1):
+        b = (np.arange((1 << l) + 1) * nt) >> l
+        tot = np.add.reduceat(np.concatenate([c, np.zeros((nrep, 1))], axis=1), b[:-1], axis=1)[:, b[:-1] < b[1:]]
+        p = np.add.reduceat(np.append(size, 0.0), b[:-1])[b[:-1] < b[1:]] / ndat
+        z = (tot.mean(axis=0) - nsamp * p) / np.sqrt(nsamp * p * (1 - p) / nrep)
+        assert np.all(np.abs(z) < 5.5), (l, np.abs(z).max())
+        ratio = tot.var(axis=0, ddof=1) / (nsamp * p * (1 - p))
+        assert np.all(np.abs(ratio - 1) < 6.5 * np.sqrt(2 / nrep)), (l, ratio.min(), ratio.max())
+
+
+def test_sampler_stream_v3_golden(orc):
+    """The stream definition is pinned by committed vectors (tests/golden/sampler_stream_v3.json, generated by
     make_sampler_golden.py): the CPU restatement must reproduce them; the GPU is held to the restatement bit for bit
     in test_kernels_gpu.py."""
     import json
     from pathlib import Path
 
-    g = json.load(open(Path(__file__).parent / "golden" / "sampler_stream_v2.json"))
-    assert g["stream_version"] == 2
+    g = json.load(open(Path(__file__).parent / "golden" / "sampler_stream_v3.json"))
+    assert g["stream_version"] == 3
     for c in g["cases"]:
         r0 = c.get("rep0", 0)
         counts = orc.sampler_tile_counts(c["seed"], c["nrep"], c["ndat"], c["nsamp"], rep0=r0)

@@ -20,7 +20,9 @@ HEADERS = ["txm_common.h", "txm_pivot.h", "txm_sampler.h", "txm_resample_i8.h", 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed"]
 # per-file flags.  txm_resample_i8t.hip: 11 int32 accumulator tiles (176 registers) per wave at two waves per SIMD only
 # fit when the 256 registers are ONE file -- MFMA accumulators in VGPRs, no AGPR split (see the file's header)
-EXTRA_FLAGS = {"txm_resample_i8t.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# txm_sampler.hip: the binomial splits of sampler stream 3 are IEEE double arithmetic in a fixed order that the CPU
+# restatement (oracle/philox_oracle.c) repeats bit for bit -- no fused multiply-add contraction
+EXTRA_FLAGS = {"txm_resample_i8t.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "txm_sampler.hip": ["-ffp-contract=off"]}
 
 
 def _hipcc() -> str:

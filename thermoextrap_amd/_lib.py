@@ -51,6 +51,7 @@ class PolyTable(ct.Structure):
 # name -> (restype, argtypes); every symbol declared in include/txmom.h
 SIGNATURES = {
     "txm_abi_version": (c_int, []),
+    "txm_sampler_stream_version": (c_int, []),
     "txm_last_error": (ct.c_char_p, []),
     "txm_init": (c_int, [c_int]),
     "txm_device_count": (c_int, [ct.POINTER(c_int)]),
@@ -100,6 +101,7 @@ SIGNATURES = {
 }
 
 ABI_VERSION = 2  # include/txmom.h TXM_ABI_VERSION
+SAMPLER_STREAM_VERSION = 3  # include/txmom.h TXM_SAMPLER_STREAM_VERSION (tests/golden/sampler_stream_v3.json)
 _lib = None
 _gpu_ready = False
 
@@ -133,6 +135,8 @@ def load(path: Path | None = None):
         fn.argtypes = args
     if lib.txm_abi_version() != ABI_VERSION:
         raise TxmError(f"ABI version mismatch: library {lib.txm_abi_version()} vs binding {ABI_VERSION}")
+    if lib.txm_sampler_stream_version() != SAMPLER_STREAM_VERSION:
+        raise TxmError(f"sampler stream mismatch: library {lib.txm_sampler_stream_version()} vs binding {SAMPLER_STREAM_VERSION}")
     _lib = lib
     return lib
 

@@ -29,6 +29,7 @@ int num_cus() { return g_num_cus; }
 using namespace txm;
 
 extern "C" int txm_abi_version(void) { return TXM_ABI_VERSION; }
+extern "C" int txm_sampler_stream_version(void) { return TXM_SAMPLER_STREAM_VERSION; }
 
 extern "C" const char *txm_last_error(void) { return g_err; }
 

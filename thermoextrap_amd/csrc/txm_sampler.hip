@@ -4,8 +4,8 @@
 // (cmomy factory_sampler as reached from data.py:1782-1789) without ever
 // materialising the (nrep, ndat) index/freq tables.
 //
-// Tile counts: recursive binomial splitting over the tree of tile ranges, one
-//          workgroup per replicate (sampler_tree_kernel).
+// Tile counts: recursive binomial splitting over a count-balanced tree of tile ranges, one binomial variate
+//          (BTRS) per node, one workgroup per replicate (sampler_tree_kernel; stream version 3).
 // Per-sample counts inside a tile ("stage 3"): txm_sampler.h, executed inside the
 //          bootstrap kernels (txm_resample*.hip), tile by tile, straight into LDS.
 #include "txm_sampler.h"
@@ -31,30 +31,26 @@ __global__ __launch_bounds__(256) void indices_to_freq_kernel(const int64_t *__r
   }
 }
 
-// ---- tile counts: recursive binomial splitting (stream v2, oracle/philox_oracle.c) -------------------
-// One workgroup per replicate walks the binary tree of tile ranges.  A node's n draws are split between its
-// children by counting 1 bits in n bits of the node's Philox bit stream: one v_bcnt per 32 draws and level,
-// no histogram, no atomics, no rejection.  Levels with few nodes are split by the whole workgroup (block
-// reduction per node), levels with >= 4 nodes per wave by one wave per node, and the subtrees below level
-// ka = k - ST_DEPTH by one wave each in wave-private LDS with g <= 64 lanes per node, g chosen so that every
-// lane has a few Philox calls per node.
-constexpr int ST_DEPTH = 7;        // levels of a wave-private subtree (2^7 leaves)
-constexpr int ST_BLOCK_NODES = 4;  // nodes per wave below which a level is split by the whole workgroup
+// ---- tile counts: recursive binomial splitting, stream v3 (oracle/philox_oracle.c is the normative statement) --------
+// Version 2 counted one random bit per draw and tree level (1.85e12 bits at N = 1e8, nrep = 1000: 20.9 ms, the
+// vector-issue bound of Philox).  Version 3 draws ONE binomial variate per tree node with O(1) uniforms -- Hormann's
+// transformed rejection with squeeze (BTRS) -- over a count-balanced tree of tile ranges, and keeps the bitwise rule
+// for the nodes with n p < 10.  Everything floating point below is IEEE double + - * / floor in a fixed order (this
+// file is compiled with -ffp-contract=off; sqrt and log are the fixed sequences det_sqrt / det_log), so that the
+// tables equal the CPU restatement bit for bit.
+#pragma clang fp contract(off)
 
 __device__ __forceinline__ uint32_t popc4(const Philox4 &o) {
   return (uint32_t)(__popc(o.w[0]) + __popc(o.w[1]) + __popc(o.w[2]) + __popc(o.w[3]));
 }
 
-// this lane's share of the 1 bits among the first `nbits` bits of stream (h, tagj): calls sub, sub + g, ...
-// The call index is the SECOND counter word: rounds 1-3 then need 2 instead of 6 multiplies per call (the rest is
-// the same for all calls of a node and hoisted out of the loop).
-// (g a power of two); the partial last call belongs to the lane whose turn it is.
-__device__ __forceinline__ uint32_t stream_ones_partial(uint32_t k0, uint32_t k1, uint32_t h, uint32_t r,
-                                                        uint32_t tagj, uint32_t nbits, uint32_t sub, uint32_t g) {
+// number of 1 bits among the first `nbits` bits of bit stream (h, tagj) of replicate r (one lane walks the calls)
+__device__ __forceinline__ uint32_t stream_ones(uint32_t k0, uint32_t k1, uint32_t h, uint32_t r, uint32_t tagj,
+                                                uint32_t nbits) {
   const uint32_t full = nbits >> 7, tail = nbits & 127u;
   uint32_t acc = 0;
-  for (uint32_t c = sub; c < full; c += g) acc += popc4(philox4x32_10<true>(h, c, r, tagj, k0, k1));
-  if (tail != 0u && (full & (g - 1u)) == sub) {
+  for (uint32_t c = 0; c < full; ++c) acc += popc4(philox4x32_10<true>(h, c, r, tagj, k0, k1));
+  if (tail != 0u) {
     const Philox4 o = philox4x32_10<true>(h, full, r, tagj, k0, k1);
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -66,19 +62,9 @@ __device__ __forceinline__ uint32_t stream_ones_partial(uint32_t k0, uint32_t k1
   return acc;
 }
 
-__device__ __forceinline__ int64_t tree_node_size(int64_t ndat, int k, int l, int64_t i) {
-  const int64_t span = (int64_t)SM_T << (k - l);
-  const int64_t lo = i * span;
-  if (lo >= ndat) return 0;
-  return (ndat - lo < span) ? ndat - lo : span;
-}
-
-// left ~ Binomial(n, A / (A + B)): all n uniforms are compared with p bit by bit at once.  SUM(v) adds v over the
-// lanes that share the node (and returns the total on each of them).
-template <class Sum>
-__device__ __forceinline__ uint32_t split_left(uint32_t k0, uint32_t k1, uint32_t h, uint32_t r, uint32_t n,
-                                               int64_t A, int64_t B, uint32_t sub, uint32_t g, Sum sum) {
-  if (B == 0) return n;
+// small nodes: left ~ Binomial(n, A / (A + B)), all n uniforms compared with p bit by bit at once (integers only)
+__device__ __forceinline__ uint32_t split_left_bits(uint32_t k0, uint32_t k1, uint32_t h, uint32_t r, uint32_t n,
+                                                    int64_t A, int64_t B) {
   uint64_t rem = (uint64_t)A;
   const uint64_t den = (uint64_t)A + (uint64_t)B;
   uint32_t tie = n, left = 0;
@@ -86,7 +72,7 @@ __device__ __forceinline__ uint32_t split_left(uint32_t k0, uint32_t k1, uint32_
     rem <<= 1;
     const bool pj = rem >= den;
     if (pj) rem -= den;
-    const uint32_t K = sum(stream_ones_partial(k0, k1, h, r, 1u + 256u * j, tie, sub, g));
+    const uint32_t K = stream_ones(k0, k1, h, r, 1u + 256u * j, tie);
     if (pj) {
       left += tie - K;
       tie = K;
@@ -98,113 +84,180 @@ __device__ __forceinline__ uint32_t split_left(uint32_t k0, uint32_t k1, uint32_
   return left;
 }
 
-// grid nrep, block 64 * nwaves (a power of two), dynamic LDS: heap[2^(ka+1)] + nwaves * sub[2^(depth+1)] + red[nwaves]
-__global__ __launch_bounds__(1024) void sampler_tree_kernel(uint32_t k0, uint32_t k1key, uint32_t nsamp,
-                                                            SamplerGeom g, uint32_t rep0,
-                                                            uint32_t *__restrict__ counts) {
+__device__ __forceinline__ double bits_f64(uint64_t b) { return __longlong_as_double((long long)b); }
+
+// sqrt(x), x > 0 normal: x = m 4^e, m in [1, 4); linear seed, four Newton steps (same sequence as the oracle's)
+__device__ __forceinline__ double det_sqrt(double x) {
+  const int E = (int)(((uint64_t)__double_as_longlong(x) >> 52) & 0x7ffu) - 1023;
+  const int e = E >> 1;
+  const double m = x * bits_f64((uint64_t)(1023 - 2 * e) << 52);
+  double s = m / 3.0 + 0.72;
+  s = 0.5 * (s + m / s);
+  s = 0.5 * (s + m / s);
+  s = 0.5 * (s + m / s);
+  s = 0.5 * (s + m / s);
+  return s * bits_f64((uint64_t)(1023 + e) << 52);
+}
+
+// log(x), x > 0 normal: x = 2^k (1 + f), s = f / (2 + f), log(1 + f) = 2 s + s R(s^2)
+__device__ __forceinline__ double det_log(double x) {
+  constexpr double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+  constexpr double L1 = 6.666666666666735130e-01, L2 = 3.999999999940941908e-01, L3 = 2.857142874366239149e-01,
+                   L4 = 2.222219843214978396e-01, L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01,
+                   L7 = 1.479819860511658591e-01;
+  uint64_t bits = (uint64_t)__double_as_longlong(x);
+  int k = (int)((bits >> 52) & 0x7ffu) - 1023;
+  bits = (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+  double m = bits_f64(bits);
+  if (m > 1.4142135623730951) {
+    m = m * 0.5;
+    k = k + 1;
+  }
+  const double f = m - 1.0;
+  const double s = f / (2.0 + f);
+  const double z = s * s;
+  const double w = z * z;
+  const double t1 = w * (L2 + w * (L4 + w * L6));
+  const double t2 = z * (L1 + w * (L3 + w * (L5 + w * L7)));
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  const double dk = (double)k;
+  return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+}
+
+__device__ __forceinline__ double stirling_tail(double k) {
+  if (k <= 9.0) {
+    // (a select chain instead of a table: per-lane indexing of a constant array is a memory load)
+    const int i = (int)k;
+    double t = 0.08106146679532726;
+    t = i == 1 ? 0.04134069595540929 : t;
+    t = i == 2 ? 0.02767792568499834 : t;
+    t = i == 3 ? 0.02079067210376509 : t;
+    t = i == 4 ? 0.01664469118982119 : t;
+    t = i == 5 ? 0.01387612882307075 : t;
+    t = i == 6 ? 0.01189670994589177 : t;
+    t = i == 7 ? 0.01041126526197209 : t;
+    t = i == 8 ? 0.009255462182712733 : t;
+    t = i == 9 ? 0.008330563433362871 : t;
+    return t;
+  }
+  const double kp1 = k + 1.0;
+  const double kp1sq = kp1 * kp1;
+  return (1.0 / 12.0 - (1.0 / 360.0 - (1.0 / 1260.0) / kp1sq) / kp1sq) / kp1;
+}
+
+__device__ __forceinline__ double u52(uint32_t hi, uint32_t lo) {
+  const uint64_t j = ((uint64_t)hi << 20) | (uint64_t)(lo >> 12);
+  return ((double)j + 0.5) * 0x1p-52;
+}
+
+// x ~ Binomial(n, p), p <= 1/2, n p >= 10: Hormann (1993), algorithm BTRS.  Attempt `att` of node h, replicate r takes
+// its two uniforms from Philox(ctr = (h, att, r, 7)).  ~86 % of the attempts end in the first test.
+__device__ __forceinline__ uint32_t btrs(uint32_t k0, uint32_t k1, uint32_t h, uint32_t r, uint32_t n, double p) {
+  const double dn = (double)n;
+  const double q = 1.0 - p;
+  const double spq = det_sqrt(dn * p * q);
+  const double b = 1.15 + 2.53 * spq;
+  const double a = -0.0873 + 0.0248 * b + 0.01 * p;
+  const double c = dn * p + 0.5;
+  const double vr = 0.92 - 4.2 / b;
+  for (uint32_t att = 0;; ++att) {
+    const Philox4 o = philox4x32_10<true>(h, att, r, 7u, k0, k1);
+    const double u = u52(o.w[0], o.w[1]) - 0.5;
+    double v = u52(o.w[2], o.w[3]);
+    const double us = 0.5 - (u < 0.0 ? -u : u);
+    const double kf = __builtin_floor((2.0 * a / us + b) * u + c);
+    if (us >= 0.07 && v <= vr) return (uint32_t)kf;
+    if (kf < 0.0 || kf > dn) continue;
+    const double alpha = (2.83 + 5.1 / b) * spq;
+    const double rr = p / q;
+    const double m = __builtin_floor((dn + 1.0) * p);
+    v = det_log(v * alpha / (a / (us * us) + b));
+    const double bound = (m + 0.5) * det_log((m + 1.0) / (rr * (dn - m + 1.0))) +
+                         (dn + 1.0) * det_log((dn - m + 1.0) / (dn - kf + 1.0)) +
+                         (kf + 0.5) * det_log(rr * (dn - kf + 1.0) / (kf + 1.0)) +
+                         ((stirling_tail(m) + stirling_tail(dn - m)) - (stirling_tail(kf) + stirling_tail(dn - kf)));
+    if (v <= bound) return (uint32_t)kf;
+  }
+}
+
+// tile boundary floor(i nt / 2^l) of the count-balanced tree; samples of [0, ndat) under node (l, i)
+__device__ __forceinline__ int64_t tree_node_size(int64_t ndat, int64_t nt, int l, int64_t i) {
+  const int64_t lo = ((i * nt) >> l) * SM_T, hi = (((i + 1) * nt) >> l) * SM_T;
+  return (hi < ndat ? hi : ndat) - (lo < ndat ? lo : ndat);
+}
+
+// draws of node (l, i) (heap index h, n draws) that go to its left child
+__device__ __forceinline__ uint32_t split_left(uint32_t k0, uint32_t k1, const SamplerGeom &g, int l, int64_t i,
+                                               uint32_t r, uint32_t n) {
+  if (n == 0u) return 0u;
+  const int64_t A = tree_node_size(g.ndat, g.ntiles, l + 1, 2 * i), B = tree_node_size(g.ndat, g.ntiles, l + 1, 2 * i + 1);
+  if (A == 0) return 0u;
+  if (B == 0) return n;
+  const uint32_t h = (1u << l) + (uint32_t)i;
+  const int64_t S = A <= B ? A : B;
+  const double p = (double)S / (double)(A + B);
+  if ((double)n * p >= 10.0) {
+    const uint32_t x = btrs(k0, k1, h, r, n, p);
+    return A <= B ? x : n - x;
+  }
+  return split_left_bits(k0, k1, h, r, n, A, B);
+}
+
+// One workgroup per replicate.  Levels 0 .. L0 - 1 (L0 = k - D, D = the depth of the lane-private subtrees) are split
+// breadth first, one thread per node, in a heap in LDS.  Below level L0 every LANE owns a subtree: it walks its 2^D
+// leaves left to right and splits the nodes it enters on the way down (depth-first; the pending right siblings of the
+// path sit in a D-entry stack in LDS).  All lanes run the same loop -- the tree has one shape -- so the only divergence
+// is inside a split (empty nodes, the rejection loop).
+// grid nrep, block TR_THREADS, dynamic LDS: heap[2^(L0+1)] + stack[(D + 1) * TR_THREADS]
+constexpr int TR_THREADS = 256;
+constexpr int TR_DEPTH = 5;    // lane-private subtree depth (when the tree is deeper than that)
+constexpr int TR_MAX_L0 = 13;  // the heap of the top levels: 2^(L0+1) words of LDS
+
+__global__ __launch_bounds__(TR_THREADS) void sampler_tree_kernel(uint32_t k0, uint32_t k1key, uint32_t nsamp,
+                                                                  SamplerGeom g, uint32_t rep0, int D,
+                                                                  uint32_t *__restrict__ counts) {
   extern __shared__ uint32_t tree_lds[];
-  const int k = g.k;
-  const int depth = k < ST_DEPTH ? k : ST_DEPTH;
-  const int ka = k - depth;
-  const int nwaves = (int)(blockDim.x >> 6);
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-  uint32_t *heap = tree_lds;                                   // levels 0 .. ka, heap indexed
-  uint32_t *sub_all = heap + ((size_t)2 << ka);                // per wave: subtree levels 0 .. depth
-  uint32_t *red = sub_all + (size_t)nwaves * ((size_t)2 << depth);
-  const uint32_t r = rep0 + blockIdx.x;  // replicate of the STREAM; row blockIdx.x of this call's table
+  const int k = g.k, L0 = k - D;
+  uint32_t *heap = tree_lds;                       // levels 0 .. L0, heap indexed
+  uint32_t *stk = heap + ((size_t)2 << L0);        // [D + 1][TR_THREADS]
+  const uint32_t r = rep0 + blockIdx.x;            // replicate of the STREAM; row blockIdx.x of this call's table
+  const int tid = (int)threadIdx.x;
 
-  for (uint32_t q = threadIdx.x; q < ((uint32_t)2 << ka); q += blockDim.x) heap[q] = 0u;
+  if (tid == 0) heap[1] = nsamp;
   __syncthreads();
-  if (threadIdx.x == 0) heap[1] = nsamp;
-  __syncthreads();
-
-  auto block_sum = [&](uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
-    __syncthreads();
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    uint32_t s = 0;
-    for (int w = 0; w < nwaves; ++w) s += red[w];
-    return s;
-  };
-  auto wave_sum = [&](uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
-    return v;
-  };
-
-  // ---- levels 0 .. ka-1: counts in the workgroup's heap ----
-  for (int l = 0; l < ka; ++l) {
+  for (int l = 0; l < L0; ++l) {
     const uint32_t nn = 1u << l;
-    const int64_t span = (int64_t)1 << (k - l);                      // tiles per node
-    const uint32_t nreal = (uint32_t)((g.ntiles + span - 1) / span);  // nodes that cover samples
-    if (nreal < (uint32_t)(ST_BLOCK_NODES * nwaves)) {
-      for (uint32_t i = 0; i < nreal; ++i) {
-        const uint32_t n = heap[nn + i];
-        const uint32_t left = split_left(k0, k1key, nn + i, r, n, tree_node_size(g.ndat, k, l + 1, 2 * (int64_t)i),
-                                         tree_node_size(g.ndat, k, l + 1, 2 * (int64_t)i + 1), threadIdx.x,
-                                         blockDim.x, block_sum);
-        if (threadIdx.x == 0) {
-          heap[2 * nn + 2 * i] = left;
-          heap[2 * nn + 2 * i + 1] = n - left;
-        }
-      }
-    } else {
-      for (uint32_t i = (uint32_t)wave; i < nreal; i += (uint32_t)nwaves) {
-        const uint32_t n = heap[nn + i];
-        const uint32_t left = split_left(k0, k1key, nn + i, r, n, tree_node_size(g.ndat, k, l + 1, 2 * (int64_t)i),
-                                         tree_node_size(g.ndat, k, l + 1, 2 * (int64_t)i + 1), (uint32_t)lane, 64u,
-                                         wave_sum);
-        if (lane == 0) {
-          heap[2 * nn + 2 * i] = left;
-          heap[2 * nn + 2 * i + 1] = n - left;
-        }
-      }
+    for (uint32_t i = (uint32_t)tid; i < nn; i += TR_THREADS) {
+      const uint32_t n = heap[nn + i];
+      const uint32_t left = split_left(k0, k1key, g, l, (int64_t)i, r, n);
+      heap[2 * nn + 2 * i] = left;
+      heap[2 * nn + 2 * i + 1] = n - left;
     }
     __syncthreads();
   }
 
-  // ---- subtrees rooted at level ka: one wave each, counts in wave-private LDS ----
-  uint32_t *sh = sub_all + (size_t)wave * ((size_t)2 << depth);
-  const uint32_t nroots = (uint32_t)((g.ntiles + ((int64_t)1 << depth) - 1) >> depth);
-  for (uint32_t s = (uint32_t)wave; s < nroots; s += (uint32_t)nwaves) {
-    if (lane == 0) sh[1] = heap[((uint32_t)1 << ka) + s];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    for (int d = 0; d < depth; ++d) {
-      const int l = ka + d;
-      const uint32_t nn = 1u << d;
-      // lanes per node: the largest power of two <= (expected Philox calls per node) / 3, within [1, 64]
-      const uint32_t ecalls = (uint32_t)(((uint64_t)nsamp >> l) >> 7);
-      uint32_t gsz = 64u;
-      while (gsz > 1u && gsz * 3u > ecalls) gsz >>= 1;
-      const uint32_t per = 64u / gsz;  // nodes per pass of the wave
-      const uint32_t sub = (uint32_t)lane & (gsz - 1u);
-      for (uint32_t base = 0; base < nn; base += per) {
-        const uint32_t jn = base + (uint32_t)lane / gsz;
-        const bool act = jn < nn;
-        const uint32_t n = act ? sh[nn + jn] : 0u;
-        const int64_t gi = ((int64_t)s << d) + jn;  // node index within level l
-        const int64_t A = tree_node_size(g.ndat, k, l + 1, 2 * gi), B = tree_node_size(g.ndat, k, l + 1, 2 * gi + 1);
-        const uint32_t left = split_left(k0, k1key, (1u << l) + (uint32_t)gi, r, n, A, B, sub, gsz, [&](uint32_t v) {
-          for (uint32_t o = gsz >> 1; o > 0u; o >>= 1) v += (uint32_t)__shfl_xor((int)v, (int)o);
-          return v;
-        });
-        if (act && sub == 0u) {
-          sh[2 * nn + 2 * jn] = left;
-          sh[2 * nn + 2 * jn + 1] = n - left;
-        }
+  const uint32_t nroots = 1u << L0, nleaf = 1u << D;
+  for (uint32_t sub0 = 0; sub0 < nroots; sub0 += TR_THREADS) {
+    const uint32_t sub = sub0 + (uint32_t)tid;
+    const bool act = sub < nroots;
+    uint32_t cur = act ? heap[nroots + sub] : 0u;
+#pragma unroll 1
+    for (uint32_t c = 0; c < nleaf; ++c) {
+      // the node entered at leaf c: depth dmin = D - ctz(c) (the root for c = 0), its count = the pending right sibling
+      const int dmin = c == 0u ? 0 : D - __builtin_ctz(c);
+      if (c != 0u) cur = stk[dmin * TR_THREADS + tid];
+#pragma unroll 1
+      for (int d = dmin; d < D; ++d) {
+        const int64_t gi = ((int64_t)sub << d) + (int64_t)(c >> (D - d));
+        const uint32_t left = split_left(k0, k1key, g, L0 + d, gi, r, cur);
+        stk[(d + 1) * TR_THREADS + tid] = cur - left;
+        cur = left;
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      __builtin_amdgcn_wave_barrier();
+      const int64_t leaf = ((int64_t)sub << D) + c;
+      const int64_t lo = (leaf * g.ntiles) >> k, hi = ((leaf + 1) * g.ntiles) >> k;
+      if (act && hi > lo) counts[(size_t)blockIdx.x * g.ntiles + lo] = cur;
     }
-    for (uint32_t j = (uint32_t)lane; j < (1u << depth); j += 64u) {
-      const int64_t t = ((int64_t)s << depth) + j;
-      if (t < g.ntiles) counts[(size_t)blockIdx.x * g.ntiles + t] = sh[(1u << depth) + j];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -310,13 +363,13 @@ extern "C" int txm_sampler_tile_counts(const txm_sampler_spec *sp, uint32_t *cou
   (void)ws_bytes;
   hipStream_t st = (hipStream_t)stream;
   const uint32_t k0 = (uint32_t)sp->seed, k1 = (uint32_t)(sp->seed >> 32);
-  // 16 waves per replicate when a replicate has enough draws to feed them, 4 otherwise
-  const int nwaves = nsamp >= ((int64_t)1 << 22) ? 16 : 4;
-  const int depth = g.k < ST_DEPTH ? g.k : ST_DEPTH, ka = g.k - depth;
-  const size_t lds = (((size_t)2 << ka) + (size_t)nwaves * ((size_t)2 << depth) + (size_t)nwaves) * sizeof(uint32_t);
+  // lane-private subtrees of depth TR_DEPTH below a heap of at most 2^TR_MAX_L0 nodes
+  int D = g.k < TR_DEPTH ? g.k : TR_DEPTH;
+  if (g.k - D > TR_MAX_L0) D = g.k - TR_MAX_L0;
+  const size_t lds = (((size_t)2 << (g.k - D)) + (size_t)(D + 1) * TR_THREADS) * sizeof(uint32_t);
   TXM_SET_MAX_LDS(sampler_tree_kernel, 160 * 1024);
-  hipLaunchKernelGGL(sampler_tree_kernel, dim3((unsigned)sp->nrep), dim3(64 * nwaves), lds, st, k0, k1,
-                     (uint32_t)nsamp, g, (uint32_t)sp->rep0, counts);
+  hipLaunchKernelGGL(sampler_tree_kernel, dim3((unsigned)sp->nrep), dim3(TR_THREADS), lds, st, k0, k1, (uint32_t)nsamp, g,
+                     (uint32_t)sp->rep0, D, counts);
   TXM_LAUNCH_CHECK();
   return TXM_OK;
 }
