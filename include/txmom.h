@@ -220,6 +220,12 @@ int txm_resample_vals_info(const void *ws, int64_t N, int64_t C, int64_t nrep, i
                            int64_t *info_host, txm_stream stream);
 size_t txm_resample_prep_bytes(int64_t N, int64_t C, int64_t nrep, int order);
 size_t txm_resample_vals_ws_bytes(int64_t N, int64_t C, int64_t nrep, int order);
+/* extra workspace, BEHIND txm_resample_vals_ws_bytes(), that a call with opts.y needs (ws_bytes >= the sum); a call
+ * without opts.y needs none of it (~2 GB at N = 1e8, C = 32, nrep = 1000) */
+size_t txm_resample_y_ws_bytes(int64_t N, int64_t C, int64_t nrep);
+/* 1 when the int8 kernel can take the shape at all (N >= one sampler tile, order <= 7, ...): what TXM_PATH_INT8 needs;
+ * txm_resample_path() is the rule TXM_PATH_AUTO applies on top of it */
+int txm_resample_i8_supported(int64_t N, int64_t C, int64_t nrep, int order);
 int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, const double *u,
                       const double *w, int64_t N, int64_t C, int order, int64_t nrep,
                       const int64_t *freq, const txm_sampler_spec *spec_host,

@@ -307,6 +307,24 @@ def test_extrapmodel(fixture, xtrap):
         fixture.xr_test(xem0.predict(fixture.betas, order=3), xem1.predict(fixture.betas, order=3))
 
 
+def test_derivs_from_args_equals_derivs_from_data(fixture, xtrap):
+    """``Derivatives.derivs(args=data.derivs_args)`` without the data object (reference models.py:357-372) evaluates the
+    same polynomial tables on the host from the caller's arrays: equal to the device evaluation of ``derivs(data=...)``,
+    labelled the same way, for raw and central data classes, with and without -log, on resampled data too."""
+    order = 4
+    sampler = xtrap.moments.factory_sampler(ndat=len(fixture.u), nrep=6, rng=np.random.default_rng(3))
+    for data in [fixture.rdata, fixture.cdata, fixture.xdata_val, fixture.xrdata_val, fixture.rdata.resample(sampler=sampler),
+                 fixture.xdata_val.resample(sampler=sampler)]:
+        xem = xtrap.beta.factory_extrapmodel(beta=fixture.beta0, data=data)
+        for minus_log in (False, True):
+            a = xem.derivatives.derivs(data=data, order=order, minus_log=minus_log)
+            b = xem.derivatives.derivs(args=data.derivs_args, order=order, minus_log=minus_log)
+            assert set(a.dims) == set(b.dims)
+            fixture.xr_test(a, b.transpose(*a.dims), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(xtrap.beta.factory_extrapmodel(beta=fixture.beta0, data=fixture.rdata).derivatives.derivs(
+        args=fixture.rdata.derivs_args, order=5).values, fixture.legacy["derivs"], rtol=1e-8)
+
+
 def test_extrapmodel_resample(fixture, xtrap):
     ndat, nrep = len(fixture.u), 10
     sampler = xtrap.moments.factory_sampler(ndat=ndat, nrep=nrep, rng=np.random.default_rng(5))

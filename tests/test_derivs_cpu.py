@@ -280,3 +280,58 @@ def test_piecewise_selection_matches_reference_rule():
     inv = InterpModel([Stub(-1.0), Stub(1.0)])._hermite_inverse(1)
     want = np.array([[0.5, 0.25, 0.5, -0.25], [-0.75, -0.25, 0.75, -0.25], [0, -0.25, 0, 0.25], [0.25, 0.25, -0.25, 0.25]])
     np.testing.assert_allclose(inv, want, atol=1e-15)
+
+
+# ---------------------------------------------------------------------------
+# Derivatives.derivs(args=...) without a data object (reference models.py:357-383: funcs[i](*args))
+# ---------------------------------------------------------------------------
+class _Sel:
+    """obj[n] / obj[n, d] -> moment arrays, like the reference's DataSelector (data.py:91-162)."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __getitem__(self, idx):
+        return self.fn(*(idx if isinstance(idx, tuple) else (idx,)))
+
+
+@pytest.mark.parametrize("central", [False, True])
+@pytest.mark.parametrize("minus_log", [False, True])
+def test_derivs_from_args_matches_oracle_and_legacy(legacy, central, minus_log):
+    """The API surface the reference serves with ``derivs(args=...)``: the caller's own moment arrays, no data object.
+    Evaluated on the host from the same polynomial tables; == the jet oracle == the reference's legacy numbers."""
+    x, u, order = legacy["x"], legacy["u"], int(legacy["order"])
+    val = moment_lookup(x, u, order)
+    if central:
+        args = (val(("x1", None)), _Sel(lambda n: val(("du", n))), _Sel(lambda n: val(("dxdu", n, None))))
+    else:
+        args = (_Sel(lambda n: val(("u", n))), _Sel(lambda n: val(("xu", n, None))))
+    d = beta.factory_derivatives("x_ave", central=central)
+    got = d.derivs(args=args, order=order, minus_log=minus_log)
+    assert got.shape == (order + 1, x.shape[1])
+    np.testing.assert_allclose(got, dorc.derivs_x_ave(x, u, order, minus_log=minus_log), rtol=2e-8, atol=1e-10)
+    np.testing.assert_allclose(got, legacy["derivs_minus_log" if minus_log else "derivs"], rtol=2e-8)
+    # list output, Taylor coefficients, argument checks
+    lst = d.derivs(args=args, order=2, order_dim=None)
+    assert len(lst) == 3 and np.allclose(lst[2], got[2]) if not minus_log else True
+    np.testing.assert_allclose(d.coefs(args=args, order=order, minus_log=minus_log)[3], got[3] / 6.0, rtol=1e-14)
+    with pytest.raises(ValueError):
+        d.derivs(args=args)                      # order is required without a data object
+    with pytest.raises(ValueError):
+        d.derivs(args=args[:1], order=2)         # wrong number of arguments
+    with pytest.raises(ValueError):
+        d.derivs()
+
+
+def test_derivs_from_args_xalpha_and_absolute_bound(legacy):
+    """x(beta)-dependent observable through obj[n, d] selectors; and eval_host(absolute=True) bounds |value|."""
+    xd, u, order = legacy["x_dep"], legacy["u"], int(legacy["order"])
+    val = moment_lookup(None, u, order, xd=xd)
+    args = (_Sel(lambda n: val(("u", n))), _Sel(lambda n, d: val(("xu", n, d))))
+    d = beta.factory_derivatives("x_ave", central=False, xalpha=True)
+    got = d.derivs(args=args, order=order)
+    np.testing.assert_allclose(got, legacy["derivs_dep"], rtol=5e-8, atol=1e-10)
+    res = S.resolve_from_args(d.args, args)
+    for k in range(order + 1):
+        bound = S.eval_host(d.series[k], res, absolute=True)
+        assert np.all(np.abs(got[k]) <= bound * (1 + 1e-12))

@@ -77,6 +77,8 @@ SIGNATURES = {
     "txm_set_resample_path": (c_int, [c_int]),
     "txm_resample_vals_info": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_int, ct.POINTER(c_i64), c_void_p]),
     "txm_resample_prep_bytes": (c_size, [c_i64, c_i64, c_i64, c_int]),
+    "txm_resample_y_ws_bytes": (c_size, [c_i64, c_i64, c_i64]),
+    "txm_resample_i8_supported": (c_int, [c_i64, c_i64, c_i64, c_int]),
     "txm_resample_vals_ws_bytes": (c_size, [c_i64, c_i64, c_i64, c_int]),
     "txm_resample_vals": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_i64, c_i64, c_int, c_i64,
                                   c_void_p, ct.POINTER(SamplerSpec), c_void_p, c_void_p, c_void_p,

@@ -923,7 +923,21 @@ extern "C" size_t txm_resample_vals_ws_bytes(int64_t N, int64_t C, int64_t nrep,
     const size_t m = plan_i8(N, C, nrep, order + 1).total;
     if (m > n) n = m;
   }
-  return align_up(n, 256) + y_extra_bytes(N, C, nrep);
+  return align_up(n, 256);
+}
+
+// ... and the scratch a call with opts.y needs BEHIND those bytes when the kernel of the main call does not carry the
+// second matrix (an order-0 bootstrap of its own: its states and its plan).  Opt-in: at the north-star shape it is
+// ~2 GB that a call without opts.y never touches.
+extern "C" size_t txm_resample_y_ws_bytes(int64_t N, int64_t C, int64_t nrep) {
+  if (N < 1 || C < 1 || nrep < 1) return 0;
+  return y_extra_bytes(N, C, nrep);
+}
+
+// whether the int8 kernel can take the shape at all (TXM_PATH_INT8 on a shape it cannot take runs the FP64 kernel)
+extern "C" int txm_resample_i8_supported(int64_t N, int64_t C, int64_t nrep, int order) {
+  if (N < 1 || C < 1 || nrep < 1 || order < 0 || order > TXM_MAX_ORDER) return 0;
+  return i8_supported(N, C, nrep, order + 1) ? 1 : 0;
 }
 
 #define TXM_K_SWITCH(K_, CALL)                          \
@@ -1264,7 +1278,7 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
   TXM_REQUIRE((o.y == nullptr) == (o.out_y == nullptr), "resample_vals: opts.y and opts.out_y go together");
   TXM_REQUIRE(o.y == nullptr || o.ldy_s >= C, "resample_vals: opts.ldy_s < C");
   hipStream_t st = (hipStream_t)stream;
-  const size_t main_bytes = txm_resample_vals_ws_bytes(N, C, nrep, order) - y_extra_bytes(N, C, nrep);
+  const size_t main_bytes = txm_resample_vals_ws_bytes(N, C, nrep, order);
   const size_t avail = ws_bytes < main_bytes ? ws_bytes : main_bytes;
   bool y_done = false;
   int rc = resample_vals_impl(x, ldx_s, u, w, N, C, order, nrep, freq, spec, counts, pivot, out, o.path, o.prep,

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
                    :
                    : "v"(lo0), "v"(hi0), "v"(lo1), "v"(hi1), "s"(wreg), "n"(off), "n"(off + T_PLANE + 128), "n"(off + 256),
                      "n"(off + 256 + T_PLANE + 128)
-                   : "memory");
+                   : "memory", "m0");  // (M0 is written: the compiler must not keep a value of its own there)
 #endif
     };
 

@@ -196,15 +196,27 @@ class ResamplePrep:
     """Persistent pre-pass block of the int8 bootstrap path for ONE set of sample arrays
     (txm_resample_opts.prep): pivot, per-window scale table, guard flags and the FP64 fallback list depend on
     (x, u, w, pivot, N, C, nrep, order) only, so a bootstrap loop over the same data computes them once.  The
-    reference caches per data object the same way (data.py:285, 844-942).  The key holds the tensors' storage
-    pointers and torch version counters: an in-place edit of the samples, another shape or another replicate count
-    invalidates the block; so does ``new_like`` on the owning data object (a fresh cache)."""
+    reference caches per data object the same way (data.py:285, 844-942).
+
+    The key is built from the CALLER's tensors (storage pointer, torch version counter, shape, strides) -- not from the
+    contiguous temporaries a call may have to make -- and the block keeps strong references to them, so their storage
+    cannot be recycled under the key; the temporaries themselves are kept here and reused with the tables.  An in-place
+    edit of a sample array through torch, another shape or another replicate count therefore invalidates the block; so
+    does ``new_like`` on the owning data object (a fresh cache).  What torch cannot see -- another library writing the
+    samples through a raw pointer -- does not bump a version counter: call ``invalidate()`` after such a write (the C
+    ABI has no such state: ``prep_valid`` there is the caller's own statement)."""
 
     def __init__(self):
         self.buf: torch.Tensor | None = None
         self.key = None
+        self.refs = None     # the caller's tensors the key describes
+        self.tensors = None  # what the kernels were given: (x2, u, w, pivot, y2), contiguous copies where needed
         self.hits = 0
         self.misses = 0
+
+    def lookup(self, key):
+        """The kernel operands of the last committed call if ``key`` still describes it, else None."""
+        return self.tensors if (key is not None and self.key == key and self.buf is not None) else None
 
     def bind(self, key, nbytes: int) -> tuple[torch.Tensor, bool]:
         valid = self.key == key and self.buf is not None and self.buf.numel() >= nbytes
@@ -212,23 +224,28 @@ class ResamplePrep:
             if self.buf is None or self.buf.numel() < nbytes:
                 self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device="cuda")
             self.key = None  # set by commit() once the call that fills the block has been issued
+            self.refs = self.tensors = None
             self.misses += 1
         else:
             self.hits += 1
         return self.buf, valid
 
-    def commit(self, key):
+    def commit(self, key, refs=None, tensors=None):
         self.key = key
+        self.refs, self.tensors = refs, tensors
 
     def invalidate(self):
+        """Forget the tables (and the cached operand copies): the next call recomputes them.  Needed only after a write
+        to the sample arrays that torch's version counters do not see."""
         self.key = None
+        self.refs = self.tensors = None
 
 
 def _tkey(t):
     return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()))
 
 
-def _call_path(path, N, C, nrep, order) -> int:
+def _call_path(path) -> int:
     """The kernel one device-sampler call takes: an explicit path, else the forced_path() context, else the
     library's shape rule (txm_resample_path, which honours TXM_I8 and txm_set_resample_path)."""
     eff = path if path is not None else _forced
@@ -251,11 +268,14 @@ def resample_vals(
     prep: ResamplePrep | None = None,
     info: torch.Tensor | None = None,
     y: torch.Tensor | None = None,
+    prep_src: tuple | None = None,
 ):
     """(nrep, C, 2, K) bootstrap states; x is (N, C) row-major (or (N,)).
 
     ``path``: "fp64" / "int8" for THIS call (None: the forced_path() context, else the library's rule).
     ``prep``: a ResamplePrep kept by the caller next to the data -- the int8 path's pre-pass is then computed once.
+    ``prep_src``: the tensors the block's key should describe when x / u / w are themselves temporaries of the caller
+    (default: the arguments as given, before any contiguous copy made here).
     ``info``: an int64 CUDA tensor of 4 words the library fills on the stream (path, windows, windows the guard
     sent to the FP64 kernel, tables reused) -- no synchronisation.
     ``y``: a second (N, C) sample matrix; returns ``(states, ymean)`` with ymean (nrep, C) = the per-replicate
@@ -268,6 +288,9 @@ def resample_vals(
     if x2.dim() != 2:
         raise ValueError("x must be (N,) or (N, C)")
     N, C = x2.shape
+    # the key of a caller-held pre-pass block describes the CALLER's tensors; the copies made below are kept with it
+    src = tuple(prep_src) if prep_src is not None else (x, u, w, pivot, y)
+    src_key = tuple(_tkey(t) for t in src)
     # the kernels want (rec, val) row-major with a row pitch >= C; anything else (transposed views,
     # broadcast rows with stride 0, overlapping pitches) is copied
     if not (x2.stride(1) == 1 or C == 1) or (N > 1 and x2.stride(0) < C):
@@ -308,7 +331,7 @@ def resample_vals(
         if tuple(out.shape) != (nrep, C, 2, order + 1) or not out.is_contiguous():
             raise ValueError(f"out must be a contiguous ({nrep}, {C}, 2, {order + 1}) tensor, got {tuple(out.shape)}")
     opts = ResampleOpts()
-    opts.path = _call_path(path, N, C, nrep, order)
+    opts.path = _call_path(path)
     ymean = y2 = None
     if y is not None:
         _check_f64_cuda(y, "y")
@@ -321,9 +344,16 @@ def resample_vals(
         opts.y, opts.ldy_s, opts.out_y = y2.data_ptr(), max(y2.stride(0) if N > 1 else C, C), ymean.data_ptr()
     key = None
     if prep is not None and freq is None:
-        takes_i8 = opts.path == 1 or (opts.path == -1 and L.txm_resample_path(N, C, nrep, order) == 1)
+        takes_i8 = (opts.path == 1 and L.txm_resample_i8_supported(N, C, nrep, order) == 1) or (
+            opts.path == -1 and L.txm_resample_path(N, C, nrep, order) == 1)
         if takes_i8:
-            key = (_tkey(x2), ls, _tkey(u), _tkey(w), _tkey(pivot), _tkey(y2), N, C, nrep, order)
+            key = (src_key, N, C, nrep, order)
+            kept = prep.lookup(key)
+            if kept is not None:  # same caller tensors, unedited: the operands of the call that filled the block
+                x2, u, w, pivot, y2 = kept
+                ls = max(x2.stride(0) if N > 1 else C, C)
+                if y2 is not None:
+                    opts.y, opts.ldy_s = y2.data_ptr(), max(y2.stride(0) if N > 1 else C, C)
             buf, valid = prep.bind(key, L.txm_resample_prep_bytes(N, C, nrep, order))
             opts.prep, opts.prep_bytes, opts.prep_valid = buf.data_ptr(), buf.numel(), int(valid)
     if info is None:  # the words resample_info() reads back: one block per (device, stream)
@@ -334,14 +364,14 @@ def resample_vals(
     if not (info.is_cuda and info.dtype == torch.int64 and info.numel() >= 4 and info.is_contiguous()):
         raise TypeError("info must be a contiguous int64 CUDA tensor with >= 4 elements")
     opts.info = info.data_ptr()
-    ws = workspace(L.txm_resample_vals_ws_bytes(N, C, nrep, order))
+    ws = workspace(L.txm_resample_vals_ws_bytes(N, C, nrep, order) + (L.txm_resample_y_ws_bytes(N, C, nrep) if y is not None else 0))
     check(
         L.txm_resample_vals(_ptr(x2), ls, 1, _ptr(u), _ptr(w), N, C, order, nrep, _ptr(freq), spec_p, counts_p,
                             _ptr(pivot), _ptr(out), ct.byref(opts), _ptr(ws), ws.numel(), _stream()),
         "txm_resample_vals",
     )
     if key is not None:
-        prep.commit(key)
+        prep.commit(key, refs=src, tensors=(x2, u, w, pivot, y2))
     res = out[:, 0] if squeeze else out
     if y is not None:
         return res, (ymean[:, 0] if y.dim() == 1 else ymean)
@@ -428,8 +458,8 @@ def resample_path(N: int, C: int, nrep: int, order: int) -> str:
     L = _L()
     if _forced == "fp64":
         return "fp64"
-    if _forced == "int8":  # wherever the int8 kernel supports the shape (i8_supported)
-        return "int8" if int(N) >= 1024 and int(order) <= 7 and int(C) <= 2048 else "fp64"
+    if _forced == "int8":  # wherever the int8 kernel supports the shape: the library's own predicate
+        return "int8" if L.txm_resample_i8_supported(int(N), int(C), int(nrep), int(order)) == 1 else "fp64"
     return "int8" if L.txm_resample_path(int(N), int(C), int(nrep), int(order)) == 1 else "fp64"
 
 

@@ -156,10 +156,7 @@ class Derivatives(_Params):
         if data is None:
             if args is None:
                 raise ValueError("must specify args or data")
-            raise NotImplementedError(
-                "derivs(args=...) without a data object is not supported: the functions are evaluated on the "
-                "device from the data object's moment states"
-            )
+            return self._derivs_from_args(args, order, minus_log, order_dim, norm)
         if order is None:
             order = data.order
         if order is None:
@@ -199,6 +196,28 @@ class Derivatives(_Params):
         out = DataArray(host, (order_dim, *src.out_dims))
         out._inherit(src.coords)
         return out
+
+    def _derivs_from_args(self, args, order, minus_log, order_dim, norm):
+        """``derivs(args=...)`` without a data object (reference models.py:357-383: ``funcs[i](*args)``): the caller's
+        arrays are not moment states in HBM, so the polynomials are evaluated where the arguments live -- on the host,
+        with the arguments' own arithmetic (numpy / labelled arrays).  Same tables as the device path."""
+        if order is None:
+            raise ValueError("must specify order or data")
+        if self.args is None:
+            raise ValueError("this Derivatives object does not name its arguments (args=None)")
+        resolve = S.resolve_from_args(self.args, tuple(args))
+        out = [S.eval_host(self.series[i], resolve) for i in range(order + 1)]
+        if minus_log:
+            ml = _minus_log_series()
+            X = list(out)
+            out = [S.eval_host(ml[i], lambda a: X[a[1]]) for i in range(order + 1)]
+        if norm:
+            out = [x / math.factorial(i) for i, x in enumerate(out)]
+        if order_dim is None:
+            return out
+        if all(is_labelled(o) for o in out):
+            return concat(out, order_dim)
+        return np.stack([np.asarray(o, dtype=float) for o in np.broadcast_arrays(*[np.asarray(o) for o in out])])
 
     def coefs(self, data=None, args=None, order=None, minus_log=False, order_dim="order"):
         """Taylor coefficients: ``derivs(..., norm=True)``."""
@@ -425,10 +444,20 @@ class StateCollection(_Params):
             if spec.get("rep0") or state0:
                 raise ValueError("rep0 / state shards address the device sampler's stream: pass device=True in the spec")
             # the reference's draws, state after state from the same generator (what the serial loop consumes)
+            # -- in groups of states whose index / frequency tables stay within EXPLICIT_SAMPLER_MAX elements per launch
+            # (the rule above is per state: a collection just under it would otherwise build S such tables at once)
             rng = cm.validate_rng(spec.get("rng"))
-            idx = np.concatenate([rng.choice(N, size=(nrep, nsamp or N), replace=True) for _ in range(S)])
-            freq = engine.indices_to_freq(torch.as_tensor(idx).cuda(), N)
-            big = engine.resample_vals_batched(xs, us, d0.order, nrep=nrep, freq=freq, ws=ws or None)
+            per = max(1, min(S, cm.EXPLICIT_SAMPLER_MAX // max(nrep * (nsamp or N), 1)))
+            parts = []
+            for a in range(0, S, per):
+                b = min(S, a + per)
+                idx = np.concatenate([rng.choice(N, size=(nrep, nsamp or N), replace=True) for _ in range(a, b)])
+                freq = engine.indices_to_freq(torch.as_tensor(idx).cuda(), N)
+                del idx
+                parts.append(engine.resample_vals_batched(xs[a:b], us[a:b], d0.order, nrep=nrep, freq=freq,
+                                                          ws=ws[a:b] if ws else None))
+                del freq
+            big = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
         cshape = tuple(d0.xv.shape[1:])
         K = d0.order + 1
         big = big.reshape(S, nrep, *cshape, 2, K)

@@ -600,7 +600,9 @@ def wrap_resample_vals(x, *y, mom, sampler, weight=None, axis=MISSING, dim=MISSI
     if x2.dim() == 2 and x2.stride(1) != 1:
         x2 = x2.contiguous()
     if sampler.is_device:
-        st = engine.resample_vals(x2, ut.contiguous(), order, sampler=sampler.device_sampler, w=wt, prep=_prep)
+        # the pre-pass block is keyed on the arrays of the data object (xt, ut, wt), not on the views / copies made here
+        st = engine.resample_vals(x2, ut.contiguous(), order, sampler=sampler.device_sampler, w=wt, prep=_prep,
+                                  prep_src=(xt, ut, wt))
     else:
         st = engine.resample_vals(x2, ut.contiguous(), order, freq=sampler.freq_device(), w=wt)
     st = st.reshape(sampler.nrep, *cshape, 2, order + 1)

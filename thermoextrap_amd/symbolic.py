@@ -337,6 +337,60 @@ def compile_table(polys: Iterable[Poly]):
 
 
 # ---------------------------------------------------------------------------
+# host evaluation on caller-supplied arguments (reference models.py:317-372: ``funcs[i](*args)``)
+# ---------------------------------------------------------------------------
+_ROLE = {"W": "u", "xW": "xu"}  # the volume expansion names its raw moments W / xW (reference volume.py:34-60)
+
+
+def resolve_from_args(names, args):
+    """atom -> value for ``Derivatives.derivs(args=...)``: ``names`` are the symbol families in the order the reference
+    passes them to its lambdified functions (central: x1, du, dxdu; raw: u, xu; callbacks append their own), ``args``
+    the matching objects -- arrays for plain symbols, ``obj[n]`` / ``obj[n, d]`` indexables for the moment families."""
+    if len(names) != len(args):
+        raise ValueError(f"expected {len(names)} args {tuple(names)}, got {len(args)}")
+    by_role = {_ROLE.get(n, n): a for n, a in zip(names, args)}
+
+    def resolve(atom):
+        kind = "u" if atom[0] == "umean" else atom[0]
+        if kind not in by_role:
+            raise ValueError(f"no argument for symbol family {atom[0]!r} (args are {tuple(names)})")
+        obj = by_role[kind]
+        idx = tuple(v for v in atom[1:] if v is not None)
+        if atom[0] == "umean" or not idx:
+            return obj
+        return obj[idx if len(idx) > 1 else idx[0]]
+
+    return resolve
+
+
+def eval_host(p: Poly, resolve, absolute: bool = False):
+    """sum_t c_t prod atoms^powers (- log(atom)) with ordinary arithmetic on whatever ``resolve(atom)`` returns (numpy
+    or labelled arrays, broadcasting as they do).  ``absolute=True`` evaluates sum_t |c_t| prod |atom|^power instead:
+    the scale of the first-order rounding-error bound of the evaluation (the condition number of a derivative is this
+    over its value; tests hold the device table to 1e-12 of it)."""
+    import numpy as np
+
+    cache: dict = {}
+
+    def val(a):
+        if a not in cache:
+            v = resolve(a)
+            cache[a] = abs(v) if absolute else v
+        return cache[a]
+
+    out = 0.0
+    for m, c in p.terms.items():
+        t = abs(float(c)) if absolute else float(c)
+        for a, q in m:
+            t = t * val(a) ** q
+        out = out + t
+    if p.log_atom is not None:
+        lg = np.log(resolve(p.log_atom))
+        out = out + (abs(lg) if absolute else -lg)
+    return out
+
+
+# ---------------------------------------------------------------------------
 # sympy view (for symbolic identity tests and `.exprs`)
 # ---------------------------------------------------------------------------
 def to_sympy(p: Poly):

@@ -8,7 +8,8 @@ C=thermoextrap_amd/csrc
 mkdir -p tools/build
 O=tools/build/$(basename "$OUT" .so)_$(basename "$SRC" .hip).o
 EXTRA=""
-if [ "$SRC" = txm_resample_i8t.hip ]; then EXTRA="-mllvm -amdgpu-mfma-vgpr-form"; fi   # as thermoextrap_amd/_build.py
+if [ "$SRC" = txm_sampler.hip ]; then EXTRA="-ffp-contract=off"; fi
+if [ "$SRC" = txm_resample_i8t.hip ]; then EXTRA="-mllvm -amdgpu-mfma-vgpr-form -Wno-inline-asm"; fi   # as thermoextrap_amd/_build.py
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-pass-failed $EXTRA "$@" -c $C/$SRC -o $O
 OBJS=""
 for f in txm_api txm_reduce txm_sampler txm_small txm_resample txm_resample_i8 txm_resample_i8t txm_perturb; do
