@@ -81,6 +81,27 @@ def dry_run(args):
         dist.init_process_group("gloo")
     rank, world = txd.world()
     nrep = 8
+    if args.config in ("c3", "c5"):
+        # the state-sharded configurations (tools/bench_states.py): every rank owns a contiguous share of the S state
+        # points, one all-gather of the per-state blocks ends a step -- the gather helpers of the product, stand-in blocks
+        S = 16 if args.config == "c3" else 64
+        mine = txd.shard_range(S, rank, world)
+        counts = txd.all_gather_ints(len(mine))                 # what input_GP_from_states(sharded="local") does
+        assert counts == txd.shard_counts(S, world) and sum(counts[:rank]) == mine.start
+        block = torch.zeros((len(mine), 3), dtype=torch.float64)
+        block[:, 0] = torch.arange(mine.start, mine.stop, dtype=torch.float64)
+        block[:, 1] = float(rank)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            full = txd.all_gather_slabs(block, counts)
+        dt = time.perf_counter() - t0
+        assert full[:, 0].tolist() == list(range(S)), full[:, 0].tolist()
+        if rank == 0:
+            print(json.dumps({"metric": "dry-run", "config": args.config, "n_gpus": world, "steps": args.steps, "states": S,
+                              "states_per_rank": counts, "ranks_seen": sorted({int(v) for v in full[:, 1].tolist()})}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     def compute(n, seed, rep0):
         out = torch.full((n, 2, 2, 3), float(rank), dtype=torch.float64)
@@ -126,6 +147,49 @@ def spawn_ranks(n: int) -> int:
     if line is not None:
         print(line, flush=True)
     return r.returncode if line is not None or r.returncode else 1
+
+
+def init_ranks(torch):
+    """(world, rank, local_rank, dist): one rank per GPU over RCCL when started under torch.distributed.run, else (1, 0, 0,
+    None).  Shared by every configuration (tools/bench_states.py for c3 / c5)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # one rank per GPU over RCCL.  TXM_BENCH_BACKEND=gloo is a rehearsal switch for a box with fewer GPUs than
+        # ranks (the ranks then share cards and the final gather goes through host memory): plumbing test only
+        backend = os.environ.get("TXM_BENCH_BACKEND", "nccl")
+        ngpu = torch.cuda.device_count()
+        if backend == "nccl" and local >= ngpu:
+            raise SystemExit(f"rank {rank}: local rank {local} but only {ngpu} GPU(s) visible")
+        local = local % max(ngpu, 1)
+        torch.cuda.set_device(local)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+        world = dist.get_world_size()  # the rank count the process group reports
+    else:
+        torch.cuda.set_device(0)
+    return world, rank, local, dist
+
+
+def ranks_identity(torch, dist, world):
+    """Which GPU every rank ran on (evidence of the rank count under RCCL: one distinct device per rank)."""
+    try:
+        props = torch.cuda.get_device_properties(torch.cuda.current_device())
+        ident = f"{getattr(props, 'uuid', '')}|{getattr(props, 'pci_bus_id', '')}|{torch.cuda.current_device()}"
+        if world > 1:
+            objs = [None] * world
+            dist.all_gather_object(objs, ident)
+            return objs
+        return [ident]
+    except Exception as exc:  # noqa: BLE001
+        return [f"unavailable: {exc}"]
 
 
 def make_data(N, C, seed, torch):
@@ -237,29 +301,7 @@ def main():
 
     import torch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # one rank per GPU over RCCL.  TXM_BENCH_BACKEND=gloo is a rehearsal switch for a box with fewer GPUs than
-        # ranks (the ranks then share cards and the final gather goes through host memory): plumbing test only
-        backend = os.environ.get("TXM_BENCH_BACKEND", "nccl")
-        ngpu = torch.cuda.device_count()
-        if backend == "nccl" and local >= ngpu:
-            raise SystemExit(f"rank {rank}: local rank {local} but only {ngpu} GPU(s) visible")
-        local = local % max(ngpu, 1)
-        torch.cuda.set_device(local)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
-        world = dist.get_world_size()  # the rank count the process group reports
-    else:
-        torch.cuda.set_device(0)
+    world, rank, local, dist = init_ranks(torch)
 
     import thermoextrap_amd as xtrap
     from thermoextrap_amd import distributed as txd
@@ -498,19 +540,7 @@ def main():
         "samples_per_s": N / (t_red * 1e-3),
     }
 
-    # which GPU every rank ran on (evidence of the rank count under RCCL: one distinct device per rank)
-    ranks_seen = None
-    try:
-        props = torch.cuda.get_device_properties(torch.cuda.current_device())
-        ident = f"{getattr(props, 'uuid', '')}|{getattr(props, 'pci_bus_id', '')}|{torch.cuda.current_device()}"
-        if world > 1:
-            objs = [None] * world
-            dist.all_gather_object(objs, ident)
-            ranks_seen = objs
-        else:
-            ranks_seen = [ident]
-    except Exception as exc:  # noqa: BLE001
-        ranks_seen = [f"unavailable: {exc}"]
+    ranks_seen = ranks_identity(torch, dist, world)
 
     if rank == 0:
         par = f"replicate-slabs x{world} (nrep/{world} per GPU, same state point)" if replicas else f"state-points x{world}"

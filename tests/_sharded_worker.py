@@ -2,6 +2,7 @@
 Checks, on a real device, that what the ranks compute together equals the one-process result BIT FOR BIT:
   * StateCollection.resample(spec, sharded=True)  (5 states: shards of 3 and 2 -- and of 1 for a 5-rank layout emulated
     by hand below)                                  vs  StateCollection.resample(spec)
+  * gpr_input.input_GP_from_states(sharded=True / "local")  vs  the one-process call (x, y and the block-diagonal noise)
   * distributed.run_step("replicas", ...)           vs  the full-nrep call, on both bootstrap kernels
 Writes <outdir>/rank<r>.json."""
 import json
@@ -52,6 +53,18 @@ def main(outdir):
     ref = mine.clone()
     dist.broadcast(ref, src=0)
     res["unseeded_consistent"] = bool(torch.equal(mine, ref))
+
+    # ---- GP input of the collection (BASELINE config 5's call), states over the ranks: the whole collection on every
+    # rank (sharded=True) and only the rank's own states (sharded="local") vs one process
+    gspec = {"nrep": nrep, "seed": 1234, "device": True}
+    one = xtrap.gpr_input.input_GP_from_states(coll, n_rep=nrep, sampler=gspec)
+    share = D.shard_range(S, rank, world)
+    local = xtrap.models.StateCollection(sts[share.start:share.stop])
+    for key, got in (("gp_sharded", xtrap.gpr_input.input_GP_from_states(coll, n_rep=nrep, sampler=gspec, sharded=True)),
+                     ("gp_local", xtrap.gpr_input.input_GP_from_states(local, n_rep=nrep, sampler=gspec, sharded="local")),
+                     ("gp_log", xtrap.gpr_input.input_GP_from_states(local, n_rep=nrep, sampler=gspec, sharded="local", log_scale=True))):
+        ref = one if key != "gp_log" else xtrap.gpr_input.input_GP_from_states(coll, n_rep=nrep, sampler=gspec, log_scale=True)
+        res[key + "_equal"] = all(a.shape == b.shape and bool((a == b).all()) for a, b in zip(got, ref))
 
     # ---- replicate slabs of one state point, both kernels
     N2, C2, order2, nrep2 = 290_000, 32, 4, 130

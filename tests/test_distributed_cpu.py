@@ -153,3 +153,21 @@ def test_bench_starts_its_own_ranks(tmp_path):
         assert len(lines) == 1, lines
         rec = json.loads(lines[0])
         assert rec["n_gpus"] == 2 and rec["rows"] == rows and rec["ranks_seen"] == [0, 1] and rec["mode"] == mode
+
+
+def test_bench_state_sharded_configs_start_their_own_ranks():
+    """`bench.py --config c3|c5 --gpus 2` (BASELINE configs 3 and 5 are quoted sharded over 8 GPUs): the STATE POINTS go over
+    the ranks.  --dry-run: launcher, rendezvous and the product's gather helpers on the CPU with stand-in blocks -- the
+    all-gather returns all 16 / 64 states, in order, and rank 0 prints one line naming both ranks."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    for cfg, S in (("c3", 16), ("c5", 64)):
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--config", cfg, "--gpus", "2", "--steps", "2", "--dry-run"],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, lines
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == 2 and rec["states"] == S and rec["states_per_rank"] == [S // 2, S // 2]
+        assert rec["ranks_seen"] == [0, 1] and rec["config"] == cfg

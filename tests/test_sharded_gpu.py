@@ -29,5 +29,6 @@ def test_two_ranks_equal_one_process_bit_for_bit(txm, tmp_path):
     for r in range(2):
         res = json.loads((tmp_path / f"rank{r}.json").read_text())
         assert res["world"] == 2 and res["rank"] == r
-        for k in ("states_equal", "states_batch_equal", "unseeded_consistent", "replicas_equal_int8", "replicas_equal_fp64"):
+        for k in ("states_equal", "states_batch_equal", "unseeded_consistent", "replicas_equal_int8", "replicas_equal_fp64",
+                  "gp_sharded_equal", "gp_local_equal", "gp_log_equal"):
             assert res[k] is True, (r, k, res)

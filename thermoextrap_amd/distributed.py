@@ -62,6 +62,18 @@ def all_gather_slabs(local: torch.Tensor, counts: Sequence[int] | None = None, g
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
 
 
+def all_gather_ints(value: int, group=None) -> list[int]:
+    """Every rank's Python int, in rank order."""
+    rank, w = world()
+    if w == 1:
+        return [int(value)]
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    ts = [torch.zeros_like(t) for _ in range(w)]
+    dist.all_gather(ts, t, group=group)
+    return [int(v.item()) for v in ts]
+
+
 def broadcast_int(value: int, src: int = 0, group=None) -> int:
     """The same Python int on every rank (rank `src`'s)."""
     rank, w = world()
