@@ -33,98 +33,22 @@
 // by the finalize kernel in window order.  A replicate's result therefore does not depend on how many replicates,
 // chunks or workgroups the launch had: rows [a, b) of a bootstrap equal the (b - a)-replicate call with rep0 = a
 // bit for bit (multi-GPU slabs, txm_sampler_spec.rep0).
-#include "txm_resample_i8.h"
-#include "txm_sampler.h"
-
-#include <type_traits>
-#include <utility>
+#include "txm_i8t_common.h"
 
 namespace txm {
 
-typedef int v2i __attribute__((ext_vector_type(2)));
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
-typedef __attribute__((address_space(3))) v2i *lds_v2i;
-#ifdef TXM_T_NO_TR  // ablation build: plain 8-byte reads in place of the transposing ones
-#define T_TRREAD(p) (*(p))
+// staged factor tiles: entry e (sample e of the 1024 the tile's k-steps slice) -> line of the tile.  A lane reads the
+// factors of its two samples (e and e + 16).  The second unit's lines sit 513 lines further on -- out of the reach of a
+// ds_read2_b64 pair and not a multiple of 64 lines (ds_read2st64_b64 would pair them again): two ds_read_b64 (2 LDS
+// cycles each) instead of one paired read (8).  Same-box A/B, round 4: 36.4 -> 35.8 ms at N = 2e7, 165.8 -> 163.2 ms at
+// the north star (-1.6 %); TXM_T_PAIRREAD restores the adjacent layout.
+#ifndef TXM_T_PAIRREAD
+#define T_PIDX(e) (((((e) >> 4) & 1) * 513) + (((e) >> 5) * 16) + ((e) & 15))
+#define T_PUNIT 513
 #else
-#define T_TRREAD(p) __builtin_amdgcn_ds_read_tr8_b64_v2i32(p)
+#define T_PIDX(e) (e)
+#define T_PUNIT 16
 #endif
-
-constexpr int T_BLOCK = 512;  // 8 waves, two per SIMD (256 registers each: 11 accumulator tiles in AGPRs + 80 VGPRs)
-constexpr int T_WAVES = T_BLOCK / 64;
-constexpr int T_CNT_BYTES = (SM_T / 4) * I8_REPS * 4;  // 65536: [256 words][64 replicates]
-constexpr int T_FRAG = 1024;                           // [32 samples][4 columns][8 bytes]
-constexpr int T_STEPS = SM_T / 32;
-#ifndef TXM_T_XD
-#define TXM_T_XD 2
-#endif
-constexpr int T_XD = TXM_T_XD;  // k-steps between the request of an x chunk and its use (the step loop is unrolled by max(4, depth))
-#ifndef TXM_T_XDN
-#define TXM_T_XDN 8
-#endif
-// ... of the narrow-state variant: its k-steps are short (a few MFMAs per wave), so the same memory latency is more
-// k-steps (measured at BASELINE config 2: depth 2 left the k-steps waiting for x -- 850 cycles each for 3 MFMAs)
-constexpr int T_XDN = TXM_T_XDN;
-static_assert((T_XD == 1 || T_XD == 2 || T_XD == 4 || T_XD == 8) && (T_XDN == 1 || T_XDN == 2 || T_XDN == 4 || T_XDN == 8), "ring depth");
-// 1.5 * 2^52 + 0x80 in each of the six low mantissa bytes (the digits come out biased by 128; byte 6 holds
-// 0x38 + digit 6, taken out at flush time as 56 * draws; byte 7 is the sign/exponent byte: the dead slot)
-constexpr double T_MAGIC = 6755399441055744.0 + 141289400074368.0;
-constexpr int T_D6_BIAS = 0x38;
-
-// Registers.  A wave holds up to 11 accumulator tiles = 176 registers of its 256.  The compiler's default splits a
-// 256-register budget 128 : 128 between VGPRs and AGPRs as soon as a function uses AGPRs, which leaves room for 8 tiles
-// only: the rest would migrate between the two files around every MFMA (v_accvgpr moves by the hundred per k-step) or
-// spill.  This file is therefore compiled with  -mllvm -amdgpu-mfma-vgpr-form  (thermoextrap_amd/_build.py): every
-// MFMA takes its accumulator in VGPRs, the kernel uses no AGPR at all and all 256 registers are one file.
-// (Pinning register classes with inline-asm MFMAs was tried first and is WRONG under register pressure: the compiler
-// does not know an asm's output is an MFMA result, so a spill store placed right behind it reads the registers before
-// the matrix pipe has written them -- silent wrong sums, measured.)
-template <int... I, class F>
-__device__ __forceinline__ void t_static_for_impl(std::integer_sequence<int, I...>, F &&f) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void t_static_for(F &&f) {
-  t_static_for_impl(std::make_integer_sequence<int, N>{}, f);
-}
-
-template <bool AG>
-__device__ __forceinline__ void t_mfma(v16i &c, const v4i &a, const v4i &b) {
-#ifdef TXM_T_NO_MFMA  // ablation build
-  asm volatile("" : "+v"(const_cast<v4i &>(a)), "+v"(const_cast<v4i &>(b)));
-  return;
-#endif
-  c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
-}
-
-template <bool ALL_VALID>
-__device__ __forceinline__ void t_fill_call(uint32_t *cntw, uint32_t k0, uint32_t k1, uint32_t rs, uint32_t t, uint32_t c,
-                                            uint32_t n, uint32_t lane4) {
-  // lane = replicate: counter word 2 differs per lane, words 0, 1, 3 are wave-uniform
-  const uint32_t first = c * 12u;
-  // (XOR3: the two XORs of a Philox round as one v_bitop3_b32 -- 3 % of the kernel here; it lost in the old kernel's
-  // fused fill, txm_sampler.h)
-  const Philox4 o = philox4x32_10<true>(t, c, rs, 3u, k0, k1);
-#pragma unroll
-  for (int wi = 0; wi < 4; ++wi) {
-    const uint32_t word = o.w[wi];
-    // byte lane of every field at once: keep bits {0, 1} of the three fields, so that a plain shift leaves 8 * (f & 3) in
-    // the five bits the shifter reads and zeros below them.  The opaque values keep this selection (mask once; bfe +
-    // lshl_add for the address): 4 instead of 6 vector instructions per draw -- left alone the optimiser re-splits the
-    // shared mask into shift, and, and per field
-    uint32_t lo2 = word & 0x00300C03u;
-    asm volatile("" : "+v"(lo2));
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      uint32_t q = __builtin_amdgcn_ubfe(word, 10 * k + 2, 8);  // field >> 2: the count word of the sample
-      asm volatile("" : "+v"(q));
-      uint32_t inc = 1u << (((k == 0) ? (lo2 << 3) : (lo2 >> (10 * k - 3))) & 31u);
-      if (!ALL_VALID) inc = (first + (uint32_t)(wi * 3 + k) < n) ? inc : 0u;
-      atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(cntw) + (q << 8) + lane4), inc);
-    }
-  }
-}
 
 // K = order + 1 is a run-time argument (it only enters the flush addresses); one launch slices the JN powers
 // J0 .. J0 + JN - 1.
@@ -336,14 +260,14 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       // (the base is an opaque byte offset: the staged tiles sit above 64 KiB, and with the constant folded in every read
       // got a v_add_u32 of its own for "lane part + 0x1fb00"; an opaque base takes the 16-bit immediate offsets)
       const uint32_t pt_lds = (uint32_t)(reinterpret_cast<const unsigned char *>(ptile) - lds);  // compile-time constant
-      uint32_t pt_b = pt_lds + (uint32_t)((((staged ? e0 : 0) + ps) * NPT + g) * 8);
-      uint32_t pu_b = pt_lds + (uint32_t)((((staged ? e0 : 0) + ps) * NPT + umc) * 8);
+      uint32_t pt_b = pt_lds + (uint32_t)((T_PIDX((staged ? e0 : 0) + ps) * NPT + g) * 8);
+      uint32_t pu_b = pt_lds + (uint32_t)((T_PIDX((staged ? e0 : 0) + ps) * NPT + umc) * 8);
       asm volatile("" : "+v"(pt_b), "+v"(pu_b));
       typedef __attribute__((address_space(3))) const double *lds_cd;
       auto pt_at = [&](uint32_t base, int idx) { return ((lds_cd)(lds + base))[idx]; };  // (cast first: the index is then a 32-bit LDS offset)
       auto factor = [&](int fi, int uu) {  // row set fi = power J0 + g + fi GS
         if (NQ == 8 && !WEIGHTED && J0 == 0 && fi == 0) return 1.0;
-        if (staged) return pt_at(pt_b, fi * GS + 16 * NPT * uu);
+        if (staged) return pt_at(pt_b, fi * GS + T_PUNIT * NPT * uu);
         double pw = WEIGHTED ? d_w[uu] : 1.0;
         for (int q = 0; q < J0 + g + fi * GS; ++q) pw *= d_du[uu];
         return pw;
@@ -352,7 +276,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       auto factor_y = [&](int uu) {
         if (!WEIGHTED) return 1.0;
         if (!staged) return d_w[uu];
-        return J0 == 0 ? pt_at(pt_b, 16 * NPT * uu) : pt_at(pt_b, JN + 16 * NPT * uu);  // tile 0 is w du^0 when J0 == 0, else the extra tile (NQ = 8: g = 0)
+        return J0 == 0 ? pt_at(pt_b, T_PUNIT * NPT * uu) : pt_at(pt_b, JN + T_PUNIT * NPT * uu);  // tile 0 is w du^0 when J0 == 0, else the extra tile (NQ = 8: g = 0)
       };
       t_static_for<NS>([&](auto fic) {
         constexpr int fi = decltype(fic)::value;
@@ -397,7 +321,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
           double pw[2];
 #pragma unroll
           for (int uu = 0; uu < 2; ++uu) {
-            if (staged) pw[uu] = pt_at(pu_b, 16 * NPT * uu);
+            if (staged) pw[uu] = pt_at(pu_b, T_PUNIT * NPT * uu);
             else {
               pw[uu] = WEIGHTED ? d_w[uu] : 1.0;
               for (int q = 0; q < J0 + umc; ++q) pw[uu] *= d_du[uu];
@@ -617,12 +541,12 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const int e = (int)threadIdx.x + q * T_BLOCK;
         const double du = (su[q] - pu) * inv_du;
         double pw = WEIGHTED ? sw[q] * inv_w : 1.0;
-        if constexpr (NPT > JN) ptile[e * NPT + JN] = pw;  // plain w for the y row set
+        if constexpr (NPT > JN) ptile[T_PIDX(e) * NPT + JN] = pw;  // plain w for the y row set
 #pragma unroll
         for (int k = 0; k < J0; ++k) pw *= du;
 #pragma unroll
         for (int jj = 0; jj < JN; ++jj) {
-          ptile[e * NPT + jj] = pw;
+          ptile[T_PIDX(e) * NPT + jj] = pw;
           pw *= du;
         }
       }
@@ -690,7 +614,7 @@ static int launch_pass_t(const I8Args &a, int K, size_t prog_bytes, hipStream_t 
   const dim3 grid((unsigned)(a.n_chunks * a.n_rbg)), block(T_BLOCK);
   constexpr int gs = 8 / NQ, ns = (JN + gs - 1) / gs + (YS ? 1 : 0), npt = JN + ((YS && WEIGHTED && J0 > 0) ? 1 : 0);
   const size_t lds = (size_t)T_WAVES * (ns + 1) * T_PB + T_CNT_BYTES + 3u * I8_REPS * sizeof(uint32_t) +
-                     (size_t)npt * SM_T * sizeof(double);
+                     (size_t)npt * (SM_T + (T_PUNIT == 16 ? 0 : 1)) * sizeof(double);
   TXM_SET_MAX_LDS((&resample_i8t_kernel<J0, JN, WEIGHTED, YS, NQ>), lds);
   hipLaunchKernelGGL((resample_i8t_kernel<J0, JN, WEIGHTED, YS, NQ>), grid, block, lds, st, a, K);
   TXM_LAUNCH_CHECK();
