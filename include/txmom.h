@@ -240,7 +240,7 @@ int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, const doubl
  * the state on a grid axis.  `states_host` is a HOST array of S device-pointer triples (w NULL for all
  * states or for none); it is copied into the workspace by the call (not stream-capturable).
  *   txm_reduce_vals_batched:   out [S][C][2][K]            (= S x txm_reduce_vals, x row-major, pitch ldx_s)
- *   txm_resample_vals_batched: out [S][nrep][C][2][K]      (= S x txm_resample_vals, FP64 kernel)
+ *   txm_resample_vals_batched: out [S][nrep][C][2][K]      (= S x txm_resample_vals; FP64 kernel, or the int8 path below)
  *     sampler: ONE spec over S * nrep replicates of ndat = N (state s owns replicates s*nrep ..
  *     (s+1)*nrep - 1 of the stream, so the states' bootstrap samples are independent), with its
  *     counts [S * nrep][ntiles]; or an explicit freq table [S * nrep][N]. */
@@ -258,6 +258,19 @@ int txm_resample_vals_batched(const txm_state_ptrs *states_host, int64_t S, int6
                               int64_t C, int order, int64_t nrep, const int64_t *freq,
                               const txm_sampler_spec *spec_host, const uint32_t *counts, double *out,
                               void *ws, size_t ws_bytes, txm_stream stream);
+/* The same with per-call options (round 4; txm_resample_vals_batched == opts_host NULL).  Narrow states (C <= 16
+ * observables, order >= 2, >= 64 replicates per state, N >= 262144; or opts.path = TXM_PATH_INT8 wherever
+ * txm_resample_i8_supported) run the int8 path of txm_resample_vals with the state on a grid axis of EVERY kernel of it
+ * (pre-pass, bootstrap kernel, the precision guard's FP64 fallback, finalize): state s of the batch is, bit for bit, the
+ * single call on state s with spec.rep0 + s * nrep.  Fields of txm_resample_opts used: path, info, prep / prep_bytes /
+ * prep_valid (ONE block of txm_resample_batched_prep_bytes() for the S states -- their pivots, window tables, guard flags
+ * and fallback lists; 0 bytes = the shape never takes the int8 path); y / out_y must be NULL.
+ * Reference loops replaced: models.py:635-641, gpr_active/active_utils.py:896-925. */
+size_t txm_resample_batched_prep_bytes(int64_t S, int64_t N, int64_t C, int64_t nrep, int order);
+int txm_resample_vals_batched_opts(const txm_state_ptrs *states_host, int64_t S, int64_t ldx_s, int64_t N,
+                                   int64_t C, int order, int64_t nrep, const int64_t *freq,
+                                   const txm_sampler_spec *spec_host, const uint32_t *counts, double *out,
+                                   const txm_resample_opts *opts_host, void *ws, size_t ws_bytes, txm_stream stream);
 
 /* ---- a4/a5: CentralMomentsData.reduce / resample_and_reduce ------------- */
 /* Block bootstrap of pre-reduced states: replicate r merges freq[r][i] copies

@@ -272,3 +272,87 @@ def test_c5_sixty_four_states_gp_input_fullsize(txm, eng):
     assert (off == 0).all()                                               # states are independent: block diagonal
     # bootstrap spread of the first derivative order ~ sigma / sqrt(N)
     np.testing.assert_allclose(res[:, 0].std(axis=1), np.stack([x.std(dim=0).cpu().numpy() for x in xs]) / np.sqrt(N), rtol=0.4)
+
+
+# ---- the int8 path with the state on a grid axis (round 4; BASELINE config 5's launch) ---------------------------------
+@pytest.mark.parametrize("S,N,C,order,nrep,weighted", [
+    (3, 300000, 4, 3, 100, False),   # config 5's state shape, one column quad
+    (4, 270000, 8, 4, 70, True),     # two quads, weights, a ragged replicate group
+    (2, 300000, 13, 6, 64, False),   # four quads, order 6 in two passes
+    (5, 9000, 3, 2, 65, False),      # short series: 4-tile windows, sliding last tile
+])
+def test_batched_int8_equals_single_calls_bit_for_bit_and_oracle(eng, orc, S, N, C, order, nrep, weighted):
+    """State s of the batched int8 launch == the single int8 call on state s with rep0 = s * nrep, bit for bit (same
+    per-window partial-sum slots, same finalize tree), and the oracle's extended-precision definition to 1e-12."""
+    xs, us, ws = states(S, N, C, 5, weighted)
+    smp = eng.DeviceSampler(77, S * nrep, N)
+    got = eng.resample_vals_batched(xs, us, order, nrep=nrep, sampler=smp, ws=ws, path="int8")
+    assert got.shape == (S, nrep, C, 2, order + 1) and torch.isfinite(got).all()
+    for s in range(S):
+        one = eng.resample_vals(xs[s], us[s], order, sampler=eng.DeviceSampler(77, nrep, N, rep0=s * nrep),
+                                w=None if ws is None else ws[s], path="int8")
+        assert eng.resample_info()["path"] == "int8"
+        assert torch.equal(got[s], one)
+    fp = eng.resample_vals_batched(xs, us, order, nrep=nrep, sampler=smp, ws=ws, path="fp64")
+    for s in range(S):
+        assert relerr(got[s], fp[s], scale(xs[s], us[s], order + 1)[None]) < 5e-13
+    if N <= 300000:
+        freq = smp.freq()
+        for s, r in ((0, 0), (S - 1, nrep - 1)):
+            fr = freq[s * nrep + r].cpu().numpy().astype(np.float64)
+            w = fr if ws is None else fr * ws[s].cpu().numpy()
+            t = orc.truth_cov(xs[s].cpu().numpy(), us[s].cpu().numpy(), order, w=w)
+            sc = scale(xs[s], us[s], order + 1).cpu().numpy()
+            assert (np.abs(got[s, r].cpu().numpy() - t) / (np.abs(t) + sc)).max() < 1e-12
+
+
+def test_batched_int8_guard_falls_back_per_state(eng, orc):
+    """An outlier in ONE state sends that state's window to the FP64 kernel inside the batched call; the other states'
+    bits do not change, and the state with the outlier still matches the oracle."""
+    S, N, C, order, nrep = 4, 300000, 4, 4, 64
+    xs, us, _ = states(S, N, C, 9)
+    smp = eng.DeviceSampler(5, S * nrep, N)
+    clean = eng.resample_vals_batched(xs, us, order, nrep=nrep, sampler=smp, path="int8")
+    us2 = [u.clone() for u in us]
+    us2[2][N // 3] += 5.0e4
+    info = torch.zeros(4, dtype=torch.int64, device="cuda")
+    dirty = eng.resample_vals_batched(xs, us2, order, nrep=nrep, sampler=smp, path="int8")
+    for s in (0, 1, 3):
+        assert torch.equal(dirty[s], clean[s])
+    one = eng.resample_vals(xs[2], us2[2], order, sampler=eng.DeviceSampler(5, nrep, N, rep0=2 * nrep), path="int8")
+    assert eng.resample_info()["windows_fp64"] >= 1
+    assert torch.equal(dirty[2], one)
+    freq = smp.freq()
+    sc = scale(xs[2], us[2], order + 1).cpu().numpy()   # the scale of the clean data (an outlier must not hide an error)
+    for r in (0, nrep - 1):
+        fr = freq[2 * nrep + r].cpu().numpy().astype(np.float64)
+        t = orc.truth_cov(xs[2].cpu().numpy(), us2[2].cpu().numpy(), order, w=fr)
+        assert (np.abs(dirty[2, r].cpu().numpy() - t) / (np.abs(t) + sc)).max() < 1e-11
+
+
+def test_batched_prep_block_is_computed_once_and_follows_edits(eng):
+    S, N, C, order, nrep = 3, 300000, 4, 3, 64
+    xs, us, _ = states(S, N, C, 13)
+    smp = eng.DeviceSampler(1, S * nrep, N)
+    prep = eng.ResamplePrep()
+    a = eng.resample_vals_batched(xs, us, order, nrep=nrep, sampler=smp, path="int8", prep=prep)
+    b = eng.resample_vals_batched(xs, us, order, nrep=nrep, sampler=smp, path="int8", prep=prep)
+    assert (prep.misses, prep.hits) == (1, 1) and torch.equal(a, b)
+    assert torch.equal(a, eng.resample_vals_batched(xs, us, order, nrep=nrep, sampler=smp, path="int8"))
+    us[1].mul_(1.5)                      # an in-place edit of ONE state: the whole block is recomputed
+    c = eng.resample_vals_batched(xs, us, order, nrep=nrep, sampler=smp, path="int8", prep=prep)
+    assert prep.misses == 2
+    assert torch.equal(c, eng.resample_vals_batched(xs, us, order, nrep=nrep, sampler=smp, path="int8"))
+    assert not torch.equal(c[1], a[1]) and torch.equal(c[0], a[0])
+
+
+def test_batched_default_dispatch_rule(eng):
+    """Small batches stay on the FP64 kernel, config-5-sized ones take the int8 path (same numbers either way)."""
+    xs, us, _ = states(2, 300000, 4, 21)
+    smp = eng.DeviceSampler(3, 2 * 64, 300000)
+    auto = eng.resample_vals_batched(xs, us, 3, nrep=64, sampler=smp)
+    assert torch.equal(auto, eng.resample_vals_batched(xs, us, 3, nrep=64, sampler=smp, path="fp64"))
+    xs, us, _ = states(17, 1 << 20, 4, 22)
+    smp = eng.DeviceSampler(3, 17 * 64, 1 << 20)
+    auto = eng.resample_vals_batched(xs, us, 3, nrep=64, sampler=smp)
+    assert torch.equal(auto, eng.resample_vals_batched(xs, us, 3, nrep=64, sampler=smp, path="int8"))

@@ -89,6 +89,10 @@ SIGNATURES = {
     "txm_resample_vals_batched_ws_bytes": (c_size, [c_i64, c_i64, c_i64, c_i64, c_int]),
     "txm_resample_vals_batched": (c_int, [ct.POINTER(StatePtrs), c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_void_p,
                                           ct.POINTER(SamplerSpec), c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
+    "txm_resample_batched_prep_bytes": (c_size, [c_i64, c_i64, c_i64, c_i64, c_int]),
+    "txm_resample_vals_batched_opts": (c_int, [ct.POINTER(StatePtrs), c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_void_p,
+                                               ct.POINTER(SamplerSpec), c_void_p, c_void_p, ct.POINTER(ResampleOpts), c_void_p,
+                                               c_size, c_void_p]),
     "txm_resample_data_ws_bytes": (c_size, [c_i64, c_i64, c_int]),
     "txm_resample_data": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_size,
                                   c_void_p]),

@@ -90,6 +90,8 @@ struct ResampleArgs {
   // from batch[s]; pivot, the partial sums, counts / freq rows and the sampler's replicate ids are those of the
   // single-state layout shifted by s (replicate s * nrep + r of one sampler over S * nrep replicates)
   const txm_state_ptrs *batch;
+  // listed mode of a BATCHED int8 call: the fallback runs of state blockIdx.z, operands from the int8 path's state table
+  const I8State *i8states = nullptr;
   // L2-sharing hint (nullptr: off).  The waves that contract one sample chunk -- 4 per workgroup x the replicate
   // groups of the chunk, placed on one XCD by the block map -- read the same samples; left alone they drift apart
   // by many tiles and every one of them streams the chunk from HBM again (measured: 19x the algorithmic bytes).
@@ -231,8 +233,22 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
   }
   constexpr bool listed = MODE == RS_LISTED;
   int64_t nruns = 1;
+  const uint32_t *LIST = a.list, *NLIST = a.n_list;
   if constexpr (listed) {
-    nruns = (int64_t)*a.n_list;
+    if (a.i8states != nullptr) {  // batched int8 call: state blockIdx.z
+      const I8State e = a.i8states[blockIdx.z];
+      X = e.x + a.col_off;  // (a.x of a listed launch is x + the column group's offset)
+      U = e.u;
+      W = e.w;
+      PIV = e.pivot;
+      CNT = e.counts;
+      PX = e.fb_x;
+      PU = e.fb_u;
+      rid0 = e.rep_base;
+      LIST = e.list;
+      NLIST = e.n_list;
+    }
+    nruns = (int64_t)*NLIST;
     if (nruns == 0) return;  // nothing flagged: the finalize kernel does not read this launch's partial sums
   }
 
@@ -282,7 +298,7 @@ __global__ __launch_bounds__(RS_BLOCK, 2) void resample_kernel(const ResampleArg
   for (int64_t run = listed ? chunk : 0; run < nruns; run += listed ? a.n_chunks : 1) {
   int64_t tb = t_begin, te = t_end;
   if constexpr (listed) {
-    tb = (int64_t)a.list[run];
+    tb = (int64_t)LIST[run];
     te = tb + a.sub_tiles;
     if (te > a.ntiles) te = a.ntiles;
   }
@@ -583,7 +599,12 @@ __global__ __launch_bounds__(256) void resample_finalize_i8_kernel(
     const uint32_t *__restrict__ wflag, int64_t nrep_pad, int64_t nrep, int64_t C,
     const double *__restrict__ pivot, double *__restrict__ out, int64_t c_off, int64_t C_total,
     const double *__restrict__ fb_x, const double *__restrict__ fb_u, int fb_chunks, int64_t fb_cpad,
-    const uint32_t *__restrict__ n_list) {
+    const uint32_t *__restrict__ n_list, const I8State *__restrict__ states = nullptr) {
+  if (states != nullptr) {  // batched int8 call: state blockIdx.y
+    const I8State e = states[blockIdx.y];
+    part_x = e.part_x; part_u = e.part_u; wflag = e.wflag; pivot = e.pivot; out = e.out;
+    fb_x = e.fb_x; fb_u = e.fb_u; n_list = e.n_list;
+  }
   // CPAD = columns of a row of part_x (32; 4, 8 or 16 where the narrow-state kernel wrote it)
   constexpr int cpad = CPAD;
   // one workgroup per replicate: thread = (column c < cpad, window segment seg of 256 / cpad).  Segment seg adds the
@@ -1020,8 +1041,8 @@ static int run_resample(ResampleArgs a, const ResamplePlan &p, bool weighted, bo
 
 // the bootstrap kernel alone, in listed mode (device sampler, N >= one tile), partial sums left for the caller's finalize
 template <int K>
-static int run_listed_k(const ResampleArgs &a, const ResamplePlan &p, bool weighted, hipStream_t st) {
-  dim3 grid((unsigned)(p.n_chunks * p.n_rbg), (unsigned)p.colgroups), block(RS_BLOCK);
+static int run_listed_k(const ResampleArgs &a, const ResamplePlan &p, bool weighted, hipStream_t st, int64_t S = 1) {
+  dim3 grid((unsigned)(p.n_chunks * p.n_rbg), (unsigned)p.colgroups, (unsigned)S), block(RS_BLOCK);
   const size_t lds = (size_t)RS_WAVES * RS_TILE_BYTES;
   if (p.nblk == 1) {
     if (weighted) hipLaunchKernelGGL((resample_kernel<K, 1, true, false, false, RS_LISTED>), grid, block, lds, st, a);
@@ -1034,12 +1055,12 @@ static int run_listed_k(const ResampleArgs &a, const ResamplePlan &p, bool weigh
   return TXM_OK;
 }
 
-static int run_listed(const ResampleArgs &a, const ResamplePlan &p0, int K, bool weighted, hipStream_t st) {
+static int run_listed(const ResampleArgs &a, const ResamplePlan &p0, int K, bool weighted, hipStream_t st, int64_t S = 1) {
   // the plan was made for a full 32-column group; a narrower last group uses one 16-column block
   ResamplePlan p = p0;
   if (a.C <= 16) p.nblk = 1;
   p.colgroups = 1;
-  TXM_K_SWITCH(K, return run_listed_k<KK>(a, p, weighted, st));
+  TXM_K_SWITCH(K, return run_listed_k<KK>(a, p, weighted, st, S));
   return TXM_OK;
 }
 }  // namespace txm
@@ -1323,15 +1344,234 @@ static BatchPlan plan_batched(int64_t S, int64_t N, int64_t C, int64_t nrep, int
 }
 }  // namespace txm
 
+// ---- S narrow state points on the int8 path (BASELINE config 5: 64 states x 1e6 samples x 4 observables) ----------------
+// The reference loops over states in Python (models.py:635-641, gpr_active/active_utils.py:896-925).  Every kernel of the
+// single-state int8 call (pre-pass, transposing-read kernel in its narrow-state variant, FP64 fallback in listed mode,
+// finalize) takes the state from a grid axis and its operands from an I8State table, so the batch is the same arithmetic
+// on the same per-window slots as S single calls: the same bits (tests/test_batched_gpu.py).
+namespace txm {
+struct I8StateLayout {
+  size_t stride, s_px, s_pu, s_fbx, s_fbu, s_stats;     // a state's scratch block in the workspace
+  size_t p_stride, p_wt, p_flag, p_list, p_nlist;       // a state's pre-pass block (workspace, or the caller's prep buffer)
+};
+struct BatchI8Plan {
+  I8Plan q;                  // one state's plan: windows, replicate groups, the fallback's chunking
+  int cpad, n_chunks;
+  int64_t tiles_per_chunk;
+  I8StateLayout L;
+  size_t off_tab, off_states, off_state0, off_prep, total;
+  size_t prep_piv, prep_state0, prep_total;  // the pre-pass block: pivots [S][1 + C], then the states' tables
+};
+static BatchI8Plan plan_batched_i8(int64_t S, int64_t N, int64_t C, int64_t nrep, int K) {
+  BatchI8Plan b;
+  b.q = plan_i8(N, C, nrep, K);
+  const I8Plan &q = b.q;
+  b.cpad = i8_cpad(C, K);
+  // chunks of whole windows: the S states fill the chip together (the per-window slots make the sums independent of it)
+  int64_t nc = (int64_t)num_cus() / ((int64_t)q.n_rbg * S) / 8 * 8;
+  if (nc < 8) nc = 8;
+  if (nc > q.nwin) nc = cdiv(q.nwin, 8) * 8;
+  b.tiles_per_chunk = cdiv(q.nwin, nc) * q.win_tiles;
+  b.n_chunks = (int)(cdiv(cdiv(q.ntiles, b.tiles_per_chunk), 8) * 8);
+  I8StateLayout &L = b.L;
+  L.s_px = 0;
+  L.s_pu = L.s_px + align_up((size_t)q.nwin * q.nrep_pad * K * 8 * b.cpad * sizeof(double), 256);
+  L.s_fbx = L.s_pu + align_up((size_t)q.nwin * q.nrep_pad * K * 8 * sizeof(double), 256);
+  L.s_fbu = L.s_fbx + align_up((size_t)q.fb.n_chunks * q.fb.nrep_pad * q.fb.C_pad * K * sizeof(double), 256);
+  L.s_stats = L.s_fbu + align_up((size_t)q.fb.n_chunks * q.fb.nrep_pad * (K + 1) * sizeof(double), 256);
+  L.stride = L.s_stats + align_up((size_t)cdiv(q.ntiles, q.win_tiles < 16 ? q.win_tiles : 16) * 100 * sizeof(double), 256);
+  L.p_wt = 0;
+  L.p_flag = L.p_wt + align_up((size_t)q.nwin * I8_WT_STRIDE * sizeof(double) + 2048, 256);
+  L.p_list = L.p_flag + align_up((size_t)q.nwin * sizeof(uint32_t), 256);
+  L.p_nlist = L.p_list + align_up((size_t)q.nwin * (size_t)(q.win_tiles / q.sub_tiles) * sizeof(uint32_t), 256);
+  L.p_stride = L.p_nlist + 256;
+  b.prep_piv = 0;
+  b.prep_state0 = align_up((size_t)S * (1 + C) * sizeof(double), 256);
+  b.prep_total = b.prep_state0 + (size_t)S * L.p_stride;
+  b.off_tab = 0;
+  b.off_states = align_up((size_t)S * sizeof(txm_state_ptrs), 256);
+  b.off_state0 = b.off_states + align_up((size_t)S * sizeof(I8State), 256);
+  b.off_prep = b.off_state0 + (size_t)S * L.stride;
+  b.total = b.off_prep + align_up(b.prep_total, 256);
+  return b;
+}
+
+// which batched calls take the int8 path: narrow states (C <= 16: the quad-sharing variant of the transposing-read kernel)
+// from order 2 on, with at least one full replicate group per state and windows long enough for the guard's statistics.
+// Measured at BASELINE config 5's work (64e6 samples x 4 observables, order 3, nrep = 100): int8 9.6 ms incl. the pre-pass
+// against 11.5 ms on the power-packed FP64 kernel (gpurun_out/r4_c5_probe.log).
+static bool use_i8_batched(int64_t S, int64_t N, int64_t C, int64_t nrep, int K, int call_path = TXM_PATH_AUTO) {
+  if (!i8_supported(N, C, nrep, K) || i8t_narrow_nq(C, K) == 0) return false;
+  const int ov = call_path != TXM_PATH_AUTO ? call_path : path_override();
+  if (ov == TXM_PATH_FP64) return false;
+  if (ov == TXM_PATH_INT8) return true;
+  // ... and enough samples in the batch to pay for the extra launches (5 states x 4e5 samples x 8 observables, nrep = 70:
+  // 0.85 ms against 0.75 ms on the FP64 kernel; 64 x 1e6 x 4, nrep = 100: 8.1 against 11.6 ms -- gpurun_out/r4_bi8b.log)
+  return K >= 3 && nrep >= 64 && N >= 262144 && S * N >= ((int64_t)1 << 24);
+}
+
+__global__ void i8_states_kernel(const txm_state_ptrs *__restrict__ tab, int64_t S, unsigned char *base, unsigned char *pbase,
+                                 I8StateLayout L, const double *piv, int64_t C, const uint32_t *counts, int64_t nrep, int64_t ntiles,
+                                 double *out, int K, uint32_t rep_base, I8State *__restrict__ states) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  unsigned char *b = base + (size_t)s * L.stride, *pb = pbase + (size_t)s * L.p_stride;
+  I8State e;
+  e.x = tab[s].x; e.u = tab[s].u; e.w = tab[s].w;
+  e.pivot = piv + s * (1 + C);
+  e.stats = (double *)(b + L.s_stats);
+  e.wtab = (double *)(pb + L.p_wt);
+  e.wflag = (uint32_t *)(pb + L.p_flag);
+  e.list = (uint32_t *)(pb + L.p_list);
+  e.n_list = (uint32_t *)(pb + L.p_nlist);
+  e.part_x = (double *)(b + L.s_px);
+  e.part_u = (double *)(b + L.s_pu);
+  e.fb_x = (double *)(b + L.s_fbx);
+  e.fb_u = (double *)(b + L.s_fbu);
+  e.counts = counts + (size_t)s * nrep * ntiles;
+  e.out = out + (size_t)s * nrep * C * 2 * K;
+  e.rep_base = rep_base + (uint32_t)(s * nrep);
+  e.pad_ = 0;
+  states[s] = e;
+}
+
+static int resample_batched_i8(const txm_state_ptrs *states_host, int64_t S, int64_t ldx_s, int64_t N, int64_t C, int K,
+                               int64_t nrep, bool weighted, const txm_sampler_spec *spec, const uint32_t *counts, double *out,
+                               void *prep, size_t prep_bytes, bool prep_valid, int64_t *info, void *ws, size_t ws_bytes,
+                               hipStream_t st) {
+  const BatchI8Plan b = plan_batched_i8(S, N, C, nrep, K);
+  const I8Plan &q = b.q;
+  if (ws_bytes < b.total) {
+    set_error("resample_vals_batched: workspace too small (%zu < %zu)", ws_bytes, b.total);
+    return TXM_ERR_WORKSPACE;
+  }
+  TXM_REQUIRE(spec->ndat == N && spec->nrep == S * nrep, "resample_vals_batched: the sampler must span S * nrep replicates of N samples");
+  TXM_REQUIRE(spec->rep0 >= 0 && spec->rep0 + spec->nrep <= ((int64_t)1 << 32), "resample_vals_batched: sampler replicates outside [0, 2^32)");
+  TXM_REQUIRE((int64_t)b.n_chunks * q.n_rbg < ((int64_t)1 << 31) && S <= 65535, "resample_vals_batched: grid too large");
+  txm_state_ptrs *tab = (txm_state_ptrs *)((char *)ws + b.off_tab);
+  TXM_HIP(hipMemcpyAsync(tab, states_host, (size_t)S * sizeof(txm_state_ptrs), hipMemcpyHostToDevice, st));
+  // the pre-pass block (pivots, window tables, guard flags, fallback lists of the S states): the caller's persistent buffer
+  // (reused when prep_valid) or scratch in ws
+  unsigned char *pb = (unsigned char *)ws + b.off_prep;
+  bool have_tables = false;
+  if (prep != nullptr) {
+    if (prep_bytes < b.prep_total) {
+      set_error("resample_vals_batched: prep buffer too small (%zu < %zu)", prep_bytes, b.prep_total);
+      return TXM_ERR_WORKSPACE;
+    }
+    pb = (unsigned char *)prep;
+    have_tables = prep_valid;
+  }
+  double *piv = (double *)(pb + b.prep_piv);
+  if (!have_tables) {
+    hipLaunchKernelGGL(pivot_batch_kernel, dim3((unsigned)(1 + C), (unsigned)S), dim3(256), 0, st, tab, ldx_s, N, C, piv);
+    TXM_LAUNCH_CHECK();
+  }
+  I8State *states = (I8State *)((char *)ws + b.off_states);
+  hipLaunchKernelGGL(i8_states_kernel, dim3((unsigned)cdiv(S, 64)), dim3(64), 0, st, tab, S, (unsigned char *)ws + b.off_state0,
+                     pb + b.prep_state0, b.L, piv, C, counts, nrep, q.ntiles, out, K, (uint32_t)spec->rep0, states);
+  TXM_LAUNCH_CHECK();
+  bool vec_ok = ldx_s % 2 == 0;
+  for (int64_t s = 0; s < S; ++s) vec_ok = vec_ok && (reinterpret_cast<uintptr_t>(states_host[s].x) & 15) == 0;
+  I8Args a;
+  a.states = states;
+  a.S = S;
+  a.x = vec_ok ? states_host[0].x : reinterpret_cast<const double *>((uintptr_t)8);  // (the pre-pass reads its alignment only)
+  a.ldx_s = ldx_s; a.u = states_host[0].u; a.w = states_host[0].w; a.N = N; a.C = C; a.nrep = nrep;
+  a.col0 = 0; a.C_call = C;
+  a.counts = counts;
+  a.k0 = (uint32_t)spec->seed;
+  a.k1 = (uint32_t)(spec->seed >> 32);
+  a.rep_base = (uint32_t)spec->rep0;
+  a.ntiles = q.ntiles;
+  a.last_tile_size = (uint32_t)(N - (q.ntiles - 1) * SM_T);
+  a.pivot = piv; a.wtab = nullptr; a.stats = nullptr; a.nwin = q.nwin;
+  a.part_x = nullptr; a.cpad = b.cpad; a.part_u = nullptr;
+  a.y = nullptr; a.ldy_s = 0; a.ypivot = nullptr; a.ywtab = nullptr; a.yflag = nullptr; a.part_y = nullptr;
+  a.n_chunks = b.n_chunks; a.n_rbg = q.n_rbg; a.tiles_per_chunk = b.tiles_per_chunk; a.win_tiles = q.win_tiles;
+  a.nrep_pad = q.nrep_pad;
+  a.wflag = nullptr; a.list = nullptr; a.n_list = nullptr; a.sub_tiles = q.sub_tiles;
+  a.progress = nullptr;
+  int rc = have_tables ? TXM_OK : launch_i8_prepass(a, K, st);
+  if (rc != TXM_OK) return rc;
+  rc = launch_resample_i8t(a, K, weighted, 0, st);
+  if (rc != TXM_OK) return rc;
+  // the windows the precision guard flags, state by state on grid axis z (a state with an empty list: its blocks exit)
+  ResampleArgs f;
+  f.x = states_host[0].x; f.ldx_s = ldx_s; f.u = states_host[0].u; f.w = states_host[0].w; f.N = N; f.C = C; f.nrep = nrep;
+  f.freq = nullptr; f.counts = counts;
+  f.k0 = a.k0; f.k1 = a.k1; f.rep_base = a.rep_base;
+  f.ntiles = q.ntiles; f.last_tile_size = a.last_tile_size;
+  f.pivot = piv; f.part_x = nullptr; f.part_u = nullptr;
+  f.n_chunks = q.fb.n_chunks; f.n_rbg = q.fb.n_rbg; f.tiles_per_chunk = q.fb.tiles_per_chunk;
+  f.nrep_pad = q.fb.nrep_pad; f.C_pad = q.fb.C_pad;
+  f.list = nullptr; f.n_list = nullptr; f.sub_tiles = q.sub_tiles; f.col_off = 0; f.batch = nullptr; f.progress = nullptr;
+  f.i8states = states;
+  TXM_REQUIRE(q.fb.nrep_pad == q.nrep_pad, "resample_vals_batched: replicate padding of the two kernels differs");
+  rc = run_listed(f, q.fb, K, weighted, st, S);
+  if (rc != TXM_OK) return rc;
+#define TXM_I8_BFIN2(KK, CP)                                                                                        \
+  hipLaunchKernelGGL((resample_finalize_i8_kernel<KK, CP>), dim3((unsigned)nrep, (unsigned)S), dim3(256), 0, st, nullptr, \
+                     nullptr, q.nwin, nullptr, q.nrep_pad, nrep, C, nullptr, nullptr, (int64_t)0, C, nullptr, nullptr,      \
+                     q.fb.n_chunks, q.fb.C_pad, nullptr, states)
+#define TXM_I8_BFIN(KK)                                  \
+  do {                                                   \
+    if (b.cpad == 16) TXM_I8_BFIN2(KK, 16);              \
+    else if (b.cpad == 8) TXM_I8_BFIN2(KK, 8);           \
+    else TXM_I8_BFIN2(KK, 4);                            \
+  } while (0)
+  switch (K) {
+    case 2: TXM_I8_BFIN(2); break;
+    case 3: TXM_I8_BFIN(3); break;
+    case 4: TXM_I8_BFIN(4); break;
+    case 5: TXM_I8_BFIN(5); break;
+    case 6: TXM_I8_BFIN(6); break;
+    case 7: TXM_I8_BFIN(7); break;
+    default: TXM_I8_BFIN(8); break;
+  }
+#undef TXM_I8_BFIN
+#undef TXM_I8_BFIN2
+  TXM_LAUNCH_CHECK();
+  if (info != nullptr) {
+    hipLaunchKernelGGL(i8_info_kernel, dim3(1), dim3(64), 0, st, pb + b.prep_state0, b.L.p_stride, b.L.p_nlist, (int)S, q.nwin,
+                       have_tables ? 1 : 0, info);
+    TXM_LAUNCH_CHECK();
+  }
+  return TXM_OK;
+}
+}  // namespace txm
+
 extern "C" size_t txm_resample_vals_batched_ws_bytes(int64_t S, int64_t N, int64_t C, int64_t nrep, int order) {
   if (S < 1 || N < 1 || C < 1 || nrep < 1 || order < 0 || order > TXM_MAX_ORDER) return 0;
-  return plan_batched(S, N, C, nrep, order + 1).total;
+  // (the larger of the two paths: which one a call takes may be forced per process, txm_set_resample_path)
+  const size_t f = plan_batched(S, N, C, nrep, order + 1).total;
+  if (!i8_supported(N, C, nrep, order + 1) || i8t_narrow_nq(C, order + 1) == 0) return f;
+  const size_t i = plan_batched_i8(S, N, C, nrep, order + 1).total;
+  return i > f ? i : f;
+}
+
+extern "C" size_t txm_resample_batched_prep_bytes(int64_t S, int64_t N, int64_t C, int64_t nrep, int order) {
+  if (S < 1 || N < 1 || C < 1 || nrep < 1 || order < 0 || order > TXM_MAX_ORDER) return 0;
+  if (!i8_supported(N, C, nrep, order + 1) || i8t_narrow_nq(C, order + 1) == 0) return 0;
+  return plan_batched_i8(S, N, C, nrep, order + 1).prep_total;
 }
 
 extern "C" int txm_resample_vals_batched(const txm_state_ptrs *states_host, int64_t S, int64_t ldx_s, int64_t N,
                                          int64_t C, int order, int64_t nrep, const int64_t *freq,
                                          const txm_sampler_spec *spec, const uint32_t *counts, double *out,
                                          void *ws, size_t ws_bytes, txm_stream stream) {
+  return txm_resample_vals_batched_opts(states_host, S, ldx_s, N, C, order, nrep, freq, spec, counts, out, nullptr, ws, ws_bytes,
+                                        stream);
+}
+
+extern "C" int txm_resample_vals_batched_opts(const txm_state_ptrs *states_host, int64_t S, int64_t ldx_s, int64_t N,
+                                              int64_t C, int order, int64_t nrep, const int64_t *freq,
+                                              const txm_sampler_spec *spec, const uint32_t *counts, double *out,
+                                              const txm_resample_opts *opts, void *ws, size_t ws_bytes, txm_stream stream) {
+  const int call_path = opts ? opts->path : TXM_PATH_AUTO;
+  TXM_REQUIRE(call_path == TXM_PATH_AUTO || call_path == TXM_PATH_FP64 || call_path == TXM_PATH_INT8,
+              "resample_vals_batched: opts.path %d is not a path", call_path);
+  TXM_REQUIRE(!(opts && (opts->y || opts->out_y)), "resample_vals_batched: no second sample matrix on the batched entry");
   TXM_REQUIRE(states_host && out && ws, "resample_vals_batched: null pointer");
   TXM_REQUIRE(S >= 1 && S <= 65535 && N >= 1 && C >= 1 && nrep >= 1, "resample_vals_batched: need S, N, C, nrep >= 1");
   TXM_REQUIRE(order >= 0 && order <= TXM_MAX_ORDER, "resample_vals_batched: order %d outside [0, %d]", order, TXM_MAX_ORDER);
@@ -1344,6 +1584,14 @@ extern "C" int txm_resample_vals_batched(const txm_state_ptrs *states_host, int6
     TXM_REQUIRE((states_host[s].w != nullptr) == weighted, "resample_vals_batched: weights for all states or for none");
   }
   const int K = order + 1;
+  if (!explicit_ && use_i8_batched(S, N, C, nrep, K, call_path))
+    return resample_batched_i8(states_host, S, ldx_s, N, C, K, nrep, weighted, spec, counts, out, opts ? opts->prep : nullptr,
+                               opts ? opts->prep_bytes : 0, opts && opts->prep_valid != 0, opts ? opts->info : nullptr, ws, ws_bytes,
+                               (hipStream_t)stream);
+  if (opts && opts->info != nullptr) {
+    hipLaunchKernelGGL(fp64_info_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, opts->info);
+    TXM_LAUNCH_CHECK();
+  }
   const BatchPlan b = plan_batched(S, N, C, nrep, K);
   if (ws_bytes < b.total) {
     set_error("resample_vals_batched: workspace too small (%zu < %zu)", ws_bytes, b.total);

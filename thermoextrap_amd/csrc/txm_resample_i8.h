@@ -25,7 +25,28 @@ constexpr double I8_GUARD = 275.0;  // 1e-13 / (0.41 * 2^-50)
 //   [44 + c]     descale of column c     = max|x_c - px_c| * 2^-50
 constexpr int I8_WT_INVDU = 0, I8_WT_INVW = 1, I8_WT_DSP = 2, I8_WT_SC = 12, I8_WT_DSC = 44;
 
+// S state points of one shape in one set of launches (txm_resample_vals_batched on the int8 path): every kernel of the
+// path takes the state from a grid axis and its operands from this table (device memory, filled by the host per call).
+// Everything a single-state call derives from its arguments sits here per state, so a batched call and S single calls
+// run the same arithmetic on the same partial-sum slots: bit for bit the same moments.
+struct I8State {
+  const double *x, *u, *w;
+  const double *pivot;     // [1 + C]
+  double *stats;           // pre-pass scratch of this state
+  double *wtab;            // [nwin][I8_WT_STRIDE]
+  uint32_t *wflag;         // [nwin]
+  uint32_t *list, *n_list; // FP64 fallback runs of this state
+  double *part_x, *part_u; // int8 partial sums (per window)
+  double *fb_x, *fb_u;     // FP64 fallback partial sums (per chunk)
+  const uint32_t *counts;  // [nrep][ntiles] rows of this state
+  double *out;             // [nrep][C][2][K]
+  uint32_t rep_base;       // stream replicate of the state's replicate 0
+  uint32_t pad_;
+};
+
 struct I8Args {
+  const I8State *states = nullptr;  // batched launch: state blockIdx.y (narrow-state kernels only); nullptr: one state
+  int64_t S = 1;
   const double *x;
   int64_t ldx_s;
   const double *u;
@@ -78,7 +99,7 @@ constexpr int I8_THROTTLE_SPINS = 48;
 // true when the int8 path can take this problem (device-sampler mode only)
 bool i8_supported(int64_t N, int64_t C, int64_t nrep, int K);
 // the pre-pass (window table, guard flags, fallback list) and the bootstrap kernel; partial sums land in part_x/part_u
-int launch_i8_prepass(const I8Args &a, int K, hipStream_t st);
+int launch_i8_prepass(const I8Args &a, int K, hipStream_t st);  // (a.states: S states, the pointers of a ignored)
 int launch_resample_i8(const I8Args &a, int K, bool weighted, size_t prog_bytes, hipStream_t st);
 // the same contraction with the B operands built by the LDS transposing read (txm_resample_i8t.hip): one power per
 // observable column, every order the int8 path serves

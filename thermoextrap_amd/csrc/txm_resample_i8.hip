@@ -44,7 +44,11 @@ __global__ __launch_bounds__(256) void i8_stats_kernel(const double *__restrict_
                                                        const double *__restrict__ w, int64_t N, int64_t C,
                                                        int64_t col0, int64_t sub_samples, int fine_groups,
                                                        const double *__restrict__ pivot, int J,
-                                                       double *__restrict__ stats) {
+                                                       double *__restrict__ stats, const I8State *__restrict__ states) {
+  if (states != nullptr) {  // batched: state blockIdx.y
+    const I8State e = states[blockIdx.y];
+    x = e.x; u = e.u; w = e.w; pivot = e.pivot; stats = e.stats;
+  }
   // thread = (column pair cp, row phase r): 16 lanes read one 256-byte row with 16-byte loads
   const int64_t sb = blockIdx.x;
   const int64_t i0 = sb * sub_samples;
@@ -225,7 +229,11 @@ __global__ __launch_bounds__(256) void i8_stats_kernel(const double *__restrict_
 __global__ __launch_bounds__(64) void i8_table_kernel(const double *__restrict__ stats, int nsub, int64_t nsub_total,
                                                       int64_t N, int64_t C, int64_t win_samples, bool weighted,
                                                       int J, double *__restrict__ wtab,
-                                                      uint32_t *__restrict__ wflag) {
+                                                      uint32_t *__restrict__ wflag, const I8State *__restrict__ states) {
+  if (states != nullptr) {
+    const I8State e = states[blockIdx.y];
+    stats = e.stats; wtab = e.wtab; wflag = e.wflag;
+  }
   const int64_t win = blockIdx.x;
   const int tid = threadIdx.x;
   const int64_t i0 = win * win_samples;
@@ -281,7 +289,11 @@ __global__ __launch_bounds__(64) void i8_table_kernel(const double *__restrict__
 __global__ __launch_bounds__(256) void i8_list_kernel(const uint32_t *__restrict__ wflag, int64_t nwin,
                                                       int64_t win_tiles, int sub_tiles,
                                                       uint32_t *__restrict__ list,
-                                                      uint32_t *__restrict__ n_list) {
+                                                      uint32_t *__restrict__ n_list, const I8State *__restrict__ states) {
+  if (states != nullptr) {  // one block per state
+    const I8State e = states[blockIdx.x];
+    wflag = e.wflag; list = e.list; n_list = e.n_list;
+  }
   __shared__ uint32_t sh[256];
   __shared__ uint32_t running;
   const int tid = threadIdx.x;
@@ -330,16 +342,18 @@ int launch_i8_prepass(const I8Args &a, int K, hipStream_t st) {
   const int64_t sub_tiles = a.win_tiles < I8_STAT_TILES ? a.win_tiles : I8_STAT_TILES;
   const int nsub = (int)(a.win_tiles / sub_tiles);
   const int64_t nsub_total = cdiv(a.ntiles, sub_tiles);
+  // (batched: a.x is the host's word for "16-byte loads are fine for every state")
   const bool vec2 = ((reinterpret_cast<uintptr_t>(a.x + a.col0) & 15) == 0) && (a.ldx_s % 2 == 0);
+  const unsigned S = (unsigned)a.S;
   if (vec2)
-    hipLaunchKernelGGL(i8_stats_kernel<true>, dim3((unsigned)nsub_total), dim3(256), 0, st, a.x, a.ldx_s, a.u, a.w,
-                       a.N, a.C, a.col0, sub_tiles * SM_T, nsub == 1 ? 1 : 0, a.pivot, K - 1, a.stats);
+    hipLaunchKernelGGL(i8_stats_kernel<true>, dim3((unsigned)nsub_total, S), dim3(256), 0, st, a.x, a.ldx_s, a.u, a.w,
+                       a.N, a.C, a.col0, sub_tiles * SM_T, nsub == 1 ? 1 : 0, a.pivot, K - 1, a.stats, a.states);
   else
-    hipLaunchKernelGGL(i8_stats_kernel<false>, dim3((unsigned)nsub_total), dim3(256), 0, st, a.x, a.ldx_s, a.u, a.w,
-                       a.N, a.C, a.col0, sub_tiles * SM_T, nsub == 1 ? 1 : 0, a.pivot, K - 1, a.stats);
+    hipLaunchKernelGGL(i8_stats_kernel<false>, dim3((unsigned)nsub_total, S), dim3(256), 0, st, a.x, a.ldx_s, a.u, a.w,
+                       a.N, a.C, a.col0, sub_tiles * SM_T, nsub == 1 ? 1 : 0, a.pivot, K - 1, a.stats, a.states);
   TXM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(i8_table_kernel, dim3((unsigned)a.nwin), dim3(64), 0, st, a.stats, nsub, nsub_total, a.N, a.C,
-                     a.win_tiles * SM_T, a.w != nullptr, K - 1, a.wtab, a.wflag);
+  hipLaunchKernelGGL(i8_table_kernel, dim3((unsigned)a.nwin, S), dim3(64), 0, st, a.stats, nsub, nsub_total, a.N, a.C,
+                     a.win_tiles * SM_T, a.w != nullptr, K - 1, a.wtab, a.wflag, a.states);
   TXM_LAUNCH_CHECK();
   if (a.y != nullptr) {
     // the second matrix: its own column scales (order-0 monomial w dy), its guard flags OR-ed into the call's -- a
@@ -347,20 +361,20 @@ int launch_i8_prepass(const I8Args &a, int K, hipStream_t st) {
     const bool vy = ((reinterpret_cast<uintptr_t>(a.y + a.col0) & 15) == 0) && (a.ldy_s % 2 == 0);
     if (vy)
       hipLaunchKernelGGL(i8_stats_kernel<true>, dim3((unsigned)nsub_total), dim3(256), 0, st, a.y, a.ldy_s, a.u, a.w,
-                         a.N, a.C, a.col0, sub_tiles * SM_T, nsub == 1 ? 1 : 0, a.ypivot, 0, a.stats);
+                         a.N, a.C, a.col0, sub_tiles * SM_T, nsub == 1 ? 1 : 0, a.ypivot, 0, a.stats, nullptr);
     else
       hipLaunchKernelGGL(i8_stats_kernel<false>, dim3((unsigned)nsub_total), dim3(256), 0, st, a.y, a.ldy_s, a.u, a.w,
-                         a.N, a.C, a.col0, sub_tiles * SM_T, nsub == 1 ? 1 : 0, a.ypivot, 0, a.stats);
+                         a.N, a.C, a.col0, sub_tiles * SM_T, nsub == 1 ? 1 : 0, a.ypivot, 0, a.stats, nullptr);
     TXM_LAUNCH_CHECK();
     hipLaunchKernelGGL(i8_table_kernel, dim3((unsigned)a.nwin), dim3(64), 0, st, a.stats, nsub, nsub_total, a.N, a.C,
-                       a.win_tiles * SM_T, a.w != nullptr, 0, a.ywtab, a.yflag);
+                       a.win_tiles * SM_T, a.w != nullptr, 0, a.ywtab, a.yflag, nullptr);
     TXM_LAUNCH_CHECK();
     hipLaunchKernelGGL(i8_or_flags_kernel, dim3((unsigned)cdiv(a.nwin, 256)), dim3(256), 0, st, a.wflag, a.yflag, a.nwin);
     TXM_LAUNCH_CHECK();
   }
-  TXM_HIP(hipMemsetAsync(a.n_list, 0, 256, st));
-  hipLaunchKernelGGL(i8_list_kernel, dim3(1), dim3(256), 0, st, a.wflag, a.nwin, a.win_tiles, a.sub_tiles, a.list,
-                     a.n_list);
+  if (a.states == nullptr) TXM_HIP(hipMemsetAsync(a.n_list, 0, 256, st));  // (batched: the caller clears the states' words)
+  hipLaunchKernelGGL(i8_list_kernel, dim3(S), dim3(256), 0, st, a.wflag, a.nwin, a.win_tiles, a.sub_tiles, a.list,
+                     a.n_list, a.states);
   TXM_LAUNCH_CHECK();
   return TXM_OK;
 }

@@ -77,8 +77,21 @@ constexpr int T_PLANE = 512, T_PB = 2 * T_PLANE + 128;  // bytes per (wave, powe
 // GS = 8 / NQ) -- ceil(JN / GS) row sets per wave instead of JN, every MFMA column in use, all orders in one pass.
 // The u-row tiles go to the last waves (the ones with the fewest power rows).
 template <int J0, int JN, bool WEIGHTED, bool YS = false, int NQ = 8>
-__global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void resample_i8t_kernel(const I8Args a, const int K) {
+__global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void resample_i8t_kernel(const I8Args a_in, const int K) {
   static_assert(NQ == 8 || NQ == 4 || NQ == 2 || NQ == 1, "column quads");
+  // batched launch (narrow states only): state blockIdx.y, its operands from the table
+  auto state_args = [&]() {
+    I8Args r = a_in;
+    if constexpr (NQ < 8) {
+      if (a_in.states != nullptr) {
+        const I8State e = a_in.states[blockIdx.y];
+        r.x = e.x; r.u = e.u; r.w = e.w; r.pivot = e.pivot; r.wtab = e.wtab; r.wflag = e.wflag;
+        r.part_x = e.part_x; r.part_u = e.part_u; r.counts = e.counts; r.rep_base = e.rep_base;
+      }
+    }
+    return r;
+  };
+  const I8Args a = state_args();
   constexpr int GS = 8 / NQ;                  // waves per column quad = stride of a wave's powers
   constexpr int NSW = (JN + GS - 1) / GS;     // power row sets per wave
   static_assert(JN >= 1 && NSW + (YS ? 1 : 0) <= 5 && J0 + JN <= 8, "power range");
@@ -611,7 +624,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 template <int J0, int JN, bool WEIGHTED, bool YS = false, int NQ = 8>
 static int launch_pass_t(const I8Args &a, int K, size_t prog_bytes, hipStream_t st) {
   if (a.progress != nullptr) TXM_HIP(hipMemsetAsync(a.progress, 0, prog_bytes, st));
-  const dim3 grid((unsigned)(a.n_chunks * a.n_rbg)), block(T_BLOCK);
+  const dim3 grid((unsigned)(a.n_chunks * a.n_rbg), (unsigned)(NQ < 8 ? a.S : 1)), block(T_BLOCK);
   constexpr int gs = 8 / NQ, ns = (JN + gs - 1) / gs + (YS ? 1 : 0), npt = JN + ((YS && WEIGHTED && J0 > 0) ? 1 : 0);
   const size_t lds = (size_t)T_WAVES * (ns + 1) * T_PB + T_CNT_BYTES + 3u * I8_REPS * sizeof(uint32_t) +
                      (size_t)npt * (SM_T + (T_PUNIT == 16 ? 0 : 1)) * sizeof(double);

@@ -427,11 +427,18 @@ def reduce_vals_batched(xs, us, order: int, ws=None) -> torch.Tensor:
 
 
 def resample_vals_batched(xs, us, order: int, *, nrep: int, sampler: DeviceSampler | None = None,
-                          freq: torch.Tensor | None = None, ws=None) -> torch.Tensor:
-    """Bootstrap of S state points of one shape in one launch per kernel (txm_resample_vals_batched):
+                          freq: torch.Tensor | None = None, ws=None, path: str | None = None,
+                          prep: ResamplePrep | None = None) -> torch.Tensor:
+    """Bootstrap of S state points of one shape in one launch per kernel (txm_resample_vals_batched_opts):
     (S, nrep, C, 2, K).  `sampler`: ONE DeviceSampler over S * nrep replicates of N samples (state s owns
-    replicates s * nrep ...), or `freq`: (S * nrep, N) explicit counts."""
+    replicates s * nrep ...), or `freq`: (S * nrep, N) explicit counts.
+
+    Narrow states (C <= 16) take the int8 path with the state on a grid axis of every kernel of it -- state s of the
+    result is, bit for bit, the single call on state s with ``rep0 + s * nrep``.  ``path``: "fp64" / "int8" for THIS call
+    (None: the forced_path() context, else the library's rule).  ``prep``: a ResamplePrep the caller keeps next to the
+    collection -- the int8 path's pre-pass over the S states is then computed once (keyed on the callers' tensors)."""
     L = _L()
+    src = (tuple(xs), tuple(us), None if ws is None else tuple(ws))
     tab, keep, S, N, C = _state_table(xs, us, ws)
     if (freq is None) == (sampler is None):
         raise ValueError("give exactly one of freq= or sampler=")
@@ -445,11 +452,44 @@ def resample_vals_batched(xs, us, order: int, *, nrep: int, sampler: DeviceSampl
             raise ValueError(f"the sampler must span {S} x {nrep} replicates of {N} samples")
         spec_p, counts_p = ct.byref(sampler.spec), _ptr(sampler.counts)
     out = torch.empty((S, nrep, C, 2, order + 1), dtype=F64, device="cuda")
+    opts = _lib.ResampleOpts()
+    opts.path = _call_path(path)
+    key = None
+    if prep is not None and freq is None:
+        nb = L.txm_resample_batched_prep_bytes(S, N, C, nrep, order)
+        if nb:  # the shape can take the int8 path (whether this call does is the library's decision: an unused block costs nothing)
+            key = (tuple(_tkey(t) for t in src[0]), tuple(_tkey(t) for t in src[1]),
+                   None if src[2] is None else tuple(_tkey(t) for t in src[2]), S, N, C, nrep, order)
+            kept = prep.lookup(key)
+            if kept is not None:  # the operand copies of the call that filled the block
+                tab, keep = kept
+            buf, valid = prep.bind(key, nb)
+            opts.prep, opts.prep_bytes, opts.prep_valid = buf.data_ptr(), buf.numel(), int(valid)
+    ikey = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)  # the words batched_info() reads back
+    info = _last_batched_info.get(ikey)
+    if info is None:
+        info = _last_batched_info[ikey] = torch.zeros(4, dtype=torch.int64, device="cuda")
+    opts.info = info.data_ptr()
     wsb = workspace(L.txm_resample_vals_batched_ws_bytes(S, N, C, nrep, order))
-    check(L.txm_resample_vals_batched(tab, S, C, N, C, order, nrep, _ptr(freq), spec_p, counts_p, _ptr(out), _ptr(wsb),
-                                      wsb.numel(), _stream()), "txm_resample_vals_batched")
+    check(L.txm_resample_vals_batched_opts(tab, S, C, N, C, order, nrep, _ptr(freq), spec_p, counts_p, _ptr(out), ct.byref(opts),
+                                           _ptr(wsb), wsb.numel(), _stream()), "txm_resample_vals_batched_opts")
+    if key is not None:
+        prep.commit(key, refs=src, tensors=(tab, keep))
     del keep
     return out[:, :, 0] if xs[0].dim() == 1 else out
+
+
+_last_batched_info: dict = {}
+
+
+def batched_info() -> dict:
+    """What the last `resample_vals_batched` call on the current stream did (synchronises): {"path", "windows" (scaling
+    windows x states), "windows_fp64" (how many of them the precision guard sent to the FP64 kernel), "prep_reused"}."""
+    info = _last_batched_info.get((torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream))
+    if info is None:
+        return {}
+    v = info.cpu().tolist()
+    return {"path": "int8" if v[0] == 1 else "fp64", "windows": int(v[1]), "windows_fp64": int(v[2]), "prep_reused": bool(v[3])}
 
 
 def resample_path(N: int, C: int, nrep: int, order: int) -> str:

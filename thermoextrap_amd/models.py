@@ -437,8 +437,17 @@ class StateCollection(_Params):
             for a in range(0, S, per):
                 b = min(S, a + per)
                 smp = engine.DeviceSampler(seed, (b - a) * nrep, N, ns, rep0=rep0 + a * nrep)
+                # the int8 path's pre-pass block of this group of states lives with the group's first data object (the
+                # reference caches per data object: data.py:285); its key is the whole group's tensors, so another
+                # collection that merely starts with the same state recomputes it
+                dcache = getattr(self.states[a].data, "_cache", None)
+                prep = None
+                if dcache is not None:
+                    prep = dcache.get("resample_prep_batched")
+                    if prep is None:
+                        prep = dcache["resample_prep_batched"] = engine.ResamplePrep()
                 parts.append(engine.resample_vals_batched(xs[a:b], us[a:b], d0.order, nrep=nrep, sampler=smp,
-                                                          ws=ws[a:b] if ws else None))
+                                                          ws=ws[a:b] if ws else None, prep=prep))
             big = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
         else:
             if spec.get("rep0") or state0:
