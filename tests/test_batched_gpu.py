@@ -347,12 +347,18 @@ def test_batched_prep_block_is_computed_once_and_follows_edits(eng):
 
 
 def test_batched_default_dispatch_rule(eng):
-    """Small batches stay on the FP64 kernel, config-5-sized ones take the int8 path (same numbers either way)."""
-    xs, us, _ = states(2, 300000, 4, 21)
-    smp = eng.DeviceSampler(3, 2 * 64, 300000)
+    """The rule looks at the state's shape only, never at the number of states in the launch: a rank that owns two of a
+    collection's states must take the kernel the one-GPU run takes (bit-for-bit sharding)."""
+    xs, us, _ = states(2, 100000, 4, 21)        # short series: FP64 kernel
+    smp = eng.DeviceSampler(3, 2 * 64, 100000)
     auto = eng.resample_vals_batched(xs, us, 3, nrep=64, sampler=smp)
+    assert eng.batched_info()["path"] == "fp64"
     assert torch.equal(auto, eng.resample_vals_batched(xs, us, 3, nrep=64, sampler=smp, path="fp64"))
-    xs, us, _ = states(17, 1 << 20, 4, 22)
-    smp = eng.DeviceSampler(3, 17 * 64, 1 << 20)
+    xs, us, _ = states(5, 300000, 4, 22)
+    smp = eng.DeviceSampler(3, 5 * 64, 300000)
     auto = eng.resample_vals_batched(xs, us, 3, nrep=64, sampler=smp)
+    assert eng.batched_info()["path"] == "int8"
     assert torch.equal(auto, eng.resample_vals_batched(xs, us, 3, nrep=64, sampler=smp, path="int8"))
+    # the first two states alone (a shard): the same kernel, the same bits
+    part = eng.resample_vals_batched(xs[:2], us[:2], 3, nrep=64, sampler=eng.DeviceSampler(3, 2 * 64, 300000))
+    assert eng.batched_info()["path"] == "int8" and torch.equal(part, auto[:2])

@@ -1405,9 +1405,13 @@ static bool use_i8_batched(int64_t S, int64_t N, int64_t C, int64_t nrep, int K,
   const int ov = call_path != TXM_PATH_AUTO ? call_path : path_override();
   if (ov == TXM_PATH_FP64) return false;
   if (ov == TXM_PATH_INT8) return true;
-  // ... and enough samples in the batch to pay for the extra launches (5 states x 4e5 samples x 8 observables, nrep = 70:
-  // 0.85 ms against 0.75 ms on the FP64 kernel; 64 x 1e6 x 4, nrep = 100: 8.1 against 11.6 ms -- gpurun_out/r4_bi8b.log)
-  return K >= 3 && nrep >= 64 && N >= 262144 && S * N >= ((int64_t)1 << 24);
+  // A rule on the STATE's shape only -- never on how many states share the launch: the states of a collection must take the
+  // same kernel whichever rank (or workspace-bounded group) they are bootstrapped in, or a sharded run would differ from the
+  // one-GPU run in the last bits.  (Small batches are launch-bound either way: 5 states x 4e5 samples x 8 observables,
+  // nrep = 70: 0.85 ms here against 0.75 ms on the FP64 kernel; 64 x 1e6 x 4, nrep = 100: 8.1 against 11.6 ms --
+  // gpurun_out/r4_bi8b.log.)
+  (void)S;
+  return K >= 3 && nrep >= 64 && N >= 262144;
 }
 
 __global__ void i8_states_kernel(const txm_state_ptrs *__restrict__ tab, int64_t S, unsigned char *base, unsigned char *pbase,

@@ -394,6 +394,7 @@ class StateCollection(_Params):
 
     # states per launch of the batched path: the sampler table is [S * nrep][ntiles] and the grid carries the state on z
     _BATCH_MAX_REPS = 1 << 22
+    _BATCH_MAX_WS = 8 << 30   # bytes of library workspace per batched launch
 
     def _resample_batched(self, spec: Mapping, rep_dim=None, state0: int = 0):
         """One sampler over S * nrep replicates, one bootstrap launch, per-state views of the result.
@@ -431,8 +432,13 @@ class StateCollection(_Params):
                 seed = int(cm.validate_rng(spec.get("rng")).integers(0, 2**63 - 1))
             rep0 = int(spec.get("rep0", 0)) + int(state0) * nrep
             ns = 0 if (nsamp is None or nsamp == N) else int(nsamp)
-            # groups of states whose S_g * nrep replicates fit one sampler table / launch
+            # groups of states whose S_g * nrep replicates fit one sampler table / launch ...
             per = max(1, min(S, self._BATCH_MAX_REPS // max(nrep, 1)))
+            # ... and whose workspace stays bounded: on the int8 path every state has its own per-window partial-sum slots
+            # and fallback buffers (75 MB per state at config 5's shape -- a thousand states would ask for 75 GB at once)
+            C_all = int(xs[0].shape[1])
+            ws1 = int(engine._L().txm_resample_vals_batched_ws_bytes(1, N, C_all, nrep, d0.order))
+            per = max(1, min(per, self._BATCH_MAX_WS // max(ws1, 1)))
             parts = []
             for a in range(0, S, per):
                 b = min(S, a + per)
