@@ -173,6 +173,10 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // (static priority for waves 4..7 was measured: +3 % time; nothing to arbitrate without a barrier per k-step)
   const int64_t my_rep = rep0 + lane;
   const bool rep_live = my_rep < a.nrep;
+  // live replicates of this group; <= 32 (a short last group): the stage-3 fill packs several calls of a replicate into one
+  // wave instruction (see the fill)
+  const int64_t live_reps = a.nrep - rep0 < I8_REPS ? a.nrep - rep0 : I8_REPS;
+  const int fill_pack = live_reps <= 8 ? 8 : live_reps <= 16 ? 4 : live_reps <= 32 ? 2 : 1;  // wave-uniform
   const uint32_t rstream = a.rep_base + (uint32_t)my_rep;
   const uint32_t lane4 = (uint32_t)lane * 4u;
   uint32_t fdraws = 0;
@@ -495,7 +499,25 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #ifdef TXM_T_NO_FILL  // ablation build
         if (tsize == 0u) {
 #else
-        if (tsize == (uint32_t)SM_T) {
+        if (tsize == (uint32_t)SM_T && fill_pack > 1) {
+          // a short LAST replicate group (live <= 32 of its 64 lanes: 8 of 64 at nrep = 200): FP = fill_pack lanes share a
+          // replicate and take FP consecutive Philox calls of it -- 1 / FP of the wave instructions of the lane-per-replicate
+          // fill below for the same draws (which lane runs a call of the stream is free; the count words are atomics)
+          const int rp = lane & (I8_REPS / fill_pack - 1), slot = lane / (I8_REPS / fill_pack);
+          const bool plive = rep0 + rp < a.nrep;
+          const uint32_t np = plive ? cnt_cur[rp] : 0u;
+          uint32_t nmx = np;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t hi = (uint32_t)__shfl_xor((int)nmx, o);
+            nmx = hi > nmx ? hi : nmx;
+          }
+          nmx = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmx);
+          const uint32_t rsp = a.rep_base + (uint32_t)(rep0 + rp);
+#pragma unroll 1
+          for (uint32_t c0 = (uint32_t)wave * (uint32_t)fill_pack; c0 * 12u < nmx; c0 += (uint32_t)(T_WAVES * fill_pack))
+            t_fill_call<false>(cntw, a.k0, a.k1, rsp, (uint32_t)t, c0 + (uint32_t)slot, np, (uint32_t)rp * 4u);
+        } else if (tsize == (uint32_t)SM_T) {
 #endif
           // dead lanes (replicates past nrep) draw like the smallest live lane: their columns are never flushed
           uint32_t nmin = rep_live ? n : 0xffffffffu, nmax = rep_live ? n : 0u;

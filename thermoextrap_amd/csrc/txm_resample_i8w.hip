@@ -218,7 +218,7 @@ __global__ __launch_bounds__(W_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
           asm volatile("" ::"v"(lo), "v"(hi));
 #else
           // (M0 = this k-step's store base, set once above; nothing the compiler emits in the k-steps writes M0 --
-          // tools/check_m0.py scans the ISA for it at build time)
+          // tools/check_m0.py scans a --save-temps assembly of this file for any other write of M0)
           asm volatile("ds_write_addtid_b32 %0 offset:%2\n\t"
                        "ds_write_addtid_b32 %1 offset:%3"
                        :

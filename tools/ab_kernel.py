@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""A/B timing of bootstrap-kernel builds: TXM_LIBRARY=<so> python tools/ab_kernel.py [N] [nrep] [order]"""
+"""A/B timing of bootstrap-kernel builds: TXM_LIBRARY=<so> python tools/ab_kernel.py [N] [nrep] [order] [C]"""
 import os, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -9,7 +9,8 @@ from thermoextrap_amd import engine
 from bench import make_data
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20_000_000
 nrep = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-C, order = 32, (int(sys.argv[3]) if len(sys.argv) > 3 else 4)
+order = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+C = int(sys.argv[4]) if len(sys.argv) > 4 else 32
 txa.require_gpu(0)
 x, u = make_data(N, C, 1000, torch)
 s = engine.DeviceSampler(0, nrep, N)
