@@ -173,10 +173,6 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // (static priority for waves 4..7 was measured: +3 % time; nothing to arbitrate without a barrier per k-step)
   const int64_t my_rep = rep0 + lane;
   const bool rep_live = my_rep < a.nrep;
-  // live replicates of this group; <= 32 (a short last group): the stage-3 fill packs several calls of a replicate into one
-  // wave instruction (see the fill)
-  const int64_t live_reps = a.nrep - rep0 < I8_REPS ? a.nrep - rep0 : I8_REPS;
-  const int fill_pack = live_reps <= 8 ? 8 : live_reps <= 16 ? 4 : live_reps <= 32 ? 2 : 1;  // wave-uniform
   const uint32_t rstream = a.rep_base + (uint32_t)my_rep;
   const uint32_t lane4 = (uint32_t)lane * 4u;
   uint32_t fdraws = 0;
@@ -499,6 +495,12 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #ifdef TXM_T_NO_FILL  // ablation build
         if (tsize == 0u) {
 #else
+        // live replicates of this group (re-derived per tile: two scalar registers fewer across the k-steps); <= 32 -- a short
+        // last group -- and the fill packs several calls of a replicate into one wave instruction
+        // (narrow-state instances only: in the wide ones the extra code costs the register allocator 6 more spilled
+        // registers and the north star 0.5 %, same-box A/B -- gpurun_out/r4_pack_ab2.log)
+        const int64_t live_reps = a.nrep - rep0;
+        const int fill_pack = NQ == 8 ? 1 : live_reps <= 8 ? 8 : live_reps <= 16 ? 4 : live_reps <= 32 ? 2 : 1;  // wave-uniform
         if (tsize == (uint32_t)SM_T && fill_pack > 1) {
           // a short LAST replicate group (live <= 32 of its 64 lanes: 8 of 64 at nrep = 200): FP = fill_pack lanes share a
           // replicate and take FP consecutive Philox calls of it -- 1 / FP of the wave instructions of the lane-per-replicate
