@@ -1359,7 +1359,7 @@ struct BatchI8Plan {
   int cpad, n_chunks;
   int64_t tiles_per_chunk;
   I8StateLayout L;
-  size_t off_tab, off_states, off_state0, off_prep, total;
+  size_t off_tab, off_states, off_bargs, off_state0, off_prep, total;
   size_t prep_piv, prep_state0, prep_total;  // the pre-pass block: pivots [S][1 + C], then the states' tables
 };
 static BatchI8Plan plan_batched_i8(int64_t S, int64_t N, int64_t C, int64_t nrep, int K) {
@@ -1390,7 +1390,8 @@ static BatchI8Plan plan_batched_i8(int64_t S, int64_t N, int64_t C, int64_t nrep
   b.prep_total = b.prep_state0 + (size_t)S * L.p_stride;
   b.off_tab = 0;
   b.off_states = align_up((size_t)S * sizeof(txm_state_ptrs), 256);
-  b.off_state0 = b.off_states + align_up((size_t)S * sizeof(I8State), 256);
+  b.off_bargs = b.off_states + align_up((size_t)S * sizeof(I8State), 256);
+  b.off_state0 = b.off_bargs + align_up((size_t)S * sizeof(I8Args), 256);
   b.off_prep = b.off_state0 + (size_t)S * L.stride;
   b.total = b.off_prep + align_up(b.prep_total, 256);
   return b;
@@ -1437,6 +1438,17 @@ __global__ void i8_states_kernel(const txm_state_ptrs *__restrict__ tab, int64_t
   e.rep_base = rep_base + (uint32_t)(s * nrep);
   e.pad_ = 0;
   states[s] = e;
+}
+
+// the bootstrap kernel's arguments of state s: the call's, with the state's operands
+__global__ void i8_batch_args_kernel(const I8Args base, int64_t S, I8Args *__restrict__ out) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const I8State e = base.states[s];
+  I8Args r = base;
+  r.x = e.x; r.u = e.u; r.w = e.w; r.pivot = e.pivot; r.wtab = e.wtab; r.wflag = e.wflag;
+  r.part_x = e.part_x; r.part_u = e.part_u; r.counts = e.counts; r.rep_base = e.rep_base;
+  out[s] = r;
 }
 
 static int resample_batched_i8(const txm_state_ptrs *states_host, int64_t S, int64_t ldx_s, int64_t N, int64_t C, int K,
@@ -1496,6 +1508,10 @@ static int resample_batched_i8(const txm_state_ptrs *states_host, int64_t S, int
   a.nrep_pad = q.nrep_pad;
   a.wflag = nullptr; a.list = nullptr; a.n_list = nullptr; a.sub_tiles = q.sub_tiles;
   a.progress = nullptr;
+  I8Args *bargs = (I8Args *)((char *)ws + b.off_bargs);
+  hipLaunchKernelGGL(i8_batch_args_kernel, dim3((unsigned)cdiv(S, 64)), dim3(64), 0, st, a, S, bargs);
+  TXM_LAUNCH_CHECK();
+  a.batch_args = bargs;
   int rc = have_tables ? TXM_OK : launch_i8_prepass(a, K, st);
   if (rc != TXM_OK) return rc;
   rc = launch_resample_i8t(a, K, weighted, 0, st);

@@ -44,8 +44,10 @@ struct I8State {
   uint32_t pad_;
 };
 
+struct I8Args;
 struct I8Args {
   const I8State *states = nullptr;  // batched launch: state blockIdx.y (narrow-state kernels only); nullptr: one state
+  const I8Args *batch_args = nullptr;  // ... and the bootstrap kernel's own arguments per state (device array [S], built per call)
   int64_t S = 1;
   const double *x;
   int64_t ldx_s;

@@ -76,22 +76,24 @@ constexpr int T_PLANE = 512, T_PB = 2 * T_PLANE + 128;  // bytes per (wave, powe
 // quad split the powers between them: wave w owns quad w % NQ and the powers g, g + GS, g + 2 GS ... (g = w / NQ,
 // GS = 8 / NQ) -- ceil(JN / GS) row sets per wave instead of JN, every MFMA column in use, all orders in one pass.
 // The u-row tiles go to the last waves (the ones with the fewest power rows).
-template <int J0, int JN, bool WEIGHTED, bool YS = false, int NQ = 8>
+// BATCHED: state blockIdx.y of a batched launch.  A template parameter and not a run-time test: a first version patched a local
+// copy of the arguments from the I8State table behind `if (a.states)`, and that copy cost the SINGLE-state narrow kernel 18 %
+// (config 2: 3.70 vs 3.09 ms per step, same box, gpurun_out/r4_c2_ab3.log) -- its fields live in scalar registers the kernel
+// does not have, where kernel arguments are re-loaded on demand.  The batched instances read a per-state argument block instead.
+template <int J0, int JN, bool WEIGHTED, bool YS = false, int NQ = 8, bool BATCHED = false>
 __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void resample_i8t_kernel(const I8Args a_in, const int K) {
   static_assert(NQ == 8 || NQ == 4 || NQ == 2 || NQ == 1, "column quads");
-  // batched launch (narrow states only): state blockIdx.y, its operands from the table
-  auto state_args = [&]() {
-    I8Args r = a_in;
-    if constexpr (NQ < 8) {
-      if (a_in.states != nullptr) {
-        const I8State e = a_in.states[blockIdx.y];
-        r.x = e.x; r.u = e.u; r.w = e.w; r.pivot = e.pivot; r.wtab = e.wtab; r.wflag = e.wflag;
-        r.part_x = e.part_x; r.part_u = e.part_u; r.counts = e.counts; r.rep_base = e.rep_base;
-      }
-    }
-    return r;
+  static_assert(!BATCHED || NQ < 8, "batched launches: narrow states");
+  // batched launch (narrow states only): state blockIdx.y runs on ITS copy of the arguments in device memory
+  // (I8Args::batch_args: uniform address, read like kernel arguments -- on demand, by scalar loads)
+  // (the constant address space: nothing writes the block while the kernel runs, and that is what lets the compiler take the
+  // fields with scalar loads; as plain global memory they became per-lane vector loads: 9.3 instead of 8.1 ms at config 5)
+  typedef const __attribute__((address_space(4))) I8Args *const_args_p;
+  auto pick_args = [&]() -> decltype(auto) {
+    if constexpr (BATCHED) return (*(const_args_p)(uintptr_t)(a_in.batch_args + blockIdx.y));
+    else return (a_in);
   };
-  const I8Args a = state_args();
+  const auto &a = pick_args();
   constexpr int GS = 8 / NQ;                  // waves per column quad = stride of a wave's powers
   constexpr int NSW = (JN + GS - 1) / GS;     // power row sets per wave
   static_assert(JN >= 1 && NSW + (YS ? 1 : 0) <= 5 && J0 + JN <= 8, "power range");
@@ -648,10 +650,24 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 template <int J0, int JN, bool WEIGHTED, bool YS = false, int NQ = 8>
 static int launch_pass_t(const I8Args &a, int K, size_t prog_bytes, hipStream_t st) {
   if (a.progress != nullptr) TXM_HIP(hipMemsetAsync(a.progress, 0, prog_bytes, st));
-  const dim3 grid((unsigned)(a.n_chunks * a.n_rbg), (unsigned)(NQ < 8 ? a.S : 1)), block(T_BLOCK);
   constexpr int gs = 8 / NQ, ns = (JN + gs - 1) / gs + (YS ? 1 : 0), npt = JN + ((YS && WEIGHTED && J0 > 0) ? 1 : 0);
   const size_t lds = (size_t)T_WAVES * (ns + 1) * T_PB + T_CNT_BYTES + 3u * I8_REPS * sizeof(uint32_t) +
                      (size_t)npt * (SM_T + (T_PUNIT == 16 ? 0 : 1)) * sizeof(double);
+  const dim3 block(T_BLOCK);
+  if constexpr (NQ < 8) {
+    if (a.states != nullptr) {
+      const dim3 grid((unsigned)(a.n_chunks * a.n_rbg), (unsigned)a.S);
+      TXM_SET_MAX_LDS((&resample_i8t_kernel<J0, JN, WEIGHTED, YS, NQ, true>), lds);
+      hipLaunchKernelGGL((resample_i8t_kernel<J0, JN, WEIGHTED, YS, NQ, true>), grid, block, lds, st, a, K);
+      TXM_LAUNCH_CHECK();
+      return TXM_OK;
+    }
+  }
+  if (a.states != nullptr) {
+    set_error("resample_i8t: a batched launch needs narrow states");
+    return TXM_ERR_INVALID;
+  }
+  const dim3 grid((unsigned)(a.n_chunks * a.n_rbg));
   TXM_SET_MAX_LDS((&resample_i8t_kernel<J0, JN, WEIGHTED, YS, NQ>), lds);
   hipLaunchKernelGGL((resample_i8t_kernel<J0, JN, WEIGHTED, YS, NQ>), grid, block, lds, st, a, K);
   TXM_LAUNCH_CHECK();
