@@ -42,13 +42,18 @@ namespace txm {
 // ds_read2_b64 pair and not a multiple of 64 lines (ds_read2st64_b64 would pair them again): two ds_read_b64 (2 LDS
 // cycles each) instead of one paired read (8).  Same-box A/B, round 4: 36.4 -> 35.8 ms at N = 2e7, 165.8 -> 163.2 ms at
 // the north star (-1.6 %); TXM_T_PAIRREAD restores the adjacent layout.
+// (PU = the unit stride in lines: 513, or 545 where a tile stages 33 chunks -- chunk groups, see the kernel)
 #ifndef TXM_T_PAIRREAD
-#define T_PIDX(e) (((((e) >> 4) & 1) * 513) + (((e) >> 5) * 16) + ((e) & 15))
-#define T_PUNIT 513
+#define T_PIDX(e) (((((e) >> 4) & 1) * T_PUNIT) + (((e) >> 5) * 16) + ((e) & 15))
+#define T_PUNIT_OF(cg) ((cg) > 1 ? 545 : 513)
+#define T_PLINES_OF(cg) (T_PUNIT_OF(cg) + ((cg) > 1 ? 33 : 32) * 16)
 #else
 #define T_PIDX(e) (e)
-#define T_PUNIT 16
+#define T_PUNIT_OF(cg) 16
+#define T_PLINES_OF(cg) ((cg) > 1 ? SM_T + 32 : SM_T)
 #endif
+// chunk groups of a launch: 2 for a one-quad state with at most four powers (see the kernel), else 1
+#define T_CG_OF(nq, jn) (((nq) == 1 && (jn) <= 4) ? 2 : 1)
 
 // K = order + 1 is a run-time argument (it only enters the flush addresses); one launch slices the JN powers
 // J0 .. J0 + JN - 1.
@@ -94,7 +99,15 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     else return (a_in);
   };
   const auto &a = pick_args();
-  constexpr int GS = 8 / NQ;                  // waves per column quad = stride of a wave's powers
+  // CG = 2 (one column quad, at most four powers: BASELINE config 5's states): with eight waves on one quad and four powers,
+  // four waves had no row set at all, and the k-steps of such a state are a latency chain per chunk, not work.  The waves form
+  // two CHUNK GROUPS instead: group c = wave / 4 contracts the chunks 16 c .. 16 c + 15 of every tile (its own stream of
+  // 512-sample half tiles: same pipeline, base + 512 c samples), wave & 3 = the power; 16 k-steps per tile and wave instead of
+  // 32.  The two groups' int32 accumulators are added in LDS at the flush (exact, so the sums are those of one group).
+  constexpr int CG = T_CG_OF(NQ, JN);
+  constexpr int T_PUNIT = T_PUNIT_OF(CG);
+  constexpr int STEPS = T_STEPS / CG;            // k-steps (chunks) of a wave per tile
+  constexpr int GS = 8 / NQ / CG;             // waves per column quad and chunk group = stride of a wave's powers
   constexpr int NSW = (JN + GS - 1) / GS;     // power row sets per wave
   static_assert(JN >= 1 && NSW + (YS ? 1 : 0) <= 5 && J0 + JN <= 8, "power range");
   static_assert(NQ == 8 || !YS, "narrow states: no second matrix");
@@ -123,7 +136,9 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // ---- producer role: lane = (sample l >> 2 of a 16-sample unit, column l & 3 of the wave's quad)
   const int ps = lane >> 2, cl = lane & 3;
   const int quad = NQ == 8 ? wave : wave % NQ;  // the wave's column quad
-  const int g = NQ == 8 ? 0 : wave / NQ;        // ... and its first power (relative to J0)
+  const int g = NQ == 8 ? 0 : (wave / NQ) % GS;  // ... and its first power (relative to J0)
+  const int cgrp = CG == 1 ? 0 : wave / (T_WAVES / CG);  // chunk group
+  const int coff = cgrp * STEPS;                         // its first chunk of a tile
   const int col = 4 * quad + cl;
   // row set fi of this wave = power J0 + g + fi GS; past the launch's powers: an idle row set (wave-uniform)
   auto row_live = [&](int fi) { return NQ == 8 || g + fi * GS < JN; };
@@ -138,7 +153,8 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const int tcl = (n32 >> 2) & 3, tdg = 4 * (n32 >> 4) + (n32 & 3);
   // u-row tile of waves 0 .. 2 UF - 1: fragment fu (monomials 4 fu .. 4 fu + 3), replicate half uh
   constexpr int NUT = 2 * UF;
-  const int uw = NQ == 8 ? wave : wave - (T_WAVES - NUT);
+  // (narrow states: the last NUT waves -- of every chunk group)
+  const int uw = NQ == 8 ? wave : (wave % (T_WAVES / CG)) - (T_WAVES / CG - NUT);
   const bool has_ut = uw >= 0 && uw < NUT;  // wave-uniform
   const int fu = has_ut ? (uw >> 1) : 0, uh = uw & 1;
   // A wave with a u-row tile for replicate half 1 takes the halves in swapped order (operand A0 = ITS u-row half, flushed
@@ -465,7 +481,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       // previous tile), zero the count tile, chunk 0 of the first tile
       if (first_tile) {
         if (wave == 0) cnt_cur[lane] = rep_live ? a.counts[(size_t)my_rep * a.ntiles + t] : 0u;
-        set_q(wbase);
+        set_q(wbase + 32 * coff);  // (chunk groups: this group's first chunk of the tile)
         xq_step = 32 * a.ldx_s * 8;
         if constexpr (YS) yq_step = 32 * a.ldy_s * 8;
         load_q(XR[0]);
@@ -473,12 +489,15 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       }
       // staging requests (in flight during the zeroing and the fill): entries 0 .. 991 = samples wbase + 32 ...,
       // entries 992 .. 1023 = the next tile's first chunk
-      double su[2], sw[2] = {1.0, 1.0};
+      // (chunk groups: entries 1024 .. 1055 = the next tile's chunk 16, which the second group slices at its last k-step)
+      constexpr int NSTG = CG > 1 ? 3 : 2;
+      double su[NSTG], sw[NSTG];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < NSTG; ++q) {
         const int e = (int)threadIdx.x + q * T_BLOCK;
-        const int64_t i = e < SM_T - 32 ? wbase + 32 + e : wnext + (e - (SM_T - 32));
+        const int64_t i = e < SM_T - 32 ? wbase + 32 + e : e < SM_T ? wnext + (e - (SM_T - 32)) : wnext + SM_T / 2 + ((e - SM_T) & 31);
         su[q] = a.u[i];
+        sw[q] = 1.0;
         if constexpr (WEIGHTED) sw[q] = a.w[i];
       }
       uint32_t ncnt = 0;
@@ -563,8 +582,8 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         double d_du[2], d_w[2] = {1.0, 1.0};
 #pragma unroll
         for (int uu = 0; uu < 2; ++uu) {
-          d_du[uu] = (a.u[wbase + 16 * uu + ps] - pu) * inv_du;
-          if constexpr (WEIGHTED) d_w[uu] = a.w[wbase + 16 * uu + ps] * inv_w;
+          d_du[uu] = (a.u[wbase + 32 * coff + 16 * uu + ps] - pu) * inv_du;
+          if constexpr (WEIGHTED) d_w[uu] = a.w[wbase + 32 * coff + 16 * uu + ps] * inv_w;
         }
         kstep(YES, NO, 0, XR[0], -1, d_du, d_w);
 #pragma unroll
@@ -576,8 +595,9 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       }
       // park the staged tiles
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < NSTG; ++q) {
         const int e = (int)threadIdx.x + q * T_BLOCK;
+        if (q == 2 && e >= SM_T + 32) continue;  // (only 32 entries of the third round exist)
         const double du = (su[q] - pu) * inv_du;
         double pw = WEIGHTED ? sw[q] * inv_w : 1.0;
         if constexpr (NPT > JN) ptile[T_PIDX(e) * NPT + JN] = pw;  // plain w for the y row set
@@ -598,20 +618,23 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       // the ring slot (s + 1) % XD (x requested XD steps ago) and requests chunk s + 1 + XD into that slot.
       // Chunk 32 is the next tile's chunk 0 (words nobody reads when there is no next tile).
 #pragma unroll 1
-      for (int s = 0; s < T_STEPS; s += UNR) {
+      for (int s = 0; s < STEPS; s += UNR) {
 #pragma unroll
         for (int e = 0; e < UNR; ++e) {
-          const int sq = s + e;
+          const int sq = s + e;   // k-step of this wave; its chunk of the tile: coff + sq
           XIn &R = XR[(e + 1) % XD];
           const XIn cur_x = R;
-          load_q(R);  // chunk sq + 1 + XD
-          // the request after chunk 31 is the next tile's chunk 0 (not adjacent when that tile is the slid last one);
-          // no next tile: chunk 31 again, words nobody reads
-          if ((T_STEPS - 2 - XD - e) % UNR == 0 && s == T_STEPS - 2 - XD - e) {
-            if (has_next) set_q(wnext);
+          load_q(R);  // chunk sq + 1 + XD of the wave's stream
+          // the request after the group's last chunk is the next tile's first chunk of the group (not adjacent when that tile
+          // is the slid last one); no next tile: the last chunk again, words nobody reads
+          if ((STEPS - 2 - XD - e) % UNR == 0 && s == STEPS - 2 - XD - e) {
+            if (has_next) set_q(wnext + 32 * coff);
             else { xq_step = 0; yq_step = 0; }
           } else step_q();
-          kstep(YES, YES, sq, cur_x, sq * 32, no_d, no_w);
+          // entry of the sliced chunk in the staged tiles: the next chunk of the tile, or -- last k-step -- the next tile's
+          // first chunk of the group (entries 992 .. for chunk 0, 1024 .. for chunk 16)
+          const int e0 = (CG > 1 && sq == STEPS - 1) ? (cgrp ? SM_T : SM_T - 32) : (coff + sq) * 32;
+          kstep(YES, YES, coff + sq, cur_x, e0, no_d, no_w);
           T_TICK(5);
         }
       }
@@ -627,12 +650,39 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (wave == 0) fsum[lane] = fdraws;
     fdraws = 0;
     __syncthreads();
+    if constexpr (CG > 1) {
+      // chunk groups: the second group hands its int32 accumulators to the first through the (now idle) count tile; the sums
+      // are exact, so what is flushed is what one group contracting all 32 chunks would have flushed
+      static_assert(NS == 1, "chunk groups: one row set per wave");
+      uint32_t *xch = cntw + (size_t)((wave & 3) * 3) * 16 * 64 + lane;
+      if (cgrp == 1) {
 #pragma unroll
-    for (int fi = 0; fi < NS; ++fi) {
-      flush_tile(acc[fi][0], hswap, fi, -1);
-      flush_tile(acc[fi][1], 1 - hswap, fi, -1);
+        for (int r = 0; r < 16; ++r) {
+          xch[(0 * 16 + r) * 64] = (uint32_t)acc[0][0][r];
+          xch[(1 * 16 + r) * 64] = (uint32_t)acc[0][1][r];
+          if (has_ut) xch[(2 * 16 + r) * 64] = (uint32_t)accu[r];
+        }
+        acc[0][0] = acc[0][1] = (v16i)(0);
+        accu = (v16i)(0);
+      }
+      __syncthreads();
+      if (cgrp == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc[0][0][r] += (int)xch[(0 * 16 + r) * 64];
+          acc[0][1][r] += (int)xch[(1 * 16 + r) * 64];
+          if (has_ut) accu[r] += (int)xch[(2 * 16 + r) * 64];
+        }
+      }
     }
-    if (has_ut) flush_tile(accu, uh, 0, fu);  // wave-uniform
+    if (CG == 1 || cgrp == 0) {  // wave-uniform
+#pragma unroll
+      for (int fi = 0; fi < NS; ++fi) {
+        flush_tile(acc[fi][0], hswap, fi, -1);
+        flush_tile(acc[fi][1], 1 - hswap, fi, -1);
+      }
+      if (has_ut) flush_tile(accu, uh, 0, fu);  // wave-uniform
+    }
     accu = (v16i)(0);
     __syncthreads();  // fsum is rewritten by the next window
     T_TICK(7);
@@ -652,7 +702,7 @@ static int launch_pass_t(const I8Args &a, int K, size_t prog_bytes, hipStream_t 
   if (a.progress != nullptr) TXM_HIP(hipMemsetAsync(a.progress, 0, prog_bytes, st));
   constexpr int gs = 8 / NQ, ns = (JN + gs - 1) / gs + (YS ? 1 : 0), npt = JN + ((YS && WEIGHTED && J0 > 0) ? 1 : 0);
   const size_t lds = (size_t)T_WAVES * (ns + 1) * T_PB + T_CNT_BYTES + 3u * I8_REPS * sizeof(uint32_t) +
-                     (size_t)npt * (SM_T + (T_PUNIT == 16 ? 0 : 1)) * sizeof(double);
+                     (size_t)npt * T_PLINES_OF(T_CG_OF(NQ, JN)) * sizeof(double);
   const dim3 block(T_BLOCK);
   if constexpr (NQ < 8) {
     if (a.states != nullptr) {
