@@ -52,8 +52,10 @@ namespace txm {
 #define T_PUNIT_OF(cg) 16
 #define T_PLINES_OF(cg) ((cg) > 1 ? SM_T + 32 : SM_T)
 #endif
-// chunk groups of a launch: 2 for a one-quad state with at most four powers (see the kernel), else 1
-#define T_CG_OF(nq, jn) (((nq) == 1 && (jn) <= 4) ? 2 : 1)
+// chunk groups of a launch: 2 for one-quad states and for two-quad states with at most six powers (see the kernel; with seven
+// the row sets of a wave and the staged tiles of 33 chunks do not fit the LDS, and with four quads a wave of a group would hold
+// every power: six row sets at order 5), else 1
+#define T_CG_OF(nq, jn) (((nq) == 1 || ((nq) == 2 && (jn) <= 6)) ? 2 : 1)
 
 // K = order + 1 is a run-time argument (it only enters the flush addresses); one launch slices the JN powers
 // J0 .. J0 + JN - 1.
@@ -99,11 +101,12 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     else return (a_in);
   };
   const auto &a = pick_args();
-  // CG = 2 (one column quad, at most four powers: BASELINE config 5's states): with eight waves on one quad and four powers,
-  // four waves had no row set at all, and the k-steps of such a state are a latency chain per chunk, not work.  The waves form
-  // two CHUNK GROUPS instead: group c = wave / 4 contracts the chunks 16 c .. 16 c + 15 of every tile (its own stream of
-  // 512-sample half tiles: same pipeline, base + 512 c samples), wave & 3 = the power; 16 k-steps per tile and wave instead of
-  // 32.  The two groups' int32 accumulators are added in LDS at the flush (exact, so the sums are those of one group).
+  // CG = 2 (narrow states): a narrow k-step is a latency chain per chunk, not work -- a wave has one or two row sets, and with
+  // one column quad and four powers (BASELINE config 5's states) four of the eight waves had none at all.  The waves form two
+  // CHUNK GROUPS instead: group c = wave / 4 contracts the chunks 16 c .. 16 c + 15 of every tile (its own stream of 512-sample
+  // half tiles: the same pipeline from base + 512 c samples), its four waves share the quads and the powers as the eight did --
+  // 16 k-steps per tile and wave with twice the row sets instead of 32.  The two groups' int32 accumulators are added through the
+  // idle count tile at the flush (exact, so the sums are those of one group).
   constexpr int CG = T_CG_OF(NQ, JN);
   constexpr int T_PUNIT = T_PUNIT_OF(CG);
   constexpr int STEPS = T_STEPS / CG;            // k-steps (chunks) of a wave per tile
@@ -651,28 +654,34 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     fdraws = 0;
     __syncthreads();
     if constexpr (CG > 1) {
-      // chunk groups: the second group hands its int32 accumulators to the first through the (now idle) count tile; the sums
-      // are exact, so what is flushed is what one group contracting all 32 chunks would have flushed
-      static_assert(NS == 1, "chunk groups: one row set per wave");
-      uint32_t *xch = cntw + (size_t)((wave & 3) * 3) * 16 * 64 + lane;
-      if (cgrp == 1) {
+      // chunk groups: the second group hands its int32 accumulators to the first through the (now idle) count tile, four tiles
+      // per wave and round; the sums are exact, so what is flushed is what one group contracting all 32 chunks would have flushed
+      constexpr int NT = 2 * NS + 1;  // tiles of a wave: NS row sets x 2 replicate halves + the u-row tile
+      uint32_t *xch = cntw + (size_t)((wave & 3) * 4) * 16 * 64 + lane;
+      auto tile_of = [&](int tt) -> v16i & { return tt < 2 * NS ? acc[tt >> 1][tt & 1] : accu; };
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          xch[(0 * 16 + r) * 64] = (uint32_t)acc[0][0][r];
-          xch[(1 * 16 + r) * 64] = (uint32_t)acc[0][1][r];
-          if (has_ut) xch[(2 * 16 + r) * 64] = (uint32_t)accu[r];
-        }
-        acc[0][0] = acc[0][1] = (v16i)(0);
-        accu = (v16i)(0);
-      }
-      __syncthreads();
-      if (cgrp == 0) {
+      for (int t0 = 0; t0 < NT; t0 += 4) {
+        if (cgrp == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          acc[0][0][r] += (int)xch[(0 * 16 + r) * 64];
-          acc[0][1][r] += (int)xch[(1 * 16 + r) * 64];
-          if (has_ut) accu[r] += (int)xch[(2 * 16 + r) * 64];
+          for (int k = 0; k < 4; ++k)
+            if (t0 + k < NT) {
+              v16i &T = tile_of(t0 + k);
+#pragma unroll
+              for (int r = 0; r < 16; ++r) xch[(k * 16 + r) * 64] = (uint32_t)T[r];
+              T = (v16i)(0);
+            }
         }
+        __syncthreads();
+        if (cgrp == 0) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (t0 + k < NT) {
+              v16i &T = tile_of(t0 + k);
+#pragma unroll
+              for (int r = 0; r < 16; ++r) T[r] += (int)xch[(k * 16 + r) * 64];
+            }
+        }
+        if (t0 + 4 < NT) __syncthreads();  // (the next round overwrites the slots)
       }
     }
     if (CG == 1 || cgrp == 0) {  // wave-uniform
@@ -700,7 +709,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 template <int J0, int JN, bool WEIGHTED, bool YS = false, int NQ = 8>
 static int launch_pass_t(const I8Args &a, int K, size_t prog_bytes, hipStream_t st) {
   if (a.progress != nullptr) TXM_HIP(hipMemsetAsync(a.progress, 0, prog_bytes, st));
-  constexpr int gs = 8 / NQ, ns = (JN + gs - 1) / gs + (YS ? 1 : 0), npt = JN + ((YS && WEIGHTED && J0 > 0) ? 1 : 0);
+  constexpr int gs = 8 / NQ / T_CG_OF(NQ, JN), ns = (JN + gs - 1) / gs + (YS ? 1 : 0), npt = JN + ((YS && WEIGHTED && J0 > 0) ? 1 : 0);
   const size_t lds = (size_t)T_WAVES * (ns + 1) * T_PB + T_CNT_BYTES + 3u * I8_REPS * sizeof(uint32_t) +
                      (size_t)npt * T_PLINES_OF(T_CG_OF(NQ, JN)) * sizeof(double);
   const dim3 block(T_BLOCK);
