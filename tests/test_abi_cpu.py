@@ -96,6 +96,15 @@ def test_per_call_entry_points_validate_without_a_device(lib):
     assert 0 < p_small < p_wide                           # one table set per 32-column group
     assert lib.txm_resample_prep_bytes(0, 32, 1000, 4) == 0
     assert lib.txm_resample_vals_ws_bytes(1_000_000, 32, 1000, 4) > p_small
+    # the batched entry's pre-pass block: one for the S states of a narrow collection, none where the int8 path never applies
+    b1 = lib.txm_resample_batched_prep_bytes(1, 1_000_000, 4, 100, 3)
+    b64 = lib.txm_resample_batched_prep_bytes(64, 1_000_000, 4, 100, 3)
+    assert 0 < b1 < b64 <= 64 * b1
+    assert lib.txm_resample_batched_prep_bytes(64, 1_000_000, 32, 100, 3) == 0      # wide states: FP64 kernel only
+    assert lib.txm_resample_batched_prep_bytes(64, 1_000_000, 4, 100, 0) == 0       # order 0: not a narrow-state shape
+    assert lib.txm_resample_batched_prep_bytes(0, 1_000_000, 4, 100, 3) == 0
+    assert lib.txm_resample_vals_batched_ws_bytes(64, 1_000_000, 4, 100, 3) > b64   # scratch of both paths + the block
+    assert lib.txm_resample_vals_batched_opts(None, 1, 4, 1000, 4, 3, 10, None, None, None, None, None, None, 0, None) == -1
 
 
 def test_no_gpu_means_loud_failure_not_fallback(lib):
