@@ -54,6 +54,13 @@ __global__ __launch_bounds__(256) void i8_stats_kernel(const double *__restrict_
   const int64_t i0 = sb * sub_samples;
   const int64_t i1 = (i0 + sub_samples < N) ? i0 + sub_samples : N;
   const int tid = threadIdx.x, cp = tid & 15, r = tid >> 4;
+  // A narrow state fills only cpw = ceil(C / 2) (rounded up to a power of two) of the 16 column-pair lanes of a row.  The other
+  // lanes take other QUARTERS of the sub-block for the same column pairs: lane cp = (column pair cpa = cp % cpw, sub = cp / cpw)
+  // walks the quarters sub, sub + 16 / cpw, ...  Every (quarter, row phase, column pair) is still summed by ONE thread in row
+  // order, so the statistics are bit for bit those of the plain mapping -- 4 x the lanes at C <= 8 (config 5's collection:
+  // 2.99 -> see profiles/r04_experiments.md).
+  const int cpw = C > 16 ? 16 : C > 8 ? 8 : C > 4 ? 4 : C > 2 ? 2 : 1, nsubq = 16 / cpw;
+  const int cpa = cp % cpw, qsub = cp / cpw;
   __shared__ double shq[4][2][256];  // per-thread quarter sums of the two columns
   __shared__ int shqn[4][256];
   __shared__ double shx[2][256], shg[2][256], shu[256], shw[256], shs[256];
@@ -66,17 +73,19 @@ __global__ __launch_bounds__(256) void i8_stats_kernel(const double *__restrict_
   const double kInf = __longlong_as_double(0x7ff0000000000000ll);
   double mx[2] = {0.0, 0.0}, gmin[2] = {kInf, kInf}, mu = 0.0, mw = 0.0;
   bool bx[2] = {false, false}, bu = false;
-  const int c0 = 2 * cp;
+  const int c0 = 2 * cpa;
+  const int slot = r * 16 + cpa;  // where the reductions below look for this (row phase, column pair)
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     shq[g][0][tid] = shq[g][1][tid] = 0.0;
     shqn[g][tid] = 0;
   }
-  if (c0 < C) {
+  __syncthreads();  // (a slot is written below by the lane that walked its quarter, not by the thread that zeroed it)
+  if (c0 < C && qsub < 4) {
     const bool two = c0 + 1 < C;
     const double px0 = pivot[1 + col0 + c0], px1 = two ? pivot[1 + col0 + c0 + 1] : 0.0;
     const int64_t gs = sub_samples / 4;  // rows per quarter (sub_samples is a multiple of 4096)
-    for (int g = 0; g < 4; ++g) {
+    for (int g = qsub; g < 4; g += nsubq) {
       const int64_t ia = i0 + g * gs;
       const int64_t ib = (ia + gs < i1) ? ia + gs : i1;
       double s0 = 0.0, s1 = 0.0;
@@ -125,9 +134,9 @@ __global__ __launch_bounds__(256) void i8_stats_kernel(const double *__restrict_
         load(i, x0, x1, ui, wi);
         body(x0, x1, ui, wi);
       }
-      shq[g][0][tid] = s0;
-      shq[g][1][tid] = s1;
-      shqn[g][tid] = n;
+      shq[g][0][slot] = s0;
+      shq[g][1][slot] = s1;
+      shqn[g][slot] = n;
       if (n > 0) {
         gmin[0] = fmin(gmin[0], s0 / (double)n);
         gmin[1] = fmin(gmin[1], s1 / (double)n);
@@ -210,6 +219,16 @@ __global__ __launch_bounds__(256) void i8_stats_kernel(const double *__restrict_
         }
       }
     }
+    __syncthreads();
+  }
+  if (nsubq > 1) {  // the lanes that shared a column pair (maxima / minima: exact in any order)
+    if (tid < cpw)
+      for (int q = 1; q < nsubq; ++q)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          shx[v][tid] = fmax(shx[v][tid], shx[v][tid + q * cpw]);
+          shg[v][tid] = fmin(shg[v][tid], shg[v][tid + q * cpw]);
+        }
     __syncthreads();
   }
   double *st = stats + sb * I8_ST_STRIDE;
