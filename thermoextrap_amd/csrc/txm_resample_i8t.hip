@@ -52,10 +52,10 @@ namespace txm {
 #define T_PUNIT_OF(cg) 16
 #define T_PLINES_OF(cg) ((cg) > 1 ? SM_T + 32 : SM_T)
 #endif
-// chunk groups of a launch: 2 for one-quad states and for two-quad states with at most six powers (see the kernel; with seven
-// the row sets of a wave and the staged tiles of 33 chunks do not fit the LDS, and with four quads a wave of a group would hold
-// every power: six row sets at order 5), else 1
-#define T_CG_OF(nq, jn) (((nq) == 1 || ((nq) == 2 && (jn) <= 6)) ? 2 : 1)
+// chunk groups of a launch: 2 for one-quad states, for two-quad states with at most six powers and for four-quad states with at
+// most four (see the kernel; beyond that the row sets of a wave and the staged tiles of 33 chunks do not fit the LDS -- with four
+// quads a wave of a group holds every power of its quad), else 1
+#define T_CG_OF(nq, jn) (((nq) == 1 || ((nq) == 2 && (jn) <= 6) || ((nq) == 4 && (jn) <= 4)) ? 2 : 1)
 
 // K = order + 1 is a run-time argument (it only enters the flush addresses); one launch slices the JN powers
 // J0 .. J0 + JN - 1.
