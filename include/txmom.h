@@ -259,8 +259,8 @@ int txm_resample_vals_batched(const txm_state_ptrs *states_host, int64_t S, int6
                               const txm_sampler_spec *spec_host, const uint32_t *counts, double *out,
                               void *ws, size_t ws_bytes, txm_stream stream);
 /* The same with per-call options (round 4; txm_resample_vals_batched == opts_host NULL).  Narrow states (C <= 16
- * observables, order >= 2, >= 64 replicates per state, N >= 262144; or opts.path = TXM_PATH_INT8 wherever
- * txm_resample_i8_supported) run the int8 path of txm_resample_vals with the state on a grid axis of EVERY kernel of it
+ * observables, order >= 1, and N >= 786432 at any replicate count or N >= 262144 from 128 replicates per state -- the rule
+ * of the single call, txm_resample_path; or opts.path = TXM_PATH_INT8 wherever txm_resample_i8_supported) run the int8 path of txm_resample_vals with the state on a grid axis of EVERY kernel of it
  * (pre-pass, bootstrap kernel, the precision guard's FP64 fallback, finalize): state s of the batch is, bit for bit, the
  * single call on state s with spec.rep0 + s * nrep.  Fields of txm_resample_opts used: path, info, prep / prep_bytes /
  * prep_valid (ONE block of txm_resample_batched_prep_bytes() for the S states -- their pivots, window tables, guard flags

@@ -148,7 +148,10 @@ def test_workspace_and_path_queries_are_pure_host_logic(lib, monkeypatch):
     big = 100_000_000
     assert lib.txm_resample_path(big, 32, 1000, 4) == 1
     assert lib.txm_resample_path(big, 32, 32, 4) == 0       # less than one 64-replicate group
-    assert lib.txm_resample_path(big, 12, 1000, 1) == 0     # order 1 with <= 16 columns: a single 16-column FP64 block
+    assert lib.txm_resample_path(big, 12, 1000, 1) == 1     # narrow states: the int8 kernel from order 1 on ...
+    assert lib.txm_resample_path(big, 4, 8, 2) == 1         # ... at any replicate count on a long series
+    assert lib.txm_resample_path(300_000, 4, 64, 3) == 0 and lib.txm_resample_path(300_000, 4, 128, 3) == 1   # short series: from 128
+    assert lib.txm_resample_path(big, 12, 1000, 0) == 0     # order 0 with <= 16 columns: a single 16-column FP64 block
     assert lib.txm_resample_path(big, 12, 1000, 4) == 1     # 8 < C <= 16: int8 kernel, two powers per column
     assert lib.txm_resample_path(big, 8, 1000, 4) == 1      # narrow state: int8 kernel, four powers per column
     assert lib.txm_resample_path(big, 32, 1000, 8) == 0     # order 8: FP64 kernel only

@@ -355,10 +355,14 @@ def test_batched_default_dispatch_rule(eng):
     assert eng.batched_info()["path"] == "fp64"
     assert torch.equal(auto, eng.resample_vals_batched(xs, us, 3, nrep=64, sampler=smp, path="fp64"))
     xs, us, _ = states(5, 300000, 4, 22)
-    smp = eng.DeviceSampler(3, 5 * 64, 300000)
-    auto = eng.resample_vals_batched(xs, us, 3, nrep=64, sampler=smp)
+    smp = eng.DeviceSampler(3, 5 * 128, 300000)
+    auto = eng.resample_vals_batched(xs, us, 3, nrep=128, sampler=smp)
     assert eng.batched_info()["path"] == "int8"
-    assert torch.equal(auto, eng.resample_vals_batched(xs, us, 3, nrep=64, sampler=smp, path="int8"))
+    assert torch.equal(auto, eng.resample_vals_batched(xs, us, 3, nrep=128, sampler=smp, path="int8"))
     # the first two states alone (a shard): the same kernel, the same bits
-    part = eng.resample_vals_batched(xs[:2], us[:2], 3, nrep=64, sampler=eng.DeviceSampler(3, 2 * 64, 300000))
+    part = eng.resample_vals_batched(xs[:2], us[:2], 3, nrep=128, sampler=eng.DeviceSampler(3, 2 * 128, 300000))
     assert eng.batched_info()["path"] == "int8" and torch.equal(part, auto[:2])
+    # a long series takes the int8 path at any replicate count
+    xs, us, _ = states(2, 1_000_000, 4, 23)
+    eng.resample_vals_batched(xs, us, 2, nrep=8, sampler=eng.DeviceSampler(3, 2 * 8, 1_000_000))
+    assert eng.batched_info()["path"] == "int8"

@@ -290,11 +290,14 @@ def test_dispatch_thresholds(eng):
         assert eng.resample_path(big, 32, 400, 1) == "int8"
         assert eng.resample_path(big, 32, 300, 0) == "fp64"       # order 0 needs >= 384
         assert eng.resample_path(big, 32, 1000, 0) == "int8"
-        assert eng.resample_path(big, 8, 1000, 4) == "int8"       # narrow state: four powers per column
-        assert eng.resample_path(big, 8, 100, 4) == "fp64"        # ... from 128 replicates
-        assert eng.resample_path(big, 8, 1000, 1) == "fp64"       # ... from order 2
-        assert eng.resample_path(big, 12, 1000, 4) == "int8"      # 8 < C <= 16: two powers per column
-        assert eng.resample_path(big, 12, 1000, 1) == "fp64"      # ... from order 2
+        assert eng.resample_path(big, 8, 1000, 4) == "int8"       # narrow states (round 4: chunk groups, packed fill):
+        assert eng.resample_path(big, 8, 8, 4) == "int8"          # ... any replicate count on a long series,
+        assert eng.resample_path(big, 8, 1000, 1) == "int8"       # ... from order 1,
+        assert eng.resample_path(big, 12, 1000, 1) == "int8"
+        assert eng.resample_path(big, 12, 1000, 0) == "fp64"      # ... not order 0 (a single 16-column FP64 block)
+        assert eng.resample_path(300_000, 8, 100, 4) == "fp64"    # ... short series from 128 replicates
+        assert eng.resample_path(300_000, 8, 128, 4) == "int8"
+        assert eng.resample_path(1_000_000, 4, 100, 3) == "int8"  # BASELINE config 5's state
         assert eng.resample_path(big, 64, 1000, 4) == "int8"      # two column groups
         assert eng.resample_path(big, 40, 1000, 4) == "fp64"      # 8-column tail group
         assert eng.resample_path(big, 32, 1000, 8) == "fp64"      # order 8: FP64 only

@@ -843,13 +843,14 @@ static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K, int call_path = TX
   // (order 4: 1.2x at 64 replicates, 1.5x at 128, 1.6x from 400), from 128 replicates at orders 1 and 2 (nrep = 128:
   // 25 vs 32 ms and 29 vs 43 ms; nrep = 1000: 157 vs 254 ms and 181 vs 342 ms) and from ~400 at order 0 (nrep = 200:
   // a tie; 400: 74 vs 80 ms; 1000: 151 vs 176 ms).  The last column group must also hold more than 16 columns.
-  // Narrow states (C <= 8) run the int8 kernel with four powers per observable column: ahead of the power-packed
-  // FP64 kernel from 128 replicates on at order >= 2 (N = 1e7, nrep = 200, C = 8: 4.5 vs 4.75 ms at order 3, 4.9 vs
-  // 6.1 at order 4, 6.2 vs 10.7 at order 6; N = 1e8: 40.6 vs 55.1 ms; C <= 4 or order <= 2: within 5 %).
-  if (C <= 8) return K >= 3 && nrep >= 128 && N >= 262144;
-  // 8 < C <= 16: two powers per column against one 16-column FP64 block (N = 1e7, C = 16, nrep = 200: 4.9 vs 5.6 ms at
-  // order 2, 6.2 vs 8.1 at order 4, 6.5 vs 10.6 at order 6; nrep = 64: 2.9 vs 3.1; N = 1e8, nrep = 1000: 193 vs 298 ms)
-  if (C <= 16) return K >= 3 && nrep >= 64 && N >= 262144;
+  // Narrow states (C <= 16, order >= 1: the quad-sharing variant of the transposing-read kernel with chunk groups, round 4):
+  // ahead of the power-packed FP64 kernel at EVERY replicate count from 4 to 200 once the series is long (tools/
+  // i8_sweep_narrow.py, N = 1e7, C = 1 .. 16, orders 1 .. 4: 1.5 - 2.4 x with the pre-pass block kept by the data object,
+  // 0.93 - 2.1 x on a first call that computes it; profiles/r04_narrow_sweep.txt).  On short series the pre-pass weighs more:
+  // N = 3e5: 1.05 - 1.6 x kept, 0.6 - 1.2 x on the first call, ahead on both from 128 replicates.  A rule on (N, nrep) that a
+  // replicate slab of a long series never crosses: from 3 x 2^18 samples every slab takes the kernel the whole call takes
+  // (N = 1e6: 1.2 - 1.35 x on the first call, 1.9 x kept).
+  if (C <= 16) return K >= 2 && (N >= 786432 || (N >= 262144 && nrep >= 128));
   const int64_t ctail = C % I8_CPAD;
   const int64_t min_rep = K >= 4 ? 64 : (K >= 2 ? 128 : 384);
   return C > 16 && (ctail == 0 || ctail > 16) && nrep >= min_rep && N >= 262144;
@@ -1408,11 +1409,10 @@ static bool use_i8_batched(int64_t S, int64_t N, int64_t C, int64_t nrep, int K,
   if (ov == TXM_PATH_INT8) return true;
   // A rule on the STATE's shape only -- never on how many states share the launch: the states of a collection must take the
   // same kernel whichever rank (or workspace-bounded group) they are bootstrapped in, or a sharded run would differ from the
-  // one-GPU run in the last bits.  (Small batches are launch-bound either way: 5 states x 4e5 samples x 8 observables,
-  // nrep = 70: 0.85 ms here against 0.75 ms on the FP64 kernel; 64 x 1e6 x 4, nrep = 100: 8.1 against 11.6 ms --
-  // gpurun_out/r4_bi8b.log.)
+  // one-GPU run in the last bits.  The single-state rule for narrow states (use_i8): long series at any replicate count,
+  // short ones from 128 replicates (64 x 1e6 x 4, order 3, nrep = 100: 6.7 against 11.6 ms on the FP64 kernel).
   (void)S;
-  return K >= 3 && nrep >= 64 && N >= 262144;
+  return K >= 2 && (N >= 786432 || (N >= 262144 && nrep >= 128));
 }
 
 __global__ void i8_states_kernel(const txm_state_ptrs *__restrict__ tab, int64_t S, unsigned char *base, unsigned char *pbase,
