@@ -147,7 +147,7 @@ def test_workspace_and_path_queries_are_pure_host_logic(lib, monkeypatch):
     assert lib.txm_set_resample_path(-1) == 0
     big = 100_000_000
     assert lib.txm_resample_path(big, 32, 1000, 4) == 1
-    assert lib.txm_resample_path(big, 32, 32, 4) == 0       # less than one 64-replicate group
+    assert lib.txm_resample_path(big, 32, 32, 4) == 1 and lib.txm_resample_path(big, 32, 16, 4) == 0   # long series: from 32 replicates
     assert lib.txm_resample_path(big, 12, 1000, 1) == 1     # narrow states: the int8 kernel from order 1 on ...
     assert lib.txm_resample_path(big, 4, 8, 2) == 1         # ... at any replicate count on a long series
     assert lib.txm_resample_path(300_000, 4, 64, 3) == 0 and lib.txm_resample_path(300_000, 4, 128, 3) == 1   # short series: from 128

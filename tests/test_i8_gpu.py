@@ -284,12 +284,16 @@ def test_dispatch_thresholds(eng):
         big = 10_000_000
         assert eng.resample_path(big, 32, 1000, 4) == "int8"
         assert eng.resample_path(big, 32, 64, 4) == "int8"
-        assert eng.resample_path(big, 32, 48, 4) == "fp64"        # less than one replicate group
-        assert eng.resample_path(big, 32, 100, 2) == "fp64"       # orders 1 and 2 need >= 128
-        assert eng.resample_path(big, 32, 128, 2) == "int8"
-        assert eng.resample_path(big, 32, 400, 1) == "int8"
-        assert eng.resample_path(big, 32, 300, 0) == "fp64"       # order 0 needs >= 384
-        assert eng.resample_path(big, 32, 1000, 0) == "int8"
+        assert eng.resample_path(big, 32, 32, 4) == "int8"        # long series: from 32 replicates (round-4 sweep)
+        assert eng.resample_path(big, 32, 16, 4) == "fp64"
+        assert eng.resample_path(big, 32, 32, 1) == "int8"
+        assert eng.resample_path(big, 32, 64, 0) == "fp64"        # order 0: a first call pays from 100
+        assert eng.resample_path(big, 32, 100, 0) == "int8"
+        assert eng.resample_path(300_000, 32, 64, 4) == "int8"    # short series: order >= 3 from 64, orders 1-2 from 128, order 0 from 384
+        assert eng.resample_path(300_000, 32, 100, 2) == "fp64"
+        assert eng.resample_path(300_000, 32, 128, 2) == "int8"
+        assert eng.resample_path(300_000, 32, 300, 0) == "fp64"
+        assert eng.resample_path(300_000, 32, 400, 0) == "int8"
         assert eng.resample_path(big, 8, 1000, 4) == "int8"       # narrow states (round 4: chunk groups, packed fill):
         assert eng.resample_path(big, 8, 8, 4) == "int8"          # ... any replicate count on a long series,
         assert eng.resample_path(big, 8, 1000, 1) == "int8"       # ... from order 1,

@@ -851,8 +851,13 @@ static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K, int call_path = TX
   // replicate slab of a long series never crosses: from 3 x 2^18 samples every slab takes the kernel the whole call takes
   // (N = 1e6: 1.2 - 1.35 x on the first call, 1.9 x kept).
   if (C <= 16) return K >= 2 && (N >= 786432 || (N >= 262144 && nrep >= 128));
+  // Wide states, re-measured in round 4 (tools/i8_sweep_narrow.py 1e7 32 ..., profiles/r04_narrow_sweep.txt; pre-pass block kept /
+  // first call): N = 1e7, order 4: 2.1 / 1.4 x at 32 replicates, 2.4 / 1.9 at 100; orders 1-2: 1.8-1.9 / 1.0-1.15 at 32, 2.1-2.25 /
+  // 1.4-1.6 at 100; order 0: 1.4-1.7 x kept at every count, but a first call only pays from 100 replicates (1.03; 0.72 at 64).
+  // N = 3e5: ahead on a first call from 128 replicates only (order 4: 1.17, order 1: 0.86).
   const int64_t ctail = C % I8_CPAD;
-  const int64_t min_rep = K >= 4 ? 64 : (K >= 2 ? 128 : 384);
+  const bool long_series = N >= 786432;
+  const int64_t min_rep = long_series ? (K >= 2 ? 32 : 100) : (K >= 4 ? 64 : (K >= 2 ? 128 : 384));  // (short series: round 3's rule)
   return C > 16 && (ctail == 0 || ctail > 16) && nrep >= min_rep && N >= 262144;
 }
 
