@@ -303,7 +303,8 @@ def test_dispatch_thresholds(eng):
         assert eng.resample_path(300_000, 8, 128, 4) == "int8"
         assert eng.resample_path(1_000_000, 4, 100, 3) == "int8"  # BASELINE config 5's state
         assert eng.resample_path(big, 64, 1000, 4) == "int8"      # two column groups
-        assert eng.resample_path(big, 40, 1000, 4) == "fp64"      # 8-column tail group
+        assert eng.resample_path(big, 40, 1000, 4) == "int8"      # 8-column tail group: the narrow-state variant behind a full group
+        assert eng.resample_path(big, 40, 1000, 0) == "fp64"      # ... which order 0 does not have
         assert eng.resample_path(big, 32, 1000, 8) == "fp64"      # order 8: FP64 only
         assert eng.resample_path(100_000, 32, 1000, 4) == "fp64"  # short series
     with eng.forced_path("int8"):

@@ -249,7 +249,14 @@ def test_second_matrix_means_equal_separate_order0_bootstrap(eng, orc):
             assert eng.resample_info()["path"] == "int8"
             st0 = eng.resample_vals(xw, uw, order, sampler=smp)
             sep = eng.resample_vals(yw_, uw, 0, sampler=smp)[:, :, 1, 0]
-        assert torch.equal(st, st0), (Cw, order)
+        if Cw > 32:
+            # the full group is bit for bit the call without y; the 8-column tail group runs the wide variant when y rides on
+            # the pass and the narrow-state variant (other partial-sum row width, other finalize tree) when it does not
+            assert torch.equal(st[:, :32], st0[:, :32]), (Cw, order)
+            sc = (xw.std(dim=0)[None, :, None, None] + 1.0) * torch.maximum(st0.abs(), torch.ones_like(st0))
+            assert ((st - st0).abs() <= 1e-13 * sc).all(), (Cw, order)
+        else:
+            assert torch.equal(st, st0), (Cw, order)
         assert ((ymw - sep).abs() <= 1e-13 * (sep.abs() + yw_.std())).all(), (Cw, order)
     order = 4
     f = eng.DeviceSampler(12, 2, N).freq().cpu().numpy()

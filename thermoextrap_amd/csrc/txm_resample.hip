@@ -855,10 +855,11 @@ static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K, int call_path = TX
   // first call): N = 1e7, order 4: 2.1 / 1.4 x at 32 replicates, 2.4 / 1.9 at 100; orders 1-2: 1.8-1.9 / 1.0-1.15 at 32, 2.1-2.25 /
   // 1.4-1.6 at 100; order 0: 1.4-1.7 x kept at every count, but a first call only pays from 100 replicates (1.03; 0.72 at 64).
   // N = 3e5: ahead on a first call from 128 replicates only (order 4: 1.17, order 1: 0.86).
+  // (a tail group of <= 16 columns runs the narrow-state variant; at order 0, which has none, such a call stays on the FP64 kernel)
   const int64_t ctail = C % I8_CPAD;
   const bool long_series = N >= 786432;
   const int64_t min_rep = long_series ? (K >= 2 ? 32 : 100) : (K >= 4 ? 64 : (K >= 2 ? 128 : 384));  // (short series: round 3's rule)
-  return C > 16 && (ctail == 0 || ctail > 16) && nrep >= min_rep && N >= 262144;
+  return C > 16 && (ctail == 0 || ctail > 16 || K >= 2) && nrep >= min_rep && N >= 262144;
 }
 
 }  // namespace txm
@@ -1176,6 +1177,11 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
       f.list = b.list; f.n_list = b.n_list;
       b.col0 = col0;
       b.C = C - col0 < I8_CPAD ? C - col0 : I8_CPAD;
+      // a tail group of <= 16 columns behind full groups runs the narrow-state variant (its own partial-sum row width) --
+      // unless a second matrix rides on the pass, which only the wide variant carries
+      const bool narrow_tail = C > I8_CPAD && b.C <= 16 && K >= 2 && !with_y;
+      b.C_call = narrow_tail ? b.C : C;
+      b.cpad = i8_cpad(b.C_call, K);
       if (!have_tables) {
         const int rc0 = launch_i8_prepass(b, K, st);
         if (rc0 != TXM_OK) return rc0;
