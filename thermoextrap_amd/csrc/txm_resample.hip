@@ -842,7 +842,7 @@ static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K, int call_path = TX
   // block and stays ahead; with two blocks the int8 kernel wins from one full replicate group on at order >= 3
   // (order 4: 1.2x at 64 replicates, 1.5x at 128, 1.6x from 400), from 128 replicates at orders 1 and 2 (nrep = 128:
   // 25 vs 32 ms and 29 vs 43 ms; nrep = 1000: 157 vs 254 ms and 181 vs 342 ms) and from ~400 at order 0 (nrep = 200:
-  // a tie; 400: 74 vs 80 ms; 1000: 151 vs 176 ms).  The last column group must also hold more than 16 columns.
+  // a tie; 400: 74 vs 80 ms; 1000: 151 vs 176 ms) -- round 3's numbers; the long-series thresholds below are round 4's re-measurement.
   // Narrow states (C <= 16, order >= 1: the quad-sharing variant of the transposing-read kernel with chunk groups, round 4):
   // ahead of the power-packed FP64 kernel at EVERY replicate count from 4 to 200 once the series is long (tools/
   // i8_sweep_narrow.py, N = 1e7, C = 1 .. 16, orders 1 .. 4: 1.5 - 2.4 x with the pre-pass block kept by the data object,
