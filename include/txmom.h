@@ -146,6 +146,19 @@ int txm_sampler_tile_counts(const txm_sampler_spec *spec_host, uint32_t *counts,
 int txm_sampler_freq(const txm_sampler_spec *spec_host, const uint32_t *counts, int64_t *freq,
                      txm_stream stream);
 
+/* Per-SAMPLE draw counts of a slab of replicates as a table in HBM (round 5): what cmomy's freq table holds
+ * (indices_to_freq, reached from data.py:1782-1789), at one byte per (replicate, sample), for the replicates
+ * [rep_begin, rep_begin + nreps) of the spec only, laid out for the int8 bootstrap kernel's matrix operands:
+ *   table[((g * ntiles + t) * 32 + s) * 4096 + q * 1024 + L * 16 + b]
+ *     = draws of sample min(1024 t, ndat - 1024) + 32 s + 16 (L >> 5) + b   (0 for the samples a slid last tile
+ *       shares with its predecessor)   in replicate rep_begin + 128 g + 32 q + (L & 31)   (0 past the spec's nrep)
+ * -- the same Philox calls as txm_sampler_freq, bit for bit.  rep_begin is a multiple of 128; ndat >= 1024;
+ * txm_sampler_count_table_bytes(ndat, nreps) = ceil(nreps / 128) * ntiles * 131072.  txm_resample_vals builds and
+ * consumes such tables inside its workspace; the entry point exists for tests and for callers that keep a table. */
+size_t txm_sampler_count_table_bytes(int64_t ndat, int64_t nreps);
+int txm_sampler_count_table(const txm_sampler_spec *spec_host, const uint32_t *counts, int64_t rep_begin,
+                            int64_t nreps, uint8_t *table, txm_stream stream);
+
 /* ---- a3/a6: cmomy.wrap_resample_vals ------------------------------------ */
 /* Sample-level bootstrap of central comoments: replicate r is the weighted
  * comoment state of the data with weights w_i * freq[r][i].
@@ -267,6 +280,8 @@ int txm_resample_vals_batched(const txm_state_ptrs *states_host, int64_t S, int6
  * and fallback lists; 0 bytes = the shape never takes the int8 path); y / out_y must be NULL.
  * Reference loops replaced: models.py:635-641, gpr_active/active_utils.py:896-925. */
 size_t txm_resample_batched_prep_bytes(int64_t S, int64_t N, int64_t C, int64_t nrep, int order);
+/* the kernel a TXM_PATH_AUTO batched call takes (TXM_PATH_FP64 / TXM_PATH_INT8): bind a prep block only for INT8 */
+int txm_resample_batched_path(int64_t S, int64_t N, int64_t C, int64_t nrep, int order);
 int txm_resample_vals_batched_opts(const txm_state_ptrs *states_host, int64_t S, int64_t ldx_s, int64_t N,
                                    int64_t C, int order, int64_t nrep, const int64_t *freq,
                                    const txm_sampler_spec *spec_host, const uint32_t *counts, double *out,

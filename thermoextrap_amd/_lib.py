@@ -73,6 +73,8 @@ SIGNATURES = {
     "txm_sampler_counts_ws_bytes": (c_size, [ct.POINTER(SamplerSpec)]),
     "txm_sampler_tile_counts": (c_int, [ct.POINTER(SamplerSpec), c_void_p, c_void_p, c_size, c_void_p]),
     "txm_sampler_freq": (c_int, [ct.POINTER(SamplerSpec), c_void_p, c_void_p, c_void_p]),
+    "txm_sampler_count_table_bytes": (c_size, [c_i64, c_i64]),
+    "txm_sampler_count_table": (c_int, [ct.POINTER(SamplerSpec), c_void_p, c_i64, c_i64, c_void_p, c_void_p]),
     "txm_resample_path": (c_int, [c_i64, c_i64, c_i64, c_int]),
     "txm_set_resample_path": (c_int, [c_int]),
     "txm_resample_vals_info": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_int, ct.POINTER(c_i64), c_void_p]),
@@ -90,6 +92,7 @@ SIGNATURES = {
     "txm_resample_vals_batched": (c_int, [ct.POINTER(StatePtrs), c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_void_p,
                                           ct.POINTER(SamplerSpec), c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
     "txm_resample_batched_prep_bytes": (c_size, [c_i64, c_i64, c_i64, c_i64, c_int]),
+    "txm_resample_batched_path": (c_int, [c_i64, c_i64, c_i64, c_i64, c_int]),
     "txm_resample_vals_batched_opts": (c_int, [ct.POINTER(StatePtrs), c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_void_p,
                                                ct.POINTER(SamplerSpec), c_void_p, c_void_p, ct.POINTER(ResampleOpts), c_void_p,
                                                c_size, c_void_p]),

@@ -1,5 +1,6 @@
-// txm_i8t_common.h -- pieces shared by the two transposing-read int8 bootstrap kernels (txm_resample_i8t.hip: eight
-// waves, a wave owns a column quad; txm_resample_i8w.hip: sixteen waves, two waves share a column quad).
+// txm_i8t_common.h -- pieces shared by the transposing-read int8 bootstrap kernels (txm_resample_i8t.hip: the sampler fill
+// inside the kernel, 64 replicates per workgroup; txm_resample_i8g.hip: counts from a table in HBM, 128 replicates) and the
+// count-table generator (txm_count_table.hip).
 #pragma once
 #include "txm_resample_i8.h"
 #include "txm_sampler.h"

@@ -810,27 +810,20 @@ static I8Plan plan_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   return p;
 }
 
-// TXM_I8=0 keeps the FP64 kernel, TXM_I8=1 takes the int8 path whenever it applies;
-// by default it is used where it pays: many replicates, enough columns to fill a block.
-// -1: automatic; TXM_PATH_FP64 / TXM_PATH_INT8: forced (txm_set_resample_path; the environment variable
-// TXM_I8=0/1 sets the initial value, read once)
-static int g_path_override = -2;
-static int path_override() {
-  if (g_path_override == -2) {
-    const char *e = getenv("TXM_I8");
-    g_path_override = (e && e[0] == '0') ? TXM_PATH_FP64 : (e && e[0] == '1') ? TXM_PATH_INT8 : -1;
-  }
-  return g_path_override;
-}
+// the process-wide default of TXM_PATH_AUTO calls (txm_set_resample_path; tests and A/B timing): -1 = the shape rule
+// below, TXM_PATH_FP64 / TXM_PATH_INT8 = forced wherever the kernel supports the shape.  No environment variable is read
+// anywhere in the library (rounds 1-4 read TXM_I8 / TXM_THROTTLE / TXM_PACK / TXM_I8W); a call that passes
+// txm_resample_opts.path does not look at this word either.
+static int g_path_override = -1;
+static int path_override() { return g_path_override; }
 
-// TXM_THROTTLE=0 switches the L2-sharing hint of the bootstrap kernels off (A/B measurements)
-static bool throttle_on() {
-  static int on = -1;
-  if (on < 0) {
-    const char *e = getenv("TXM_THROTTLE");
-    on = (e && e[0] == '0') ? 0 : 1;
-  }
-  return on != 0;
+// the L2-sharing hint of the bootstrap kernels; an A/B build without it: -DTXM_NO_THROTTLE (tools/build_variant.sh)
+static constexpr bool throttle_on() {
+#ifdef TXM_NO_THROTTLE
+  return false;
+#else
+  return true;
+#endif
 }
 
 static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K, int call_path = TXM_PATH_AUTO) {
@@ -983,13 +976,13 @@ extern "C" int txm_resample_i8_supported(int64_t N, int64_t C, int64_t nrep, int
   }
 
 namespace txm {
-// TXM_PACK=0 keeps the one-power-per-column kernel for narrow states too (A/B measurements)
-static bool pack_on() {
-  static const bool on = [] {
-    const char *e = getenv("TXM_PACK");
-    return !(e && e[0] == '0');
-  }();
-  return on;
+// narrow states: several powers per B-operand column; an A/B build with one power per column: -DTXM_NO_PACK
+static constexpr bool pack_on() {
+#ifdef TXM_NO_PACK
+  return false;
+#else
+  return true;
+#endif
 }
 template <int K>
 static int run_resample(ResampleArgs a, const ResamplePlan &p, bool weighted, bool explicit_,
@@ -1579,6 +1572,13 @@ extern "C" size_t txm_resample_vals_batched_ws_bytes(int64_t S, int64_t N, int64
   if (!i8_supported(N, C, nrep, order + 1) || i8t_narrow_nq(C, order + 1) == 0) return f;
   const size_t i = plan_batched_i8(S, N, C, nrep, order + 1).total;
   return i > f ? i : f;
+}
+
+// the kernel a TXM_PATH_AUTO batched call takes (the batched counterpart of txm_resample_path): callers that keep a
+// pre-pass block bind it only when the call really runs the int8 path
+extern "C" int txm_resample_batched_path(int64_t S, int64_t N, int64_t C, int64_t nrep, int order) {
+  if (S < 1 || N < 1 || C < 1 || nrep < 1 || order < 0 || order > TXM_MAX_ORDER) return TXM_PATH_FP64;
+  return use_i8_batched(S, N, C, nrep, order + 1) ? TXM_PATH_INT8 : TXM_PATH_FP64;
 }
 
 extern "C" size_t txm_resample_batched_prep_bytes(int64_t S, int64_t N, int64_t C, int64_t nrep, int order) {

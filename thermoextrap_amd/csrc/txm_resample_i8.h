@@ -106,10 +106,6 @@ int launch_resample_i8(const I8Args &a, int K, bool weighted, size_t prog_bytes,
 // the same contraction with the B operands built by the LDS transposing read (txm_resample_i8t.hip): one power per
 // observable column, every order the int8 path serves
 int launch_resample_i8t(const I8Args &a, int K, bool weighted, size_t prog_bytes, hipStream_t st);
-// the sixteen-wave cut of the wide shape (txm_resample_i8w.hip): two waves share a column quad, four waves per SIMD;
-// bit for bit the sums of launch_resample_i8t.  i8w_takes: the launches it serves
-bool i8w_takes(const I8Args &a, int K, bool weighted);
-int launch_resample_i8w(const I8Args &a, int K, bool weighted, size_t prog_bytes, hipStream_t st);
 // true when a call of this shape carries a second sample matrix inside its last pass (else the caller bootstraps it on its own)
 bool i8t_carries_y(int64_t C, int K);
 bool i8t_applicable(const double *x, int64_t ldx_s, int64_t C);  // C = all columns of the call

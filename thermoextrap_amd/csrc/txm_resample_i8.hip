@@ -401,17 +401,8 @@ int launch_i8_prepass(const I8Args &a, int K, hipStream_t st) {
 // every shape of the int8 path runs the transposing-read kernel (txm_resample_i8t.hip): one power per observable column
 // for C > 16, the quad-sharing variant for narrow states.  (The round-1/2 kernel that sliced the digits on the VALU --
 // resample_i8_kernel, DESIGN.md 4.2b "history" -- lived here until round 3.)
-// TXM_I8W=1 sends the wide shape to the sixteen-wave cut (txm_resample_i8w.hip).  It is bit for bit the eight-wave
-// kernel and measured 8 % SLOWER on MI355X (profiles/r04_experiments.md: the int8 MFMA and the vector unit of a SIMD do not
-// run side by side, so four shorter streams per SIMD buy no overlap and pay twice the operand reads) -- kept as the
-// record of that experiment and for the bitwise test, not as a product path.  (Read per call: the test flips it.)
-static bool i8w_on() {
-  const char *e = getenv("TXM_I8W");
-  return e && e[0] == '1';
-}
-
+// (A sixteen-wave cut of the wide shape was measured 8 % slower in round 4: tools/experiments/.)
 int launch_resample_i8(const I8Args &a, int K, bool weighted, size_t prog_bytes, hipStream_t st) {
-  if (i8w_on() && i8w_takes(a, K, weighted)) return launch_resample_i8w(a, K, weighted, prog_bytes, st);
   return launch_resample_i8t(a, K, weighted, prog_bytes, st);
 }
 

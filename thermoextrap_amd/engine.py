@@ -247,7 +247,7 @@ def _tkey(t):
 
 def _call_path(path) -> int:
     """The kernel one device-sampler call takes: an explicit path, else the forced_path() context, else the
-    library's shape rule (txm_resample_path, which honours TXM_I8 and txm_set_resample_path)."""
+    library's shape rule (txm_resample_path, which honours txm_set_resample_path)."""
     eff = path if path is not None else _forced
     if eff in ("fp64", "int8"):
         return _PATHS[eff]
@@ -457,7 +457,10 @@ def resample_vals_batched(xs, us, order: int, *, nrep: int, sampler: DeviceSampl
     key = None
     if prep is not None and freq is None:
         nb = L.txm_resample_batched_prep_bytes(S, N, C, nrep, order)
-        if nb:  # the shape can take the int8 path (whether this call does is the library's decision: an unused block costs nothing)
+        # bind (and afterwards commit) the block only when THIS call runs the int8 path -- the library's own predicates, as the
+        # single call does: a call that ran the FP64 kernel never fills the block, and a later int8 call would read it as valid
+        takes_i8 = bool(nb) and (opts.path == 1 or (opts.path == -1 and L.txm_resample_batched_path(S, N, C, nrep, order) == 1))
+        if takes_i8:
             key = (tuple(_tkey(t) for t in src[0]), tuple(_tkey(t) for t in src[1]),
                    None if src[2] is None else tuple(_tkey(t) for t in src[2]), S, N, C, nrep, order)
             kept = prep.lookup(key)

@@ -12,6 +12,7 @@ nrep = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 order = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 C = int(sys.argv[4]) if len(sys.argv) > 4 else 32
 txa.require_gpu(0)
+import _toolenv; _toolenv.apply()
 x, u = make_data(N, C, 1000, torch)
 s = engine.DeviceSampler(0, nrep, N)
 out = torch.empty((nrep, C, 2, order + 1), dtype=torch.float64, device="cuda")

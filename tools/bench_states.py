@@ -214,7 +214,7 @@ def _c5_roofline(info, flops, t_k, S, N, C, K, nrep):
                 "guard_windows_fp64": info.get("windows_fp64"),
                 "prepass_reused": info.get("prep_reused"),
                 "measured": "HIP events around 5 txm_resample_vals_batched_opts calls (rank 0's states; pre-pass block kept by the caller as in the steps)"}
-    pack = 1 if os.environ.get("TXM_PACK", "1").startswith("0") or not (2 <= K <= 6 and C <= 8) else (4 if C <= 4 and K >= 3 else 2)
+    pack = 1 if not (2 <= K <= 6 and C <= 8) else (4 if C <= 4 and K >= 3 else 2)
     # the FP64 kernel pads the observables to one 16-column MFMA block and the replicates to 64 per workgroup
     exec_flops = 2.0 * S * N * (-(-nrep // 128) * 128) * -(-K // pack) * 16
     return {"kernel": "txm::resample_kernel, batched over states (FP64 MFMA contraction, Philox stage 3 fused) + pivot + finalize",

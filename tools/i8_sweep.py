@@ -11,7 +11,7 @@ for C in (20, 32):
             s = eng.DeviceSampler(1, nrep, N)
             t = {}
             for mode in ("1", "0"):
-                os.environ["TXM_I8"] = mode
+                eng._L().txm_set_resample_path(int(mode))
                 eng.resample_vals(x, u, order, sampler=s); torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(); eng.resample_vals(x, u, order, sampler=s); e1.record(); torch.cuda.synchronize()

@@ -8,7 +8,7 @@ x, u = make_data(N, C, 0, torch)
 s = eng.DeviceSampler(1, nrep, N)
 out = {}
 for mode in ("1", "0"):
-    os.environ["TXM_I8"] = mode
+    eng._L().txm_set_resample_path(int(mode))
     r = eng.resample_vals(x, u, order, sampler=s)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -17,6 +17,7 @@ C = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 order = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 iters = int(sys.argv[5]) if len(sys.argv) > 5 else 2
 txa.require_gpu(0)
+import _toolenv; _toolenv.apply()
 x, u = make_data(N, C, 1000, torch)
 state = engine.reduce_vals(x, u, order)
 pivot = torch.cat([state[0, 0, 1:2], state[:, 1, 0]]).contiguous()
