@@ -217,6 +217,7 @@ int txm_sampler_count_table(const txm_sampler_spec *spec_host, const uint32_t *c
 #define TXM_PATH_AUTO (-1)
 #define TXM_PATH_FP64 0
 #define TXM_PATH_INT8 1
+#define TXM_PATH_INT8_FUSED 2 /* the int8 path with the sampler drawn inside the contraction kernel (the round-3/4 kernel; what narrow states always run): for tests and A/B timing */
 typedef struct txm_resample_opts {
   int32_t path;
   int32_t prep_valid;

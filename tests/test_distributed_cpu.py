@@ -106,6 +106,24 @@ WORKER = textwrap.dedent(
     # uneven slabs without counts
     g = D.all_gather_slabs(torch.full((rank + 1, 2), float(rank)))
     assert g.shape == (3, 2) and g[:, 0].tolist() == [0.0, 1.0, 1.0]
+    # input_GP_from_states(sharded=...): every raise is decided from gathered words, on EVERY rank -- a world larger than the
+    # number of states, an empty local list or ineligible states on one rank must fail everywhere, not leave the other ranks
+    # blocked in the all-gather (round-4 advice).  (No compute is reached: the checks come first.)
+    from thermoextrap_amd import gpr_input as G
+    plain = M.StateCollection(states=(FakeState(0),))               # one (ineligible) state for two ranks
+    for kw in ({"sharded": True}, {"sharded": "local"}):
+        c = plain if kw["sharded"] is True else M.StateCollection(states=(FakeState(0),) if rank == 0 else ())
+        try:
+            G.input_GP_from_states(c, sampler={"nrep": 4, "seed": 5}, **kw)
+            raise SystemExit("sharded GP input accepted more ranks than states")
+        except ValueError as e:
+            assert "more ranks than states" in str(e), e
+    two = M.StateCollection(states=(FakeState(0), FakeState(1)))    # a state per rank, none eligible: both ranks refuse
+    try:
+        G.input_GP_from_states(two, sampler={"nrep": 4, "seed": 5}, sharded=True)
+        raise SystemExit("sharded GP input accepted ineligible states")
+    except ValueError as e:
+        assert "ranks without such states: [0, 1]" in str(e), e
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(os.environ["TXM_OUT"], f"rank{rank}.ok"), "w").write("ok")
@@ -131,8 +149,13 @@ def test_two_rank_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, TXM_ROOT=str(ROOT), TXM_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1")
+    import socket
+
+    with socket.socket() as sk:  # a free port (a fixed one collides with a concurrent run of this suite)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()

@@ -15,7 +15,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libtxmom.so"
 SOURCES = ["txm_api.hip", "txm_reduce.hip", "txm_sampler.hip", "txm_small.hip", "txm_resample.hip", "txm_resample_i8.hip",
-           "txm_resample_i8t.hip", "txm_count_table.hip", "txm_perturb.hip"]
+           "txm_resample_i8t.hip", "txm_resample_i8g.hip", "txm_count_table.hip", "txm_perturb.hip"]
 HEADERS = ["txm_common.h", "txm_pivot.h", "txm_sampler.h", "txm_resample_i8.h", "txm_i8t_common.h", "txm_i8g.h", "../../include/txmom.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed"]
 # per-file flags.  txm_resample_i8t.hip: 11 int32 accumulator tiles (176 registers) per wave at two waves per SIMD only
@@ -25,7 +25,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-pass-faile
 # (-Wno-inline-asm: its store asm names M0 as clobbered -- it writes it -- and clang remarks on every instance that M0 is
 # a reserved register)
 _I8T = ["-mllvm", "-amdgpu-mfma-vgpr-form", "-Wno-inline-asm"]
-EXTRA_FLAGS = {"txm_resample_i8t.hip": _I8T, "txm_sampler.hip": ["-ffp-contract=off"]}
+EXTRA_FLAGS = {"txm_resample_i8t.hip": _I8T, "txm_resample_i8g.hip": _I8T, "txm_sampler.hip": ["-ffp-contract=off"]}
 
 
 def _hipcc() -> str:

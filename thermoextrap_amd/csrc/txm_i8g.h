@@ -25,4 +25,9 @@ static inline size_t count_table_bytes(int64_t ntiles, int64_t nreps) {
 int launch_count_table(const uint32_t *counts, int64_t nrep, int64_t N, uint32_t k0, uint32_t k1, uint32_t rep_base,
                        int64_t rep_begin, int64_t n_groups, unsigned char *table, hipStream_t st);
 
+// the contraction over a count table (txm_resample_i8g.hip): one 32-column group (a.col0, a.C), every pass of the order
+bool i8g_applicable(const double *x, int64_t ldx_s, int64_t C, const double *y, int64_t ldy_s);  // C = all columns of the call
+int launch_resample_i8g(const I8Args &a, int K, bool weighted, const unsigned char *table, int64_t rep_begin, int n_grp,
+                        hipStream_t st);
+
 }  // namespace txm

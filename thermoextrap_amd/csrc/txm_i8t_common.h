@@ -38,6 +38,7 @@ constexpr int T_XDN = TXM_T_XDN;
 static_assert((T_XD == 1 || T_XD == 2 || T_XD == 4 || T_XD == 8) && (T_XDN == 1 || T_XDN == 2 || T_XDN == 4 || T_XDN == 8), "ring depth");
 // 1.5 * 2^52 + 0x80 in each of the six low mantissa bytes (the digits come out biased by 128; byte 6 holds
 // 0x38 + digit 6, taken out at flush time as 56 * draws; byte 7 is the sign/exponent byte: the dead slot)
+constexpr int T_PLANE = 512, T_PB = 2 * T_PLANE + 128;  // X region of a wave: bytes per plane, per (wave, row set)
 constexpr double T_MAGIC = 6755399441055744.0 + 141289400074368.0;
 constexpr int T_D6_BIAS = 0x38;
 

@@ -29,6 +29,7 @@
 #include "txm_sampler.h"
 #include "txm_pivot.h"
 #include "txm_resample_i8.h"
+#include "txm_i8g.h"
 
 namespace txm {
 
@@ -754,6 +755,9 @@ struct I8Plan {
   // precision-guard fallback: the FP64 kernel's plan / partial sums for one column group
   int sub_tiles;
   size_t off_fbx, off_fbu, off_prog, prog_bytes, off_stats, off_prep;
+  // the per-sample count table of the call's replicates (txm_count_table.hip; wide states: the contraction kernel without a
+  // sampler inside, txm_resample_i8g.hip) -- 0 bytes for shapes that never take that kernel
+  size_t off_table, table_bytes;
   // second sample matrix (txm_resample_opts.y) carried by the int8 kernel: its per-window partial sums, the FP64
   // fallback's sums for it, the sums themselves [nrep][C] (2 doubles each) and its pre-pass tables inside the prep block
   size_t off_py, off_fby, prep_ypiv, prep_ywt, prep_yflag;
@@ -806,7 +810,9 @@ static I8Plan plan_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   p.off_py = p.off_stats + align_up((size_t)cdiv(p.ntiles, p.win_tiles < 16 ? p.win_tiles : 16) * 100 * sizeof(double), 256);
   p.off_fby = p.off_py + align_up((size_t)p.nwin * p.nrep_pad * 8 * I8_CPAD * sizeof(double), 256);
   p.off_prep = p.off_fby + align_up((size_t)p.fb.n_chunks * p.fb.nrep_pad * p.fb.C_pad * sizeof(double), 256);
-  p.total = p.off_prep + align_up(p.prep_total, 256);
+  p.off_table = p.off_prep + align_up(p.prep_total, 256);
+  p.table_bytes = (C > 16 && N >= SM_T) ? count_table_bytes(p.ntiles, nrep) : 0;
+  p.total = p.off_table + align_up(p.table_bytes, 256);
   return p;
 }
 
@@ -830,7 +836,7 @@ static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K, int call_path = TX
   if (!i8_supported(N, C, nrep, K)) return false;
   const int ov = call_path != TXM_PATH_AUTO ? call_path : path_override();
   if (ov == TXM_PATH_FP64) return false;
-  if (ov == TXM_PATH_INT8) return true;
+  if (ov == TXM_PATH_INT8 || ov == TXM_PATH_INT8_FUSED) return true;
   // measured on MI355X (tools/i8_sweep.py, N = 1e7; tools/ab_order.py, N = 1e8): C <= 16 runs one 16-column FP64
   // block and stays ahead; with two blocks the int8 kernel wins from one full replicate group on at order >= 3
   // (order 4: 1.2x at 64 replicates, 1.5x at 128, 1.6x from 400), from 128 replicates at orders 1 and 2 (nrep = 128:
@@ -860,7 +866,7 @@ static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K, int call_path = TX
 using namespace txm;
 
 extern "C" int txm_set_resample_path(int path) {
-  TXM_REQUIRE(path == -1 || path == TXM_PATH_FP64 || path == TXM_PATH_INT8, "set_resample_path: %d is not a path", path);
+  TXM_REQUIRE(path == -1 || path == TXM_PATH_FP64 || path == TXM_PATH_INT8 || path == TXM_PATH_INT8_FUSED, "set_resample_path: %d is not a path", path);
   g_path_override = path;
   return TXM_OK;
 }
@@ -1084,8 +1090,13 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
   const int K = order + 1;
   if (y_done) *y_done = false;
   if (!explicit_ && use_i8(N, C, nrep, K, path)) {
-    const bool with_y = y != nullptr && i8t_carries_y(C, K);
     const I8Plan q = plan_i8(N, C, nrep, K);
+    // wide states: the per-sample counts of the call's replicates as a table in HBM (built once, shared by the column groups
+    // and the passes) and the contraction kernel without a sampler inside (txm_resample_i8g.hip).  Misaligned operands and
+    // TXM_PATH_INT8_FUSED keep the kernel that draws in place; narrow states and narrow tail groups always run it.
+    const bool fused_only = path == TXM_PATH_INT8_FUSED || (path == TXM_PATH_AUTO && path_override() == TXM_PATH_INT8_FUSED);
+    const bool table_call = !fused_only && q.table_bytes != 0 && i8g_applicable(x, ldx_s, C, y, ldy_s);
+    const bool with_y = y != nullptr && (table_call || i8t_carries_y(C, K));
     if (ws_bytes < q.total) {
       set_error("resample_vals: workspace too small (%zu < %zu)", ws_bytes, q.total);
       return TXM_ERR_WORKSPACE;
@@ -1159,6 +1170,7 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
     TXM_REQUIRE(q.fb.nrep_pad == q.nrep_pad, "resample_vals: replicate padding of the two kernels differs");
     // one launch (or two, orders 5-7) per group of 32 columns; the groups reuse the partial buffers
     int g = 0;
+    bool have_table = false;
     for (int64_t col0 = 0; col0 < C; col0 += I8_CPAD, ++g) {
       unsigned char *pg = pb + q.prep_group0 + (size_t)g * q.prep_group_stride;
       b.wtab = (double *)(pg + q.prep_wt);
@@ -1179,7 +1191,19 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
         const int rc0 = launch_i8_prepass(b, K, st);
         if (rc0 != TXM_OK) return rc0;
       }
-      const int rc = launch_resample_i8(b, K, w != nullptr, q.prog_bytes, st);
+      const bool table_kernel = table_call && !narrow_tail;
+      int rc;
+      if (table_kernel) {
+        unsigned char *table = (unsigned char *)ws + q.off_table;
+        if (!have_table) {
+          rc = launch_count_table(counts, nrep, N, b.k0, b.k1, b.rep_base, 0, cdiv(nrep, G_REPS), table, st);
+          if (rc != TXM_OK) return rc;
+          have_table = true;
+        }
+        rc = launch_resample_i8g(b, K, w != nullptr, table, 0, (int)cdiv(nrep, G_REPS), st);
+      } else {
+        rc = launch_resample_i8(b, K, w != nullptr, q.prog_bytes, st);
+      }
       if (rc != TXM_OK) return rc;
       f.x = x + col0; f.C = b.C; f.col_off = col0;
       {
@@ -1299,7 +1323,7 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
   o.path = TXM_PATH_AUTO; o.prep_valid = 0; o.prep = nullptr; o.prep_bytes = 0; o.info = nullptr;
   o.y = nullptr; o.ldy_s = 0; o.out_y = nullptr;
   if (opts) o = *opts;
-  TXM_REQUIRE(o.path == TXM_PATH_AUTO || o.path == TXM_PATH_FP64 || o.path == TXM_PATH_INT8,
+  TXM_REQUIRE(o.path == TXM_PATH_AUTO || o.path == TXM_PATH_FP64 || o.path == TXM_PATH_INT8 || o.path == TXM_PATH_INT8_FUSED,
               "resample_vals: opts.path %d is not a path", (int)o.path);
   TXM_REQUIRE((o.y == nullptr) == (o.out_y == nullptr), "resample_vals: opts.y and opts.out_y go together");
   TXM_REQUIRE(o.y == nullptr || o.ldy_s >= C, "resample_vals: opts.ldy_s < C");
@@ -1410,7 +1434,7 @@ static bool use_i8_batched(int64_t S, int64_t N, int64_t C, int64_t nrep, int K,
   if (!i8_supported(N, C, nrep, K) || i8t_narrow_nq(C, K) == 0) return false;
   const int ov = call_path != TXM_PATH_AUTO ? call_path : path_override();
   if (ov == TXM_PATH_FP64) return false;
-  if (ov == TXM_PATH_INT8) return true;
+  if (ov == TXM_PATH_INT8 || ov == TXM_PATH_INT8_FUSED) return true;
   // A rule on the STATE's shape only -- never on how many states share the launch: the states of a collection must take the
   // same kernel whichever rank (or workspace-bounded group) they are bootstrapped in, or a sharded run would differ from the
   // one-GPU run in the last bits.  The single-state rule for narrow states (use_i8): long series at any replicate count,
@@ -1600,7 +1624,7 @@ extern "C" int txm_resample_vals_batched_opts(const txm_state_ptrs *states_host,
                                               const txm_sampler_spec *spec, const uint32_t *counts, double *out,
                                               const txm_resample_opts *opts, void *ws, size_t ws_bytes, txm_stream stream) {
   const int call_path = opts ? opts->path : TXM_PATH_AUTO;
-  TXM_REQUIRE(call_path == TXM_PATH_AUTO || call_path == TXM_PATH_FP64 || call_path == TXM_PATH_INT8,
+  TXM_REQUIRE(call_path == TXM_PATH_AUTO || call_path == TXM_PATH_FP64 || call_path == TXM_PATH_INT8 || call_path == TXM_PATH_INT8_FUSED,
               "resample_vals_batched: opts.path %d is not a path", call_path);
   TXM_REQUIRE(!(opts && (opts->y || opts->out_y)), "resample_vals_batched: no second sample matrix on the batched entry");
   TXM_REQUIRE(states_host && out && ws, "resample_vals_batched: null pointer");

@@ -1,0 +1,452 @@
+// txm_resample_i8g.hip -- the int8 bootstrap contraction WITHOUT a sampler inside (round 5).  Same sums, same fixed-point
+// words, same partial-sum slots as txm_resample_i8t.hip (cmomy.wrap_resample_vals as called from thermoextrap
+// data.py:1803-1810, 1354-1366):
+//        S1[r][c][j] = sum_i f[r][i] w_i du_i^j dx_ic        S0[r][j] = sum_i f[r][i] w_i du_i^j
+// but the counts f come from a table in HBM that count_table_kernel (txm_count_table.hip) wrote in MFMA-A-operand order.
+//
+// Why.  In resample_i8t_kernel 36 % of all vector instructions were the stage-3 sampler fill (Philox + ds_add), the
+// 64 KiB count tile held the workgroup at 64 replicates, and every sliced B operand fed two MFMAs.  Measured on gfx950
+// (tools/mfma_i8_probe3.hip, profiles/r05_experiments.md): a v_mfma_i32_32x32x32_i8 hides about four vector
+// instructions issued beside it (38.5 -> 41 cycles per slot) and charges ~5 cycles for each one beyond that -- the old
+// kernel ran at 9.1 vector instructions per MFMA.  Here:
+//   * workgroup = 8 waves x 128 replicates x 32 columns x at most THREE row sets (powers J0 .. J0 + JN - 1, plus the
+//     second matrix's row set): wave w owns column quad w, 3 x 4 accumulator tiles (192 registers); every sliced operand
+//     feeds FOUR MFMAs; orders above 2 take several passes, all over ONE count table (a pass re-reads x and the table).
+//   * the u-row (S0) rides in the dead eighth byte of the fixed-point words: digit d of w du^j sits in byte 7 of column
+//     (d & 3) of quad 2 fi + (d >> 2) of row set fi -- no u-row tiles, no u-row MFMAs.
+//   * no global load lands in a register inside the k-steps: counts, x, y, u and w arrive by LDS-DMA
+//     (global_load_lds) with explicit s_waitcnt vmcnt counts -- the count words of a block of 4 k-steps into a
+//     double-buffered ring shared by the eight waves (one s_barrier per block), a wave's own x columns into a private
+//     ring three k-steps ahead, u and w two blocks ahead; the staged factors w du^j of a block are computed from them by
+//     two waves while the block before runs.
+//   * grid = scaling windows x replicate groups; the int32 sums of a window are exact, the flush writes the same
+//     doubles into the same slots as resample_i8t_kernel: the two kernels agree BIT FOR BIT.
+#include "txm_i8g.h"
+
+namespace txm {
+
+constexpr int G_BS = 4;  // k-steps per block (one barrier per block)
+constexpr int G_XR = 4;  // chunks in a wave's x ring (= G_BS: ring slots are compile-time offsets)
+static_assert(G_XR == G_BS && G_BS == 4, "the wait counts below are written for blocks of four k-steps");
+constexpr int G_FU = 2176;           // bytes between the factor lines of a lane's two 16-sample units (> 2040: no ds_read2 pairing)
+constexpr int G_RAW = 2 * G_BS * 256;  // one raw buffer: u then w of a block's chunks
+
+// LDS-DMA: 16 (4) bytes per lane from saddr + voff to the LDS address in M0 + 16 (4) * lane
+__device__ __forceinline__ void g_dma16(const void *sbase, uint32_t voff, uint32_t lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_dst) : "memory", "m0");
+}
+__device__ __forceinline__ void g_dma4(const void *sbase, uint32_t voff, uint32_t lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_dst) : "memory", "m0");
+}
+template <int N>
+__device__ __forceinline__ void g_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int J0, int JN, bool WEIGHTED, bool YS>
+__global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void resample_i8g_kernel(
+    const I8Args a, const int K, const unsigned char *__restrict__ table, const int64_t rep_begin, const int n_grp) {
+  constexpr int NS = JN + (YS ? 1 : 0);  // row sets of the pass
+  static_assert(JN >= 1 && NS <= 3 && J0 + JN <= 8, "row sets");
+  constexpr int NPT = JN + ((YS && WEIGHTED && J0 > 0) ? 1 : 0);  // staged factors per sample (the y row set needs plain w)
+  constexpr int NX = YS ? 2 : 1;                                 // x-ring DMAs per k-step
+  constexpr int WREG = NS * T_PB;
+  constexpr int OFF_A = T_WAVES * WREG;                           // [2][G_BS][4096] count words
+  constexpr int OFF_X = OFF_A + 2 * G_BS * G_KSTEP_BYTES;         // [wave][G_XR][32 samples][4 columns] doubles
+  constexpr int OFF_Y = OFF_X + T_WAVES * G_XR * 1024;
+  constexpr int OFF_RAW = OFF_Y + (YS ? T_WAVES * G_XR * 1024 : 0);  // [3][u | w][G_BS * 32] doubles
+  constexpr int OFF_F = OFF_RAW + 3 * G_RAW;                      // [2][unit][G_FU]: factors, line (chunk-in-block, sample) x NPT
+  constexpr int OFF_FS = OFF_F + 2 * 2 * G_FU;                    // [128] draws per replicate in the window
+  static_assert(G_BS * 16 * NPT * 8 <= G_FU, "factor lines");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  uint32_t *fsum = reinterpret_cast<uint32_t *>(lds + OFF_FS);
+
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int n32 = lane & 31, half = lane >> 5;
+  const uint32_t wreg = (uint32_t)(wave * WREG);
+
+  // ---- which window, which replicate group (the groups of a window share an XCD: b and b + 8 land on the same one)
+  const int b = blockIdx.x;
+  const int64_t win = (int64_t)((b >> 3) / n_grp) * 8 + (b & 7);
+  const int grp = (b >> 3) % n_grp;
+  if (win >= a.nwin) return;
+  if (a.wflag[win] != 0u) return;  // precision guard: this window goes to the FP64 kernel
+  const int64_t rep0 = rep_begin + (int64_t)grp * G_REPS;
+  const int64_t WT = a.win_tiles;
+  const int64_t t0 = win * WT;
+  const int64_t t1 = t0 + WT < a.ntiles ? t0 + WT : a.ntiles;
+  const int nsteps = (int)(t1 - t0) * T_STEPS;  // k-steps (32-sample chunks) of the window
+  const int nblk = nsteps / G_BS;
+  const unsigned char *tab = table + ((size_t)grp * (size_t)a.ntiles + (size_t)t0) * G_TILE_BYTES;
+
+  // ---- producer role: lane = (sample l >> 2 of a 16-sample unit, column l & 3 of the wave's quad)
+  const int ps = lane >> 2, cl = lane & 3;
+  const int col = 4 * wave + cl;
+  const int ccol = col < a.C ? col : 0;
+  const int qsrc = 4 * wave < a.C ? wave : 0;  // quads past C re-read quad 0 (their sums are never flushed)
+  // ---- consumer role (as resample_i8t_kernel)
+  const uint32_t rd_off = wreg + (uint32_t)(((lane >> 4) & 1) * (T_PLANE + 128) + (16 * half + ((lane & 15) >> 1)) * 16 + (lane & 1) * 8);
+  const int tcl = (n32 >> 2) & 3, tdg = 4 * (n32 >> 4) + (n32 & 3);
+  // ---- the u-row overlay: waves 2 fi, 2 fi + 1 carry the digits of row set fi's monomial w du^j in byte 7 of their words
+  const int ofi = wave >> 1;                        // the row set this wave overlays (if < JN)
+  const int odig = 4 * (wave & 1) + cl;             // this lane's digit (7: none)
+  // v_perm selector: byte odig of {hi, lo} into byte 3, zeros below; digits 0..5 come biased by 0x80
+  const uint32_t osel = odig < 7 ? (((uint32_t)odig << 24) | 0x000c0c0cu) : 0x0c0c0c0cu;
+  const uint32_t oxor = odig < 6 ? 0x80000000u : 0u;
+
+  const double *wt = a.wtab + win * I8_WT_STRIDE;
+  const double pu = a.pivot[0];
+  const double inv_du = wt[I8_WT_INVDU];
+  const double inv_w = WEIGHTED ? wt[I8_WT_INVW] : 1.0;
+  const double sc = wt[I8_WT_SC + ccol];
+  const double px = a.pivot[1 + a.col0 + ccol];
+  const double *wty = YS ? a.ywtab + win * I8_WT_STRIDE : wt;
+  const double scy = YS ? wty[I8_WT_SC + ccol] : 0.0;
+  const double py = YS ? a.ypivot[1 + a.col0 + ccol] : 0.0;
+
+  v16i acc[NS][4];
+#pragma unroll
+  for (int e = 0; e < NS; ++e)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[e][q] = (v16i)(0);
+
+  // first sample of chunk c of the window (the last tile of the series slides its window back)
+  auto chunk_sample = [&](int c) -> int64_t {
+    int64_t b0 = (t0 + (c >> 5)) * SM_T;
+    if (b0 > a.N - SM_T) b0 = a.N - SM_T;
+    return b0 + 32 * (c & 31);
+  };
+  // ---- x ring: the wave's own four columns of a chunk, [32 samples][4 columns] doubles, lane L fetches the 16-byte half
+  // (L & 1) of row L >> 1
+  const uint32_t xvoff = (uint32_t)(((lane >> 1) * a.ldx_s + a.col0 + 4 * qsrc) * 8 + (lane & 1) * 16);
+  const uint32_t yvoff = YS ? (uint32_t)(((lane >> 1) * a.ldy_s + a.col0 + 4 * qsrc) * 8 + (lane & 1) * 16) : 0u;
+  const uint32_t xring = (uint32_t)(OFF_X + wave * G_XR * 1024), yring = (uint32_t)(OFF_Y + wave * G_XR * 1024);
+  int cq = 0;  // chunk of the next x request (uniform)
+  const char *xq = reinterpret_cast<const char *>(a.x + chunk_sample(0) * a.ldx_s);
+  const char *yq = YS ? reinterpret_cast<const char *>(a.y + chunk_sample(0) * a.ldy_s) : nullptr;
+  const int64_t xstep = 32 * a.ldx_s * 8, ystep = YS ? 32 * a.ldy_s * 8 : 0;
+  auto x_request = [&](int slot) {  // chunk cq -> ring slot; chunks past the window re-read its last one
+    g_dma16(xq, xvoff, xring + (uint32_t)slot * 1024u);
+    if constexpr (YS) g_dma16(yq, yvoff, yring + (uint32_t)slot * 1024u);
+    ++cq;
+    if (cq < nsteps) {
+      if ((cq & 31) == 0) {  // a new tile (the slid last one does not follow its predecessor in memory)
+        const int64_t i0 = chunk_sample(cq);
+        xq = reinterpret_cast<const char *>(a.x + i0 * a.ldx_s);
+        if constexpr (YS) yq = reinterpret_cast<const char *>(a.y + i0 * a.ldy_s);
+      } else {
+        xq += xstep;
+        if constexpr (YS) yq += ystep;
+      }
+    }
+  };
+  // ---- count words of block B -> ring buffer B & 1: the wave's two 1-KiB pieces
+  auto a_request = [&](int B) {
+    const int Bc = B < nblk ? B : nblk - 1;
+    const unsigned char *src = tab + (size_t)Bc * (G_BS * G_KSTEP_BYTES) + (size_t)wave * 2048;
+    const uint32_t dst = (uint32_t)(OFF_A + (B & 1) * (G_BS * G_KSTEP_BYTES) + wave * 2048);
+    g_dma16(src, (uint32_t)lane * 16u, dst);
+    g_dma16(src + 1024, (uint32_t)lane * 16u, dst + 1024u);
+  };
+  // ---- raw u / w of factor block B (the chunks B * G_BS + 1 .. B * G_BS + G_BS, i.e. what block B's k-steps slice):
+  // waves 0..3 one chunk of u each, waves 4..7 one chunk of w (u again when unweighted: never read)
+  auto raw_request = [&](int B) {
+    int c = B * G_BS + 1 + (wave & 3);
+    if (c > nsteps - 1) c = nsteps - 1;
+    const double *src = ((WEIGHTED && wave >= 4) ? a.w : a.u) + chunk_sample(c);
+    g_dma4(src, (uint32_t)lane * 4u, (uint32_t)(OFF_RAW + (B % 3) * G_RAW + (wave >> 2) * (G_BS * 256) + (wave & 3) * 256));
+  };
+  // ---- factors of block B from raw buffer B % 3 into factor buffer B & 1 (waves 6 and 7: one sample per lane)
+  auto stage_factors = [&](int B) {
+    if (wave < 6) return;  // uniform
+    const int e = (int)threadIdx.x - 6 * 64;  // entry: chunk-in-block e >> 5, sample e & 31
+    const double *raw = reinterpret_cast<const double *>(lds + OFF_RAW + (B % 3) * G_RAW);
+    const double du = (raw[e] - pu) * inv_du;
+    double pw = WEIGHTED ? raw[G_BS * 32 + e] * inv_w : 1.0;
+    double *f = reinterpret_cast<double *>(lds + OFF_F + (B & 1) * (2 * G_FU) + ((e >> 4) & 1) * G_FU) + (((e >> 5) * 16 + (e & 15)) * NPT);
+    if constexpr (NPT > JN) f[JN] = pw;  // plain w for the y row set
+#pragma unroll
+    for (int k = 0; k < J0; ++k) pw *= du;
+#pragma unroll
+    for (int jj = 0; jj < JN; ++jj) {
+      f[jj] = pw;
+      pw *= du;
+    }
+  };
+
+  // ---- store the fixed-point words of the wave's two units of one row set (as resample_i8t_kernel: four 256-byte runs)
+  auto store_x2 = [&](uint32_t lo0, uint32_t hi0, uint32_t lo1, uint32_t hi1, int off) {
+    asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                 "ds_write_addtid_b32 %0 offset:%5\n\t"
+                 "ds_write_addtid_b32 %1 offset:%6\n\t"
+                 "ds_write_addtid_b32 %2 offset:%7\n\t"
+                 "ds_write_addtid_b32 %3 offset:%8"
+                 :
+                 : "v"(lo0), "v"(hi0), "v"(lo1), "v"(hi1), "s"(wreg), "n"(off), "n"(off + T_PLANE + 128), "n"(off + 256),
+                   "n"(off + 256 + T_PLANE + 128)
+                 : "memory", "m0");
+  };
+  // the words of row set fi for this lane's two samples: f[uu] = the sample factor, d[uu] = dx (or dy)
+  auto produce_row = [&](auto fic, const double (&f)[2], const double (&d)[2]) {
+    constexpr int fi = decltype(fic)::value;
+    uint32_t lo[2], hi[2];
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) {
+      const uint64_t bits = (uint64_t)__double_as_longlong(fma(f[uu], d[uu], T_MAGIC));
+      lo[uu] = (uint32_t)bits ^ 0x80808080u;
+      hi[uu] = (uint32_t)(bits >> 32) ^ 0x00008080u;
+    }
+    if (fi < JN && ofi == fi) {  // wave-uniform: this wave carries digits of the row set's u-row monomial in byte 7
+      // (the permute as a volatile asm: the compiler must keep the branch -- if-converted, all eight waves executed the
+      // overlay of all three row sets, 30 vector instructions per k-step instead of 10 on six waves)
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu) {
+        const uint64_t ub = (uint64_t)__double_as_longlong(__builtin_ldexp(f[uu], 50) + T_MAGIC);
+        uint32_t dig;
+        asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(dig) : "v"((uint32_t)(ub >> 32)), "v"((uint32_t)ub), "v"(osel));
+        hi[uu] = (hi[uu] & 0x00ffffffu) | (dig ^ oxor);
+      }
+    }
+    store_x2(lo[0], hi[0], lo[1], hi[1], fi * T_PB);
+  };
+
+  typedef __attribute__((address_space(3))) const double *lds_cd;
+  typedef __attribute__((address_space(3))) const v4i *lds_cv4;
+
+  // ================= prologue =================
+  // draws per replicate in the window (the top digit's bias is removed with them at the flush)
+  if (threadIdx.x < G_REPS) {
+    const int64_t r = rep0 + threadIdx.x;
+    uint32_t s = 0;
+    if (r < a.nrep)
+      for (int64_t t = t0; t < t1; ++t) s += a.counts[(size_t)r * a.ntiles + t];
+    fsum[threadIdx.x] = s;
+  }
+  // zero the X regions once (the padding between the planes is never written)
+  for (int e = threadIdx.x; e < T_WAVES * WREG / 16; e += T_BLOCK) reinterpret_cast<uint4 *>(lds)[e] = make_uint4(0, 0, 0, 0);
+  // chunk 0's u / w straight from memory (the direct path of resample_i8t_kernel)
+  double d_du[2], d_w[2] = {1.0, 1.0};
+  {
+    const int64_t i0 = chunk_sample(0);
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) {
+      d_du[uu] = (a.u[i0 + 16 * uu + ps] - pu) * inv_du;
+      if constexpr (WEIGHTED) d_w[uu] = a.w[i0 + 16 * uu + ps] * inv_w;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (nothing of the compiler's is in flight behind the DMAs below)
+  raw_request(0);
+  raw_request(1);
+  a_request(0);
+#pragma unroll
+  for (int c = 0; c < G_XR; ++c) x_request(c);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  stage_factors(0);
+  {
+    // the X words of chunk 0 (no matrix work yet)
+    const uint32_t xa = xring + (uint32_t)(ps * 32 + cl * 8);
+    double dx[2], dy[2] = {0.0, 0.0};
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) {
+      dx[uu] = (*(lds_cd)(lds + xa + uu * 512) - px) * sc;
+      if constexpr (YS) dy[uu] = (*(lds_cd)(lds + xa + (yring - xring) + uu * 512) - py) * scy;
+    }
+    t_static_for<NS>([&](auto fic) {
+      constexpr int fi = decltype(fic)::value;
+      double f[2];
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu) {
+        if constexpr (YS && fi == JN) {
+          f[uu] = WEIGHTED ? d_w[uu] : 1.0;
+        } else {
+          double pw = WEIGHTED ? d_w[uu] : 1.0;
+          for (int q = 0; q < J0 + fi; ++q) pw *= d_du[uu];
+          f[uu] = pw;
+        }
+      }
+      if constexpr (YS && fi == JN) produce_row(fic, f, dy);
+      else produce_row(fic, f, dx);
+    });
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // factors of block 0 visible; chunk 0's x slot free
+  x_request(0);                                                    // chunk G_XR into slot 0
+
+  // ================= the blocks =================
+  // Step s = B * 4 + p contracts chunk s (count words: ring buffer B & 1, X words: the wave's regions), slices chunk
+  // s + 1 (x from ring slot (p + 1) & 3, factors from buffer B & 1 line p) and requests chunk s + 5 into that slot.
+  // vmcnt: a wave's DMAs complete in order.  Issue order: [block start: 2 count pieces, 1 raw piece], then per step NX x
+  // pieces at its end.  The x of chunk s + 1 was requested at the end of step s - 4; newer than it at the top of step s
+  // are the x pieces of steps s - 3 .. s - 1 (3 NX) and the three pieces of the one block start among the last four
+  // steps (this step's own when p = 0): 3 NX + 3 at every p.  At the end of a block its block-start pieces are older than
+  // the 4 NX x pieces of its steps.
+#pragma unroll 1
+  for (int B = 0; B < nblk; ++B) {
+    a_request(B + 1);
+    raw_request(B + 2);
+    stage_factors(B + 1);
+    const uint32_t a_va = (uint32_t)(OFF_A + (B & 1) * (G_BS * G_KSTEP_BYTES)) + (uint32_t)lane * 16u;
+    uint32_t f_va = (uint32_t)(OFF_F + (B & 1) * (2 * G_FU) + ps * NPT * 8);
+    uint32_t x_va = xring + (uint32_t)(ps * 32 + cl * 8);
+    asm volatile("" : "+v"(f_va), "+v"(x_va));  // opaque bases: the reads below take 16-bit immediate offsets
+    t_static_for<G_BS>([&](auto pc) {
+      constexpr int p = decltype(pc)::value;
+      constexpr int slot = (p + 1) & 3;
+      g_wait_vm<3 * NX + 3>();
+      // operands of chunk s
+      v2i Bt[NS][2];
+#pragma unroll
+      for (int fi = 0; fi < NS; ++fi) {
+        Bt[fi][0] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB));
+        Bt[fi][1] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB + 128));
+      }
+      v4i A[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) A[q] = *(lds_cv4)(lds + a_va + p * G_KSTEP_BYTES + q * 1024);
+      // x of chunk s + 1
+      double dx[2], dy[2] = {0.0, 0.0};
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu) {
+        dx[uu] = (*(lds_cd)(lds + x_va + slot * 1024 + uu * 512) - px) * sc;
+        if constexpr (YS) dy[uu] = (*(lds_cd)(lds + x_va + (OFF_Y - OFF_X) + slot * 1024 + uu * 512) - py) * scy;
+      }
+      t_static_for<NS>([&](auto fic) {
+        constexpr int fi = decltype(fic)::value;
+        const v4i Bv = {Bt[fi][0][0], Bt[fi][0][1], Bt[fi][1][0], Bt[fi][1][1]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t_mfma<true>(acc[fi][q], A[q], Bv);
+        // the words of chunk s + 1, row set fi: behind the reads that took chunk s's (LDS operations of a wave execute in order)
+        double f[2];
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) {
+          if constexpr (YS && fi == JN) {
+            f[uu] = !WEIGHTED ? 1.0 : *(lds_cd)(lds + f_va + uu * G_FU + (p * 16 * NPT + (J0 == 0 ? 0 : JN)) * 8);
+          } else if constexpr (!WEIGHTED && J0 == 0 && fi == 0) {
+            f[uu] = 1.0;
+          } else {
+            f[uu] = *(lds_cd)(lds + f_va + uu * G_FU + (p * 16 * NPT + fi) * 8);
+          }
+        }
+        if constexpr (YS && fi == JN) produce_row(fic, f, dy);
+        else produce_row(fic, f, dx);
+      });
+      x_request(slot);  // chunk s + 5 (slot of chunk s + 1, just read)
+    });
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 * NX) : "memory");
+  }
+
+  // ================= flush: int32 accumulators of the window -> its slot of the partial sums =================
+  // D layout of v_mfma_i32_32x32x32_i8: column = lane & 31, row = 8 * (reg / 4) + 4 * (lane >> 5) + reg % 4
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  auto odig_of = [](int w, int c) { return 4 * (w & 1) + c; };  // the u-row digit column c of wave w carries in its dead byte
+  auto flush_tile = [&](v16i &T, int q, int rs) {
+    uint32_t z = 0;
+    asm volatile("" : "+v"(z));  // opaque zero: the addresses are formed where they are used, not hoisted and spilled
+    const int64_t opq = (int64_t)z;
+    const int64_t rrow = rep0 + 32 * q + 4 * half;
+    bool valid = tdg < I8_NSL;
+    int dgt = tdg < I8_NSL ? tdg : 0;
+    int j = 0;
+    double dsc;
+    double *base;
+    size_t stride;
+    const int64_t cpad = a.cpad;
+    const bool is_y = YS && rs == JN;
+    if (tdg == 7 && !is_y && ofi == rs && odig_of(wave, tcl) < 7) {
+      // the u-row digit this column's dead byte carried: [window][replicate][power][digit slot]
+      dgt = odig_of(wave, tcl);
+      valid = true;
+      j = J0 + rs;
+      dsc = wt[I8_WT_DSP + j] * 0x1p-50;
+      base = a.part_u + ((size_t)win * a.nrep_pad + rrow) * K * 8 + (size_t)j * 8 + dgt + opq;
+      stride = (size_t)K * 8;
+    } else if (is_y) {
+      const int c = 4 * wave + tcl;
+      valid = valid && c < a.C;
+      dsc = wty[I8_WT_DSP + 0] * wty[I8_WT_DSC + (c < a.C ? c : 0)];
+      base = a.part_y + (((size_t)win * a.nrep_pad + rrow) * 8 + dgt) * cpad + c + opq;
+      stride = (size_t)8 * cpad;
+    } else {
+      const int c = 4 * wave + tcl;
+      valid = valid && c < a.C;
+      j = J0 + rs;
+      dsc = wt[I8_WT_DSP + j] * wt[I8_WT_DSC + (c < a.C ? c : 0)];
+      base = a.part_x + ((((size_t)win * a.nrep_pad + rrow) * K + j) * 8 + dgt) * cpad + c + opq;
+      stride = (size_t)K * cpad * 8;
+    }
+    dsc *= (double)((int64_t)1 << (8 * dgt));
+    const int bias = dgt == I8_NSL - 1 ? T_D6_BIAS : 0;
+    if (valid) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r >> 2) * 8 + (r & 3);
+        if (rrow + m < a.nrep) {
+          const int v = T[r] - bias * (int)fsum[32 * q + m + 4 * half];
+          base[(size_t)m * stride] = (double)v * dsc;
+        }
+      }
+    }
+  };
+#pragma unroll
+  for (int fi = 0; fi < NS; ++fi)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) flush_tile(acc[fi][q], q, fi);
+}
+
+// ---------------------------------------------------------------------------
+template <int J0, int JN, bool WEIGHTED, bool YS>
+static int launch_pass_g(const I8Args &a, int K, const unsigned char *table, int64_t rep_begin, int n_grp, hipStream_t st) {
+  constexpr int NS = JN + (YS ? 1 : 0);
+  const size_t lds = (size_t)T_WAVES * NS * T_PB + 2 * G_BS * G_KSTEP_BYTES + (size_t)(YS ? 2 : 1) * T_WAVES * G_XR * 1024 + 3 * G_RAW +
+                     2 * 2 * G_FU + G_REPS * sizeof(uint32_t);
+  const dim3 grid((unsigned)(cdiv(a.nwin, 8) * 8 * n_grp));
+  TXM_SET_MAX_LDS((&resample_i8g_kernel<J0, JN, WEIGHTED, YS>), lds);
+  hipLaunchKernelGGL((resample_i8g_kernel<J0, JN, WEIGHTED, YS>), grid, dim3(T_BLOCK), lds, st, a, K, table, rep_begin, n_grp);
+  TXM_LAUNCH_CHECK();
+  return TXM_OK;
+}
+
+// what the kernel asks of a call beyond the shape (LDS-DMA moves 16 bytes per lane): x (and y) 16-byte aligned with an even
+// row pitch, and whole column quads readable inside a row
+bool i8g_applicable(const double *x, int64_t ldx_s, int64_t C, const double *y, int64_t ldy_s) {
+  if (C <= 16) return false;  // narrow states: the quad-sharing variant of resample_i8t_kernel
+  const int64_t cq = (C + 3) / 4 * 4;
+  if (((uintptr_t)x & 15) != 0 || (ldx_s & 1) != 0 || cq > ldx_s) return false;
+  if (y != nullptr && (((uintptr_t)y & 15) != 0 || (ldy_s & 1) != 0 || cq > ldy_s)) return false;
+  return true;
+}
+
+// the passes of one 32-column group over the count table of replicate groups [rep_begin, rep_begin + 128 n_grp):
+// K power row sets (+ the second matrix's) dealt out over the fewest passes of at most three, sizes within one of each
+// other (a pass costs at least a read of the table, so two passes of 2 beat 3 + 1); the second matrix rides on the last
+int launch_resample_i8g(const I8Args &a, int K, bool weighted, const unsigned char *table, int64_t rep_begin, int n_grp,
+                        hipStream_t st) {
+  const bool ys = a.y != nullptr;
+  const int rows = K + (ys ? 1 : 0), np = (rows + 2) / 3;
+  int j0 = 0;
+  for (int i = 0; i < np; ++i) {
+    const int n = rows / np + (i < rows % np ? 1 : 0);
+    const bool last = i == np - 1;
+    const int jn = n - ((last && ys) ? 1 : 0);
+    const bool y_here = last && ys;
+    int rc = TXM_ERR_INVALID;
+#define G_CASE(J0_, JN_)                                                                                         \
+  if (j0 == J0_ && jn == JN_) {                                                                                  \
+    if (y_here) {                                                                                                \
+      if constexpr (JN_ <= 2) rc = weighted ? launch_pass_g<J0_, JN_, true, true>(a, K, table, rep_begin, n_grp, st) \
+                                            : launch_pass_g<J0_, JN_, false, true>(a, K, table, rep_begin, n_grp, st); \
+    } else rc = weighted ? launch_pass_g<J0_, JN_, true, false>(a, K, table, rep_begin, n_grp, st)                \
+                       : launch_pass_g<J0_, JN_, false, false>(a, K, table, rep_begin, n_grp, st);              \
+  }
+    G_CASE(0, 1) G_CASE(0, 2) G_CASE(0, 3) G_CASE(2, 1) G_CASE(2, 2) G_CASE(3, 1) G_CASE(3, 2) G_CASE(3, 3)
+    G_CASE(5, 1) G_CASE(5, 2) G_CASE(6, 1) G_CASE(6, 2)
+#undef G_CASE
+    if (rc != TXM_OK) {
+      if (rc == TXM_ERR_INVALID) set_error("resample_i8g: no pass for powers %d..%d", j0, j0 + jn - 1);
+      return rc;
+    }
+    j0 += jn;
+  }
+  return TXM_OK;
+}
+
+}  // namespace txm

@@ -75,7 +75,7 @@ namespace txm {
 //   (Measured alternative, same box: lane = (sample, column PAIR), one ds_write_b128 per power and a plain
 //   [sample][column][8 B] region -- 17 % fewer instructions per k-step, 10 % MORE time: 40.4 vs 36.8 ms at N = 2e7.  The
 //   store path of the wide writes costs more than the issue slots they save.)
-constexpr int T_PLANE = 512, T_PB = 2 * T_PLANE + 128;  // bytes per (wave, power)
+// (T_PLANE, T_PB: txm_i8t_common.h)
 // YS: the launch carries one more row set, the order-0 monomial w * dy of a SECOND sample matrix y (I8Args::y: the
 // volume callback's dx/dq, txm_resample_opts.y) -- its per-replicate sums ride on the same count tile and k-steps.
 //

@@ -249,7 +249,7 @@ def _call_path(path) -> int:
     """The kernel one device-sampler call takes: an explicit path, else the forced_path() context, else the
     library's shape rule (txm_resample_path, which honours txm_set_resample_path)."""
     eff = path if path is not None else _forced
-    if eff in ("fp64", "int8"):
+    if eff in ("fp64", "int8", "int8_fused"):
         return _PATHS[eff]
     return -1
 
@@ -344,10 +344,11 @@ def resample_vals(
         opts.y, opts.ldy_s, opts.out_y = y2.data_ptr(), max(y2.stride(0) if N > 1 else C, C), ymean.data_ptr()
     key = None
     if prep is not None and freq is None:
-        takes_i8 = (opts.path == 1 and L.txm_resample_i8_supported(N, C, nrep, order) == 1) or (
+        takes_i8 = (opts.path in (1, 2) and L.txm_resample_i8_supported(N, C, nrep, order) == 1) or (
             opts.path == -1 and L.txm_resample_path(N, C, nrep, order) == 1)
         if takes_i8:
-            key = (src_key, N, C, nrep, order)
+            # (the path is part of the key: whether a second matrix's tables sit in the block depends on the kernel that carries it)
+            key = (src_key, N, C, nrep, order, opts.path)
             kept = prep.lookup(key)
             if kept is not None:  # same caller tensors, unedited: the operands of the call that filled the block
                 x2, u, w, pivot, y2 = kept
@@ -459,7 +460,7 @@ def resample_vals_batched(xs, us, order: int, *, nrep: int, sampler: DeviceSampl
         nb = L.txm_resample_batched_prep_bytes(S, N, C, nrep, order)
         # bind (and afterwards commit) the block only when THIS call runs the int8 path -- the library's own predicates, as the
         # single call does: a call that ran the FP64 kernel never fills the block, and a later int8 call would read it as valid
-        takes_i8 = bool(nb) and (opts.path == 1 or (opts.path == -1 and L.txm_resample_batched_path(S, N, C, nrep, order) == 1))
+        takes_i8 = bool(nb) and (opts.path in (1, 2) or (opts.path == -1 and L.txm_resample_batched_path(S, N, C, nrep, order) == 1))
         if takes_i8:
             key = (tuple(_tkey(t) for t in src[0]), tuple(_tkey(t) for t in src[1]),
                    None if src[2] is None else tuple(_tkey(t) for t in src[2]), S, N, C, nrep, order)
@@ -501,12 +502,12 @@ def resample_path(N: int, C: int, nrep: int, order: int) -> str:
     L = _L()
     if _forced == "fp64":
         return "fp64"
-    if _forced == "int8":  # wherever the int8 kernel supports the shape: the library's own predicate
+    if _forced in ("int8", "int8_fused"):  # wherever the int8 kernel supports the shape: the library's own predicate
         return "int8" if L.txm_resample_i8_supported(int(N), int(C), int(nrep), int(order)) == 1 else "fp64"
     return "int8" if L.txm_resample_path(int(N), int(C), int(nrep), int(order)) == 1 else "fp64"
 
 
-_PATHS = {None: -1, "auto": -1, "fp64": 0, "int8": 1}
+_PATHS = {None: -1, "auto": -1, "fp64": 0, "int8": 1, "int8_fused": 2}
 _forced: str | None = None
 
 

@@ -144,10 +144,21 @@ def _input_gp_sharded(coll, n_rep, log_scale, spec, local):
         counts = D.shard_counts(len(coll), w)
         share = D.shard_range(len(coll), rank, w)
         mine = StateCollection(list(coll.states[share.start:share.stop]), kws=coll.kws)
-    if len(mine) == 0:
-        raise ValueError("more ranks than states: give every rank at least one state")
-    if mine._batch_eligible(1) is None:
-        raise ValueError("sharded=... needs ExtrapModel states over DataCentralMomentsVals of one shape")
+    # Every decision that ends in a raise is taken on EVERY rank from gathered words: a rank that raised on a local condition
+    # (no states, states of another shape) while the others went on into the all-gather below would leave them blocked in the
+    # collective until its timeout.
+    key = mine._batch_eligible(1) if len(mine) else None
+    # a rank-comparable signature of the states' shape (the eligibility key holds a per-process object id)
+    import zlib
+    sig = -1 if key is None else zlib.crc32(repr((key[0][1:], key[1:10])).encode())
+    sigs = D.all_gather_ints(sig)
+    if min(counts) == 0:
+        raise ValueError(f"more ranks than states: give every rank at least one state (states per rank: {list(counts)})")
+    if min(sigs) < 0:
+        raise ValueError("sharded=... needs ExtrapModel states over DataCentralMomentsVals of one shape "
+                         f"(ranks without such states: {[r for r, v in enumerate(sigs) if v < 0]})")
+    if len(set(sigs)) != 1:
+        raise ValueError("sharded=...: the ranks hold states of different shapes / orders; the blocks cannot be gathered")
     state0 = sum(counts[:rank])
     order = mine.order
     cov_d, dv_d = _batched_blocks(mine, spec, order, state0=state0)

@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""The table-fed int8 kernel (txm_resample_i8g.hip) against the kernel that draws in place (TXM_PATH_INT8_FUSED), BIT FOR BIT,
+over orders, weights, column counts, ragged sizes and the second matrix; then timing of both.
+   python tools/i8g_check.py [time]"""
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+import thermoextrap_amd as txa
+from thermoextrap_amd import engine
+from bench import make_data
+
+txa.require_gpu(0)
+bad = 0
+cases = []
+for order in range(0, 8):
+    cases.append((300_000, 32, 200, order, False, False))
+cases += [(300_000, 32, 130, 4, True, False), (1_000_003, 24, 100, 3, True, False), (555_555, 40, 64, 2, False, False),
+          (300_000, 64, 70, 5, False, False), (2_000_000, 32, 257, 6, True, False), (300_000, 32, 64, 1, False, True),
+          (400_001, 32, 100, 4, True, True), (300_000, 30, 90, 6, False, True), (300_000, 32, 33, 0, True, True),
+          (300_000, 20, 40, 7, True, True), (1_100_000, 32, 128, 2, False, True)]
+for (N, C, nrep, order, weighted, withy) in cases:
+    x, u = make_data(N, C, 7, torch)
+    w = (torch.rand(N, dtype=torch.float64, device="cuda") + 0.5) if weighted else None
+    y = (x * 0.5 + torch.randn_like(x)) if withy else None
+    s = engine.DeviceSampler(11, nrep, N, rep0=5)
+    r = {}
+    for path in ("int8_fused", "int8"):
+        out = engine.resample_vals(x, u, order, sampler=s, w=w, y=y, path=path)
+        r[path] = out if withy else (out, None)
+    torch.cuda.synchronize()
+    same = torch.equal(r["int8"][0], r["int8_fused"][0])
+    if withy:
+        d = (r["int8"][1] - r["int8_fused"][1]).abs().max().item()
+        sc = r["int8_fused"][1].abs().max().item()
+        # the y row set: bit for bit where the fused kernel carried it too (order != 4), else against its separate order-0 bootstrap
+        samey = torch.equal(r["int8"][1], r["int8_fused"][1]) or d <= 1e-14 * sc
+    else:
+        samey = True
+    f = engine.resample_vals(x, u, order, sampler=s, w=w, path="fp64")
+    rel = ((r["int8"][0] - f).abs() / (f.abs() + f.abs().mean(dim=0, keepdim=True) + 1e-300)).max().item()
+    print(f"N={N} C={C} nrep={nrep} order={order} w={weighted} y={withy}: states {'SAME' if same else 'DIFFER'}  y {'ok' if samey else 'DIFFER'}  vs fp64 {rel:.1e}", flush=True)
+    if not same:
+        dd = (r["int8"][0] - r["int8_fused"][0]).abs()
+        idx = torch.nonzero(dd > 0)
+        print("   differing entries:", idx.shape[0], "first", idx[:5].tolist(), "max abs", dd.max().item(), flush=True)
+    bad += (not same) + (not samey)
+
+if len(sys.argv) > 1:
+    for (N, nrep, order) in [(20_000_000, 1000, 4), (100_000_000, 1000, 4), (100_000_000, 1000, 0), (100_000_000, 1000, 6)]:
+        x, u = make_data(N, 32, 1000, torch)
+        s = engine.DeviceSampler(0, nrep, N)
+        out = torch.empty((nrep, 32, 2, order + 1), dtype=torch.float64, device="cuda")
+        for path in ("int8_fused", "int8", "int8_fused", "int8"):
+            engine.resample_vals(x, u, order, sampler=s, out=out, path=path)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); engine.resample_vals(x, u, order, sampler=s, out=out, path=path); e1.record(); torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            print(f"N={N} nrep={nrep} order={order} {path:11s}: {min(ts):8.2f} ms (incl. pre-pass; table path incl. the generator)", flush=True)
+        del x, u
+print("FAILED" if bad else "ALL SAME")
+sys.exit(1 if bad else 0)
