@@ -81,6 +81,31 @@ int txm_reduce_vals(const double *x, int64_t ldx_s, int64_t ldx_c, const double 
                     const double *w, int64_t N, int64_t C, int order, double *out, void *ws,
                     size_t ws_bytes, txm_stream stream);
 
+/* ---- the same reduction in pieces: sample shards (SURVEY 8(e) partition (4)) and streaming accumulation ----------
+ * The reduce kernels accumulate WEIGHT-SCALED POWER SUMS about a pivot {pivot_u, pivot_x[0..C)}:
+ *     sums[c][0][j] = sum_i w_i (u_i - pivot_u)^j          sums[c][1][j] = sum_i w_i (x_ic - pivot_x[c]) (u_i - pivot_u)^j
+ * Sums about ONE pivot add exactly like the samples they stand for, so N samples split over ranks (or over time) are:
+ * one pivot everybody uses, per-shard sums, one addition in a fixed order, one shift to the cmomy state.
+ *   txm_reduce_vals_pivot   the library's own estimate (strided means of at most 1024 samples) for a shard: [1 + C]
+ *   txm_reduce_vals_sums    the sums of a shard about a GIVEN pivot: [C][2][K]            (ws: txm_reduce_vals_ws_bytes)
+ *   txm_sums_to_state       out[C][2][K] = shift(sums[0] + sums[1] + ... + sums[n - 1]), sums [n][C][2][K], added in index
+ *                           order -- an all-gathered stack of per-rank sums gives every rank the same bits
+ *   replaces, for a sample-sharded array, the one cmomy.wrap_reduce_vals call of data.py:1632-1640 / 1194-1203.
+ * txm_push_vals: cmomy's CentralMomentsData.push_vals(x, u, weight=w) -- accumulate a new chunk of samples into an
+ * existing state [C][2][K] in place (a state of zeros is the empty accumulator): the chunk's sums about its own pivot,
+ * the old state re-expressed about that pivot, added and shifted back.  (thermoextrap itself never calls push_vals --
+ * SURVEY 0.7 -- but it is the streaming form of the reduction above.)  ws: txm_push_vals_ws_bytes. */
+int txm_reduce_vals_pivot(const double *x, int64_t ldx_s, int64_t ldx_c, const double *u, int64_t N, int64_t C,
+                          double *pivot, txm_stream stream);
+int txm_reduce_vals_sums(const double *x, int64_t ldx_s, int64_t ldx_c, const double *u, const double *w,
+                         int64_t N, int64_t C, int order, const double *pivot, double *sums, void *ws,
+                         size_t ws_bytes, txm_stream stream);
+int txm_sums_to_state(const double *sums, int64_t n, const double *pivot, int64_t C, int order, double *out,
+                      txm_stream stream);
+size_t txm_push_vals_ws_bytes(int64_t N, int64_t C, int order);
+int txm_push_vals(double *state, const double *x, int64_t ldx_s, int64_t ldx_c, const double *u, const double *w,
+                  int64_t N, int64_t C, int order, void *ws, size_t ws_bytes, txm_stream stream);
+
 /* 1-D central moments of R independent series, mom = M - 1.
  *   replaces cmomy.wrap_reduce_vals(uv, weight=w, mom=order[+1])
  *   reference call sites: data.py:1183-1191 (x_is_u, mom = order + 1),

@@ -4,6 +4,7 @@ Checks, on a real device, that what the ranks compute together equals the one-pr
     by hand below)                                  vs  StateCollection.resample(spec)
   * gpr_input.input_GP_from_states(sharded=True / "local")  vs  the one-process call (x, y and the block-diagonal noise)
   * distributed.run_step("replicas", ...)           vs  the full-nrep call, on both bootstrap kernels
+  * distributed.sharded_reduce(x[shard], u[shard])  same bits on both ranks, the one-rank reduce of all samples to 1e-12
 Writes <outdir>/rank<r>.json."""
 import json
 import os
@@ -76,6 +77,24 @@ def main(outdir):
             got = D.run_step("replicas", compute, nrep2, 4321)
             full = compute(nrep2, 4321, 0)
         res[f"replicas_equal_{path}"] = bool(torch.equal(got, full))
+    # ---- SAMPLE-sharded reduce (SURVEY 8(e) partition (4)): every rank reduces its half of one long series; the result is the
+    # same on both ranks (bit for bit) and the one-rank state of all samples to 1e-12 of each comoment's scale
+    N3, C3, order3 = 400_001, 6, 4
+    x, u = data(N3, C3, 9)
+    w = 0.5 + torch.rand(N3, dtype=torch.float64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    sh = D.shard_range(N3, rank, world)
+    for key, ww in (("shred", None), ("shred_w", w)):
+        got = D.sharded_reduce(x[sh.start:sh.stop], u[sh.start:sh.stop], order3, w=None if ww is None else ww[sh.start:sh.stop])
+        full = eng.reduce_vals(x, u, order3, w=ww)
+        other = got.cpu().clone()
+        dist.broadcast(other, src=0)
+        res[key + "_same_on_all_ranks"] = bool(torch.equal(got.cpu(), other))
+        su = float(u.std())
+        sx = x.std(dim=0)
+        scale = torch.stack([torch.stack([sx[c] ** a * su ** b for b in range(order3 + 1)]) for a in range(2) for c in range(C3)]
+                            ).reshape(2, C3, order3 + 1).permute(1, 0, 2)
+        err = ((got - full).abs() / (full.abs() + scale)).max().item()
+        res[key + "_max_err"] = err
     Path(outdir, f"rank{rank}.json").write_text(json.dumps(res))
     dist.barrier()
     dist.destroy_process_group()

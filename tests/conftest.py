@@ -61,6 +61,42 @@ def post_data_rng():
     return make
 
 
+_NUM = r"[-+]?(?:\d+\.\d*|\.\d+|\d+)(?:[eE][-+]?\d+)?"
+
+
+def kat_case(kat, name):
+    """Numbers of a notebook whose stored outputs sit in the golden file as text (`<name>_raw_outputs`):
+    Temperature_Extrap_Case2/3/4.ipynb and Customized_Derivatives.ipynb print, in this order, the model's derivatives
+    (norm=False), its predictions at betas[:4] (volumes[:4]) and the bootstrap std of those predictions; a later cell prints
+    the analytic coefficients and the derivatives refitted on sub-samples ("With N_configs = 100000" is the full data)."""
+    import re
+
+    text = "\n".join(v for _, v in sorted(kat[name + "_raw_outputs"].items(), key=lambda kv: int(kv[0])))
+
+    def nums(t):
+        return [float(v) for v in re.findall(_NUM, t)]
+
+    def after(label, t=text):
+        m = re.search(label + r".*?\[(.*?)\]", t, re.S)
+        return nums(m.group(1)) if m else None
+
+    out = {"derivs": after(r"Model parameters \(derivatives\):"), "predict4": after(r"Model predictions:"),
+           "true_coefs": after(r"True extrapolation coefficients:"), "derivs_N1e5": after(r"With N_configs = 100000:")}
+    m = re.search(r"Bootstrapped uncertainties in predictions:.*?\[(.*?)\]", text, re.S)
+    out["boot_std4"] = nums(m.group(1)) if m else None
+    if out["boot_std4"] is None:  # Case4 prints the bare DataArray of cell 6
+        arrs = re.findall(r"array\(\[(.*?)\]\)", text, re.S)
+        out["boot_std4"] = nums(arrs[2]) if len(arrs) > 2 else None
+    return out
+
+
+@pytest.fixture(scope="session")
+def idealgas_vol5():
+    """Customized_Derivatives.ipynb cell 8: idealgas.generate_data((100000, 1000), beta=1, vol=5) on default_rng(0)
+    (tests/golden/make_golden.py); x per configuration, W = -1000 x, dx/dq = x."""
+    return np.load(GOLDEN / "idealgas_seed0_vol5.npz")["x"]
+
+
 def rel_close(a, b, sig):
     """a matches b to `sig` printed significant digits (notebook reprs)."""
     a = np.asarray(a, dtype=float)

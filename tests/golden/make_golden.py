@@ -129,11 +129,10 @@ def make_kat():
     return kat
 
 
-def idealgas_seed0():
-    """idealgas.generate_data((100000, 1000), beta=5.6) on default_rng(0)
+def idealgas_seed0(beta=5.6, vol=1.0):
+    """idealgas.generate_data((100000, 1000), beta, vol) on default_rng(0)
     (src/thermoextrap/idealgas.py:166-189, 403-421)."""
     rng = np.random.default_rng(0)
-    beta, vol = 5.6, 1.0
     r = rng.random((100_000, 1000))
     pos = (-1.0 / beta) * np.log(1.0 - r * (1.0 - np.exp(-beta * vol)))
     x = pos.mean(axis=-1)
@@ -223,6 +222,9 @@ def main():
     assert np.allclose(got, ht, atol=5e-5), (got, ht)
     (HERE / "kat_notebooks.json").write_text(json.dumps(kat, indent=1))
     np.savez_compressed(HERE / "idealgas_seed0.npz", x=x, u=u)
+    # Customized_Derivatives.ipynb cell 8: the same draw at beta = 1, volume = 5 (the volume-extrapolation example; u = 1000 x)
+    xv5, _ = idealgas_seed0(beta=1.0, vol=5.0)
+    np.savez_compressed(HERE / "idealgas_seed0_vol5.npz", x=xv5)
 
     fx = make_fixture(util, extrap)
     np.savez_compressed(HERE / "fixture_legacy.npz", **fx)

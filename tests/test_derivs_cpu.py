@@ -335,3 +335,91 @@ def test_derivs_from_args_xalpha_and_absolute_bound(legacy):
     for k in range(order + 1):
         bound = S.eval_host(d.series[k], res, absolute=True)
         assert np.all(np.abs(got[k]) <= bound * (1 + 1e-12))
+
+
+# ---------------------------------------------------------------------------
+# reference-held vectors of the notebooks Case2 / Case3 / Case4 / Customized_Derivatives (round 5: parsed before, asserted now)
+# ---------------------------------------------------------------------------
+BETAS4 = [0.1, 0.6, 1.1, 1.6]
+
+
+def _xalpha_samples(x, order=6, beta_ref=5.6):
+    """Temperature_Extrap_Case2.ipynb cell 4: x^(0) = beta_ref x, x^(1) = x, higher beta-derivatives zero -> (N, order + 1, 1)."""
+    xd = np.zeros((len(x), order + 1, 1))
+    xd[:, 0, 0] = x * beta_ref
+    xd[:, 1, 0] = x
+    return xd
+
+
+def test_oracle_matches_notebook_xalpha_minus_log_cases(kat, idealgas_data):
+    """The oracle's derivative formulas against the reference's stored notebook outputs (4 printed decimals):
+    Case2 = x(beta)-dependent observable (xalpha), Case3 = -log<x>, Case4 = xalpha AND -log -- the only pin of that
+    combination (reference tests/test_beta.py:775-916 exercises it against the same analytic model)."""
+    from conftest import kat_case
+
+    x, u = idealgas_data
+    xd = _xalpha_samples(x)
+    for name, got in (("case2", dorc.derivs_x_ave_xalpha(xd, u, 6)), ("case3", dorc.derivs_x_ave(x, u, 6, minus_log=True)),
+                      ("case4", dorc.derivs_x_ave_xalpha(xd, u, 6, minus_log=True))):
+        k = kat_case(kat, name)
+        got = np.asarray(got).reshape(7)
+        # 4 printed decimals; orders 5 and 6 are differences of terms ~1e4 times larger (the reference's own fp64 one-pass
+        # central moments and this extended-precision evaluation differ by a few 1e-5 there: 2.177125 against a printed 2.1772)
+        np.testing.assert_allclose(got, k["derivs"], atol=6e-5, rtol=4e-5, err_msg=name)
+        np.testing.assert_allclose(got, k["derivs_N1e5"], atol=6e-5, rtol=4e-5, err_msg=name)
+        np.testing.assert_allclose(dorc.predict(got, 5.6, BETAS4, order=2), k["predict4"], atol=6e-5, err_msg=name)
+
+
+def test_oracle_matches_notebook_volume(kat, idealgas_vol5):
+    """Customized_Derivatives.ipynb cells 8-13: d0 = <x>, d1 = (-<x><W> + <xW> + <dx/dq>) / (V ndim) with W = -1000 x, dx/dq = x,
+    V = 5, ndim = 1 (reference volume.py:63-78)."""
+    from conftest import kat_case
+
+    x = idealgas_vol5
+    w = -1000.0 * x
+    d = np.array([x.mean(), (-x.mean() * w.mean() + (x * w).mean() + x.mean()) / 5.0])
+    k = kat_case(kat, "custom")
+    np.testing.assert_allclose(d, k["derivs"], atol=6e-5)
+    np.testing.assert_allclose(dorc.predict(d, 5.0, [0.5, 1.0, 1.5, 2.0], order=1), k["predict4"], atol=6e-5)
+
+
+def test_idealgas_analytic_module(kat):
+    """thermoextrap_amd.idealgas against what the reference holds for it: the "True extrapolation coefficients" lines of the
+    notebooks (x_beta_extrap / _depend / _minuslog / _depend_minuslog at beta_ref = 5.6, x_vol_extrap at V = 5, beta = 1) and
+    the identities the closed forms satisfy (reference tests/test_idealgas.py:7-46 compares them with the legacy IGmodel class,
+    which imports cmomy and cannot be loaded here)."""
+    from conftest import kat_case
+
+    from thermoextrap_amd import idealgas as ig
+
+    for name, fn in (("case2", ig.x_beta_extrap_depend), ("case3", ig.x_beta_extrap_minuslog), ("case4", ig.x_beta_extrap_depend_minuslog)):
+        want = np.array(kat_case(kat, name)["true_coefs"])
+        got = fn(6, 5.6, np.array(BETAS4))[1]
+        np.testing.assert_allclose(got, want, atol=6e-5, rtol=6e-5, err_msg=name)  # (printed with 4 decimals or 5 significant digits)
+    np.testing.assert_allclose(ig.x_beta_extrap(6, 5.6, np.array(BETAS4))[1], kat["case1"]["true_coefs"], atol=6e-5, rtol=6e-5)
+    tot, coefs = ig.x_vol_extrap(1, 5.0, np.array([0.5, 1.0, 1.5, 2.0]), beta=1.0)
+    np.testing.assert_allclose(coefs, kat_case(kat, "custom")["true_coefs"], atol=6e-5)
+    np.testing.assert_allclose(tot, coefs[0] + coefs[1] * (np.array([0.5, 1.0, 1.5, 2.0]) - 5.0), rtol=1e-14)
+    # identities: Var(x) = -d<x>/dbeta; the density integrates to 1 and to the cdf, its mean is x_ave; d<x>/dL matches a difference
+    b = np.linspace(0.1, 10, 5)
+    for vol in (1.0, 2.5):
+        h = 1e-5
+        np.testing.assert_allclose(ig.x_var(b, vol), -(ig.x_ave(b + h, vol) - ig.x_ave(b - h, vol)) / (2 * h), rtol=1e-6)
+        xs = np.linspace(0.0, vol, 20001)
+        for bb in b:
+            p = ig.x_prob(xs, bb, vol)
+            np.testing.assert_allclose(np.trapezoid(p, xs), 1.0, rtol=1e-6)
+            np.testing.assert_allclose(np.trapezoid(p * xs, xs), ig.x_ave(bb, vol), rtol=1e-5)
+            cdf_num = np.concatenate(([0.0], np.cumsum(0.5 * (p[1:] + p[:-1]) * np.diff(xs))))
+            np.testing.assert_allclose(cdf_num, ig.x_cdf(xs, bb, vol), atol=1e-6)
+        np.testing.assert_allclose(ig.dvol_xave(1)(b, vol), (ig.x_ave(b, vol + h) - ig.x_ave(b, vol - h)) / (2 * h), rtol=1e-6, atol=1e-9)
+    # u_prob: the normal density of npart independent particles
+    us = np.linspace(100.0, 250.0, 30001)
+    p = ig.u_prob(us, 1000, 5.6)
+    np.testing.assert_allclose(np.trapezoid(p, us), 1.0, rtol=1e-6)
+    np.testing.assert_allclose(np.trapezoid(p * us, us), 1000 * ig.x_ave(5.6), rtol=1e-6)
+    np.testing.assert_allclose(np.trapezoid(p * (us - 1000 * ig.x_ave(5.6)) ** 2, us), 1000 * ig.x_var(5.6), rtol=1e-5)
+    # x_sample inverts x_cdf
+    r = np.random.default_rng(3).random(7)
+    xs = ig.x_sample(7, 2.0, 1.5, rng=np.random.default_rng(3))
+    np.testing.assert_allclose(ig.x_cdf(xs, 2.0, 1.5), r, rtol=1e-12)

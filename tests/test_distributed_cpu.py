@@ -106,6 +106,30 @@ WORKER = textwrap.dedent(
     # uneven slabs without counts
     g = D.all_gather_slabs(torch.full((rank + 1, 2), float(rank)))
     assert g.shape == (3, 2) and g[:, 0].tolist() == [0.0, 1.0, 1.0]
+    # sharded_reduce: rank 0's pivot is the one every rank uses, the per-rank sums are gathered in rank order, every rank gets
+    # the same state -- here with float64 stand-ins for the three device calls (the kernels themselves: tests/test_push_shard_gpu.py)
+    import math
+    g = torch.Generator().manual_seed(17)
+    xx = 3.0 + torch.randn(1001, 2, generator=g, dtype=torch.float64); uu = 5.0 + 2.0 * torch.randn(1001, generator=g, dtype=torch.float64)
+    sh = D.shard_range(1001, rank, w)
+    Kk = 3
+    def piv_fn(x_, u_): return torch.cat([u_[:7].mean()[None], x_[:7].mean(0)])
+    def sums_fn(x_, u_, o_, p_, w_):
+        du = u_ - p_[0]; dx = x_ - p_[1:]
+        return torch.stack([torch.stack([torch.stack([(du ** j).sum() for j in range(o_ + 1)]),
+                                         torch.stack([(dx[:, c] * du ** j).sum() for j in range(o_ + 1)])]) for c in range(x_.shape[1])])
+    seen = {}
+    def fin_fn(stack, p_):
+        seen["stack"], seen["piv"] = stack.clone(), p_.clone()
+        S = stack[0].clone()
+        for i in range(1, stack.shape[0]): S = S + stack[i]
+        return S
+    tot = D.sharded_reduce(xx[sh.start:sh.stop], uu[sh.start:sh.stop], Kk - 1, ops=(piv_fn, sums_fn, fin_fn))
+    assert torch.equal(seen["piv"], piv_fn(xx[:501], uu[:501]))                       # rank 0's shard decided the pivot
+    assert seen["stack"].shape == (2, 2, 2, Kk)
+    want = sums_fn(xx, uu, Kk - 1, seen["piv"], None)
+    assert torch.allclose(tot, want, rtol=1e-12, atol=1e-9)
+    ref_t = tot.clone(); dist.broadcast(ref_t, src=0); assert torch.equal(tot, ref_t)  # identical on every rank
     # input_GP_from_states(sharded=...): every raise is decided from gathered words, on EVERY rank -- a world larger than the
     # number of states, an empty local list or ineligible states on one rank must fail everywhere, not leave the other ranks
     # blocked in the all-gather (round-4 advice).  (No compute is reached: the checks come first.)

@@ -32,3 +32,6 @@ def test_two_ranks_equal_one_process_bit_for_bit(txm, tmp_path):
         for k in ("states_equal", "states_batch_equal", "unseeded_consistent", "replicas_equal_int8", "replicas_equal_fp64",
                   "gp_sharded_equal", "gp_local_equal", "gp_log_equal"):
             assert res[k] is True, (r, k, res)
+        for k in ("shred", "shred_w"):  # sample-sharded reduce: identical on the ranks, the whole-array state to 1e-12 of scale
+            assert res[k + "_same_on_all_ranks"] is True, (r, k, res)
+            assert res[k + "_max_err"] < 1e-12, (r, k, res)

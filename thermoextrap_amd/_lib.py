@@ -64,6 +64,13 @@ SIGNATURES = {
     "txm_reduce_vals_ws_bytes": (c_size, [c_i64, c_i64, c_int]),
     "txm_reduce_vals": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p,
                                 c_void_p, c_size, c_void_p]),
+    "txm_reduce_vals_pivot": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_void_p]),
+    "txm_reduce_vals_sums": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p,
+                                     c_void_p, c_size, c_void_p]),
+    "txm_sums_to_state": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
+    "txm_push_vals_ws_bytes": (c_size, [c_i64, c_i64, c_int]),
+    "txm_push_vals": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p, c_size,
+                              c_void_p]),
     "txm_reduce_vals_1d_ws_bytes": (c_size, [c_i64, c_i64, c_int]),
     "txm_reduce_vals_1d": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p,
                                    c_size, c_void_p]),

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(RED_BLOCK) void reduce_rowmajor_kernel(
 template <int K>
 __global__ __launch_bounds__(RED_BLOCK) void finalize_rowmajor_kernel(
     const double *__restrict__ partial, int nblk_x, int cols_per_chunk, int64_t C,
-    const double *__restrict__ pivot, double *__restrict__ out, int n_colchunks = 0) {
+    const double *__restrict__ pivot, double *__restrict__ out, int n_colchunks = 0, int sums_only = 0) {
   const int64_t c = blockIdx.x;
   if (c >= C) return;
   // batched mode: blockIdx.y = state
@@ -187,7 +187,15 @@ __global__ __launch_bounds__(RED_BLOCK) void finalize_rowmajor_kernel(
       S0[j] = sh[0][j];
       S1[j] = sh[0][K + j];
     }
-    pivot_sums_to_state<K>(S0, S1, pivot[0], pivot[1 + c], st);
+    if (sums_only) {  // the weight-scaled pivot power sums themselves (txm_reduce_vals_sums: sample-sharded reduce, push_vals)
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        st[j] = S0[j];
+        st[K + j] = S1[j];
+      }
+    } else {
+      pivot_sums_to_state<K>(S0, S1, pivot[0], pivot[1 + c], st);
+    }
 #pragma unroll
     for (int q = 0; q < 2 * K; ++q) out[c * 2 * K + q] = st[q];
   }
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(RED_BLOCK) void reduce_colmajor_kernel(
 template <int K, bool COV>
 __global__ __launch_bounds__(RED_BLOCK) void finalize_colmajor_kernel(
     const double *__restrict__ partial, int nblk_x, const double *__restrict__ pivot,
-    double *__restrict__ out) {
+    double *__restrict__ out, int sums_only = 0) {
   constexpr int NV = COV ? 2 * K : K;
   const int s = blockIdx.x;
   double acc[NV];
@@ -316,7 +324,15 @@ __global__ __launch_bounds__(RED_BLOCK) void finalize_colmajor_kernel(
         S0[j] = sh[0][j];
         S1[j] = sh[0][K + j];
       }
-      pivot_sums_to_state<K>(S0, S1, pivot[0], pivot[1 + s], st);
+      if (sums_only) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          st[j] = S0[j];
+          st[K + j] = S1[j];
+        }
+      } else {
+        pivot_sums_to_state<K>(S0, S1, pivot[0], pivot[1 + s], st);
+      }
 #pragma unroll
       for (int q = 0; q < 2 * K; ++q) out[(size_t)s * 2 * K + q] = st[q];
     } else {
@@ -386,7 +402,7 @@ template <int K>
 static int launch_rowmajor(const double *x, int64_t ldx_s, const double *u, const double *w,
                            int64_t N, int64_t C, const double *pivot, double *partial, double *out,
                            hipStream_t st, const txm_state_ptrs *batch = nullptr, int64_t S = 1,
-                           bool aligned16 = true) {
+                           bool aligned16 = true, int sums_only = 0) {
   // batched: `x` is only consulted for its alignment (aligned16 = every state's x is 16-byte aligned)
   RowPlan p = plan_rowmajor(aligned16 ? x : reinterpret_cast<const double *>(8), ldx_s, N, C);
   if (S > 1) {  // S states share the chip
@@ -415,7 +431,7 @@ static int launch_rowmajor(const double *x, int64_t ldx_s, const double *u, cons
 #undef TXM_RM_CASE
   TXM_LAUNCH_CHECK();
   hipLaunchKernelGGL((finalize_rowmajor_kernel<K>), dim3((unsigned)C, (unsigned)S), block, 0, st, partial,
-                     p.grid_x, p.cols_per_chunk, C, pivot, out, p.chunks);
+                     p.grid_x, p.cols_per_chunk, C, pivot, out, p.chunks, sums_only);
   TXM_LAUNCH_CHECK();
   return TXM_OK;
 }
@@ -423,7 +439,7 @@ static int launch_rowmajor(const double *x, int64_t ldx_s, const double *u, cons
 template <int K>
 static int launch_colmajor_cov(const double *x, int64_t ld_series, const double *u, const double *w,
                                int64_t N, int64_t C, const double *pivot, double *partial,
-                               double *out, hipStream_t st) {
+                               double *out, hipStream_t st, int sums_only = 0) {
   int gx = grid_x_for(N, RED_BLOCK * 2);
   // many series: fewer blocks per series is enough to fill the chip
   while (gx > 1 && (int64_t)gx * C > (int64_t)num_cus() * 16) gx = (gx + 1) / 2;
@@ -436,7 +452,7 @@ static int launch_colmajor_cov(const double *x, int64_t ld_series, const double 
                        u, w, N, pivot, partial);
   TXM_LAUNCH_CHECK();
   hipLaunchKernelGGL((finalize_colmajor_kernel<K, true>), dim3((unsigned)C), block, 0, st, partial,
-                     gx, pivot, out);
+                     gx, pivot, out, sums_only);
   TXM_LAUNCH_CHECK();
   return TXM_OK;
 }
@@ -483,35 +499,172 @@ extern "C" size_t txm_reduce_vals_ws_bytes(int64_t N, int64_t C, int order) {
   return reduce_vals_ws_bytes_impl(N, C, order);
 }
 
+// pivot_in == nullptr: the library's strided estimate; sums_only: out = the pivot power sums [C][2][K] (S0 | S1), not the state
+static int reduce_vals_impl(const double *x, int64_t ldx_s, int64_t ldx_c, const double *u, const double *w, int64_t N,
+                            int64_t C, int order, const double *pivot_in, int sums_only, double *out, void *ws,
+                            size_t ws_bytes, hipStream_t st, const char *who) {
+  TXM_REQUIRE(x && u && out && ws, "%s: null pointer", who);
+  TXM_REQUIRE(N >= 1 && C >= 1, "%s: need N >= 1 and C >= 1 (N=%lld C=%lld)", who, (long long)N, (long long)C);
+  TXM_REQUIRE(order >= 0 && order <= TXM_MAX_ORDER, "%s: order %d outside [0, %d]", who, order, TXM_MAX_ORDER);
+  TXM_REQUIRE(ldx_c == 1 || ldx_s == 1, "%s: need ldx_c == 1 or ldx_s == 1", who);
+  TXM_REQUIRE(C <= 65535, "%s: C > 65535 unsupported", who);
+  if (ws_bytes < txm_reduce_vals_ws_bytes(N, C, order)) {
+    set_error("%s: workspace too small", who);
+    return TXM_ERR_WORKSPACE;
+  }
+  double *pivot = (double *)ws;
+  double *partial = (double *)((char *)ws + align_up((size_t)(1 + C) * sizeof(double), 256));
+  if (pivot_in != nullptr) {
+    TXM_HIP(hipMemcpyAsync(pivot, pivot_in, sizeof(double) * (size_t)(1 + C), hipMemcpyDeviceToDevice, st));
+  } else {
+    hipLaunchKernelGGL(pivot_kernel, dim3((unsigned)(1 + C)), dim3(RED_BLOCK), 0, st, x, ldx_s, ldx_c, u, (int64_t)1, N, pivot);
+    TXM_LAUNCH_CHECK();
+  }
+  const int K = order + 1;
+  if (ldx_c == 1 && !(C == 1 && ldx_s == 1)) {
+    TXM_REQUIRE(ldx_s >= C, "%s: row pitch ldx_s < C", who);
+    TXM_K_SWITCH(K, return launch_rowmajor<KK>(x, ldx_s, u, w, N, C, pivot, partial, out, st, nullptr, 1, true, sums_only));
+  } else {
+    // (val, rec) layout, or a single contiguous series
+    const int64_t ld_series = (C == 1) ? 0 : ldx_c;
+    TXM_K_SWITCH(K, return launch_colmajor_cov<KK>(x, ld_series, u, w, N, C, pivot, partial, out, st, sums_only));
+  }
+  return TXM_OK;
+}
+
 extern "C" int txm_reduce_vals(const double *x, int64_t ldx_s, int64_t ldx_c, const double *u,
                                const double *w, int64_t N, int64_t C, int order, double *out,
                                void *ws, size_t ws_bytes, txm_stream stream) {
-  TXM_REQUIRE(x && u && out && ws, "reduce_vals: null pointer");
-  TXM_REQUIRE(N >= 1 && C >= 1, "reduce_vals: need N >= 1 and C >= 1 (N=%lld C=%lld)", (long long)N,
-              (long long)C);
-  TXM_REQUIRE(order >= 0 && order <= TXM_MAX_ORDER, "reduce_vals: order %d outside [0, %d]", order,
-              TXM_MAX_ORDER);
-  TXM_REQUIRE(ldx_c == 1 || ldx_s == 1, "reduce_vals: need ldx_c == 1 or ldx_s == 1");
-  TXM_REQUIRE(C <= 65535, "reduce_vals: C > 65535 unsupported");
-  if (ws_bytes < txm_reduce_vals_ws_bytes(N, C, order)) {
-    set_error("reduce_vals: workspace too small");
+  return reduce_vals_impl(x, ldx_s, ldx_c, u, w, N, C, order, nullptr, 0, out, ws, ws_bytes, (hipStream_t)stream, "reduce_vals");
+}
+
+// ---- sample-sharded reduce / streaming accumulation (SURVEY 8(e) partition (4); cmomy push_vals) -------------------
+// The reduce kernels accumulate weight-scaled power sums about a pivot; sums about ONE pivot add exactly (same algebra on
+// every shard), so N samples split over ranks or over time are: a pivot everybody uses, per-shard sums, one fixed-order
+// addition, one shift.
+extern "C" int txm_reduce_vals_pivot(const double *x, int64_t ldx_s, int64_t ldx_c, const double *u, int64_t N, int64_t C,
+                                     double *pivot, txm_stream stream) {
+  TXM_REQUIRE(x && u && pivot, "reduce_vals_pivot: null pointer");
+  TXM_REQUIRE(N >= 1 && C >= 1 && C <= 65535, "reduce_vals_pivot: need N >= 1 and 1 <= C <= 65535");
+  TXM_REQUIRE(ldx_c == 1 || ldx_s == 1, "reduce_vals_pivot: need ldx_c == 1 or ldx_s == 1");
+  hipLaunchKernelGGL(pivot_kernel, dim3((unsigned)(1 + C)), dim3(RED_BLOCK), 0, (hipStream_t)stream, x, ldx_s, ldx_c, u,
+                     (int64_t)1, N, pivot);
+  TXM_LAUNCH_CHECK();
+  return TXM_OK;
+}
+
+extern "C" int txm_reduce_vals_sums(const double *x, int64_t ldx_s, int64_t ldx_c, const double *u, const double *w,
+                                    int64_t N, int64_t C, int order, const double *pivot, double *sums, void *ws,
+                                    size_t ws_bytes, txm_stream stream) {
+  TXM_REQUIRE(pivot, "reduce_vals_sums: null pivot");
+  return reduce_vals_impl(x, ldx_s, ldx_c, u, w, N, C, order, pivot, 1, sums, ws, ws_bytes, (hipStream_t)stream,
+                          "reduce_vals_sums");
+}
+
+namespace txm {
+// out[c] = shift( sums[0][c] + sums[1][c] + ... + sums[n - 1][c] ), added in that order; thread per column
+template <int K>
+__global__ __launch_bounds__(256) void sums_to_state_kernel(const double *__restrict__ sums, int64_t n, int64_t C,
+                                                            const double *__restrict__ pivot, double *__restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double S0[K], S1[K], st[2 * K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) S0[j] = S1[j] = 0.0;
+  for (int64_t i = 0; i < n; ++i) {
+    const double *src = sums + (i * C + c) * 2 * K;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      S0[j] += src[j];
+      S1[j] += src[K + j];
+    }
+  }
+  pivot_sums_to_state<K>(S0, S1, pivot[0], pivot[1 + c], st);
+#pragma unroll
+  for (int q = 0; q < 2 * K; ++q) out[c * 2 * K + q] = st[q];
+}
+
+// a cmomy state [2][K] as weight-scaled power sums about (pu, px) -- the inverse of pivot_sums_to_state
+template <int K>
+__device__ inline void state_to_pivot_sums(const double *st, double pu, double px, double *S0, double *S1) {
+  const double W = st[0];
+  const double du = ((K > 1) ? st[1] : 0.0) - pu, dx = st[K] - px;
+#pragma unroll
+  for (int b = 0; b < K; ++b) {
+    double a0 = 0.0, a1 = 0.0, c = 1.0, p = 1.0;  // c = C(b, j), p = du^(b - j), j descending
+    for (int j = b; j >= 0; --j) {
+      const double m0 = (j == 0) ? 1.0 : (j == 1 ? 0.0 : st[j]);
+      const double m1 = (j == 0) ? 0.0 : st[K + j];
+      a0 += c * p * m0;
+      a1 += c * p * (m1 + dx * m0);
+      p *= du;
+      c = c * (double)j / (double)(b - j + 1);
+    }
+    S0[b] = (W == 0.0) ? 0.0 : W * a0;
+    S1[b] = (W == 0.0) ? 0.0 : W * a1;
+  }
+}
+
+// state[c] <- shift( sums(state[c]) + chunk[c] ): the old state re-expressed about the chunk's pivot, added, shifted back
+template <int K>
+__global__ __launch_bounds__(256) void push_merge_kernel(double *__restrict__ state, const double *__restrict__ chunk,
+                                                         int64_t C, const double *__restrict__ pivot) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double old[2 * K], S0[K], S1[K], st[2 * K];
+#pragma unroll
+  for (int q = 0; q < 2 * K; ++q) old[q] = state[c * 2 * K + q];
+  state_to_pivot_sums<K>(old, pivot[0], pivot[1 + c], S0, S1);
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    S0[j] += chunk[c * 2 * K + j];
+    S1[j] += chunk[c * 2 * K + K + j];
+  }
+  if (S0[0] == 0.0) return;  // nothing pushed into an empty accumulator: it stays empty (zeros)
+  pivot_sums_to_state<K>(S0, S1, pivot[0], pivot[1 + c], st);
+#pragma unroll
+  for (int q = 0; q < 2 * K; ++q) state[c * 2 * K + q] = st[q];
+}
+}  // namespace txm
+
+extern "C" int txm_sums_to_state(const double *sums, int64_t n, const double *pivot, int64_t C, int order, double *out,
+                                 txm_stream stream) {
+  TXM_REQUIRE(sums && pivot && out, "sums_to_state: null pointer");
+  TXM_REQUIRE(n >= 1 && C >= 1, "sums_to_state: need n >= 1 and C >= 1");
+  TXM_REQUIRE(order >= 0 && order <= TXM_MAX_ORDER, "sums_to_state: order %d outside [0, %d]", order, TXM_MAX_ORDER);
+  TXM_K_SWITCH(order + 1, hipLaunchKernelGGL((sums_to_state_kernel<KK>), dim3((unsigned)cdiv(C, 256)), dim3(256), 0,
+                                             (hipStream_t)stream, sums, n, C, pivot, out));
+  TXM_LAUNCH_CHECK();
+  return TXM_OK;
+}
+
+extern "C" size_t txm_push_vals_ws_bytes(int64_t N, int64_t C, int order) {
+  if (N < 1 || C < 1 || order < 0 || order > TXM_MAX_ORDER) return 0;
+  return align_up((size_t)(1 + C) * sizeof(double), 256) + align_up((size_t)C * 2 * (order + 1) * sizeof(double), 256) +
+         txm_reduce_vals_ws_bytes(N, C, order);
+}
+
+extern "C" int txm_push_vals(double *state, const double *x, int64_t ldx_s, int64_t ldx_c, const double *u, const double *w,
+                             int64_t N, int64_t C, int order, void *ws, size_t ws_bytes, txm_stream stream) {
+  TXM_REQUIRE(state && x && u && ws, "push_vals: null pointer");
+  TXM_REQUIRE(N >= 1 && C >= 1 && C <= 65535, "push_vals: need N >= 1 and 1 <= C <= 65535");
+  TXM_REQUIRE(order >= 0 && order <= TXM_MAX_ORDER, "push_vals: order %d outside [0, %d]", order, TXM_MAX_ORDER);
+  if (ws_bytes < txm_push_vals_ws_bytes(N, C, order)) {
+    set_error("push_vals: workspace too small");
     return TXM_ERR_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
   double *pivot = (double *)ws;
-  double *partial = (double *)((char *)ws + align_up((size_t)(1 + C) * sizeof(double), 256));
-  hipLaunchKernelGGL(pivot_kernel, dim3((unsigned)(1 + C)), dim3(RED_BLOCK), 0, st, x, ldx_s, ldx_c,
-                     u, (int64_t)1, N, pivot);
+  double *chunk = (double *)((char *)ws + align_up((size_t)(1 + C) * sizeof(double), 256));
+  void *rws = (char *)chunk + align_up((size_t)C * 2 * (order + 1) * sizeof(double), 256);
+  int rc = txm_reduce_vals_pivot(x, ldx_s, ldx_c, u, N, C, pivot, stream);
+  if (rc != TXM_OK) return rc;
+  rc = reduce_vals_impl(x, ldx_s, ldx_c, u, w, N, C, order, pivot, 1, chunk, rws, txm_reduce_vals_ws_bytes(N, C, order), st,
+                        "push_vals");
+  if (rc != TXM_OK) return rc;
+  TXM_K_SWITCH(order + 1, hipLaunchKernelGGL((push_merge_kernel<KK>), dim3((unsigned)cdiv(C, 256)), dim3(256), 0, st, state,
+                                             chunk, C, pivot));
   TXM_LAUNCH_CHECK();
-  const int K = order + 1;
-  if (ldx_c == 1 && !(C == 1 && ldx_s == 1)) {
-    TXM_REQUIRE(ldx_s >= C, "reduce_vals: row pitch ldx_s < C");
-    TXM_K_SWITCH(K, return launch_rowmajor<KK>(x, ldx_s, u, w, N, C, pivot, partial, out, st));
-  } else {
-    // (val, rec) layout, or a single contiguous series
-    const int64_t ld_series = (C == 1) ? 0 : ldx_c;
-    TXM_K_SWITCH(K, return launch_colmajor_cov<KK>(x, ld_series, u, w, N, C, pivot, partial, out, st));
-  }
   return TXM_OK;
 }
 

@@ -757,7 +757,7 @@ struct I8Plan {
   size_t off_fbx, off_fbu, off_prog, prog_bytes, off_stats, off_prep;
   // the per-sample count table of the call's replicates (txm_count_table.hip; wide states: the contraction kernel without a
   // sampler inside, txm_resample_i8g.hip) -- 0 bytes for shapes that never take that kernel
-  size_t off_table, table_bytes;
+  size_t off_table, table_bytes, off_gprog;  // (+ sixteen progress words per window: the L2-sharing hint of that kernel)
   // second sample matrix (txm_resample_opts.y) carried by the int8 kernel: its per-window partial sums, the FP64
   // fallback's sums for it, the sums themselves [nrep][C] (2 doubles each) and its pre-pass tables inside the prep block
   size_t off_py, off_fby, prep_ypiv, prep_ywt, prep_yflag;
@@ -812,7 +812,8 @@ static I8Plan plan_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   p.off_prep = p.off_fby + align_up((size_t)p.fb.n_chunks * p.fb.nrep_pad * p.fb.C_pad * sizeof(double), 256);
   p.off_table = p.off_prep + align_up(p.prep_total, 256);
   p.table_bytes = (C > 16 && N >= SM_T) ? count_table_bytes(p.ntiles, nrep) : 0;
-  p.total = p.off_table + align_up(p.table_bytes, 256);
+  p.off_gprog = p.off_table + align_up(p.table_bytes, 256);
+  p.total = p.off_gprog + (p.table_bytes ? align_up((size_t)cdiv(p.nwin, 8) * 8 * 16 * sizeof(uint32_t), 256) : 0);
   return p;
 }
 
@@ -1200,7 +1201,9 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
           if (rc != TXM_OK) return rc;
           have_table = true;
         }
-        rc = launch_resample_i8g(b, K, w != nullptr, table, 0, (int)cdiv(nrep, G_REPS), st);
+        I8Args bg = b;
+        bg.progress = (throttle_on() && nrep > G_REPS) ? (uint32_t *)((char *)ws + q.off_gprog) : nullptr;
+        rc = launch_resample_i8g(bg, K, w != nullptr, table, 0, (int)cdiv(nrep, G_REPS), st);
       } else {
         rc = launch_resample_i8(b, K, w != nullptr, q.prog_bytes, st);
       }

@@ -30,6 +30,10 @@ constexpr int G_XR = 4;  // chunks in a wave's x ring (= G_BS: ring slots are co
 static_assert(G_XR == G_BS && G_BS == 4, "the wait counts below are written for blocks of four k-steps");
 constexpr int G_FU = 2176;           // bytes between the factor lines of a lane's two 16-sample units (> 2040: no ds_read2 pairing)
 constexpr int G_RAW = 2 * G_BS * 256;  // one raw buffer: u then w of a block's chunks
+#ifndef TXM_G_LEAD
+#define TXM_G_LEAD 2
+#endif
+constexpr uint32_t G_LEAD = TXM_G_LEAD;  // tiles a replicate group may run ahead of the slowest one of its window
 
 // LDS-DMA: 16 (4) bytes per lane from saddr + voff to the LDS address in M0 + 16 (4) * lane
 __device__ __forceinline__ void g_dma16(const void *sbase, uint32_t voff, uint32_t lds_dst) {
@@ -37,6 +41,20 @@ __device__ __forceinline__ void g_dma16(const void *sbase, uint32_t voff, uint32
 }
 __device__ __forceinline__ void g_dma4(const void *sbase, uint32_t voff, uint32_t lds_dst) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_dst) : "memory", "m0");
+}
+// sixteen progress words of a window, read past the scalar cache (glc): SMEM counts on lgkmcnt, so a poll does not touch
+// the wave's vmcnt queue of DMAs
+typedef uint32_t g_v16u __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ uint32_t g_min_progress(const uint32_t *pg) {
+  g_v16u v;
+  asm volatile("s_load_dwordx16 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(pg) : "memory");
+  uint32_t m = 0xffffffffu;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const uint32_t e = v[i] == 0u ? 0xffffffffu : v[i];  // 0: a group that has not started (or does not exist)
+    m = e < m ? e : m;
+  }
+  return m;
 }
 template <int N>
 __device__ __forceinline__ void g_wait_vm() {
@@ -55,8 +73,8 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   constexpr int OFF_X = OFF_A + 2 * G_BS * G_KSTEP_BYTES;         // [wave][G_XR][32 samples][4 columns] doubles
   constexpr int OFF_Y = OFF_X + T_WAVES * G_XR * 1024;
   constexpr int OFF_RAW = OFF_Y + (YS ? T_WAVES * G_XR * 1024 : 0);  // [3][u | w][G_BS * 32] doubles
-  constexpr int OFF_F = OFF_RAW + 3 * G_RAW;                      // [2][unit][G_FU]: factors, line (chunk-in-block, sample) x NPT
-  constexpr int OFF_FS = OFF_F + 2 * 2 * G_FU;                    // [128] draws per replicate in the window
+  constexpr int OFF_F = OFF_RAW + 3 * G_RAW;                      // [3][unit][G_FU]: factors, line (chunk-in-block, sample) x NPT
+  constexpr int OFF_FS = OFF_F + 3 * 2 * G_FU;                    // [128] draws per replicate in the window
   static_assert(G_BS * 16 * NPT * 8 <= G_FU, "factor lines");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   uint32_t *fsum = reinterpret_cast<uint32_t *>(lds + OFF_FS);
@@ -110,6 +128,13 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[e][q] = (v16i)(0);
 
+#ifdef TXM_G_TIMING  // diagnostic build: cycles per phase of two workgroups (tools/i8g_timing.py)
+  long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tk0 = clock64();
+#define G_TICK(k) do { const long long t1_ = clock64(); tm[k] += t1_ - tk0; tk0 = t1_; } while (0)
+#else
+#define G_TICK(k) do {} while (0)
+#endif
   // first sample of chunk c of the window (the last tile of the series slides its window back)
   auto chunk_sample = [&](int c) -> int64_t {
     int64_t b0 = (t0 + (c >> 5)) * SM_T;
@@ -156,14 +181,22 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const double *src = ((WEIGHTED && wave >= 4) ? a.w : a.u) + chunk_sample(c);
     g_dma4(src, (uint32_t)lane * 4u, (uint32_t)(OFF_RAW + (B % 3) * G_RAW + (wave >> 2) * (G_BS * 256) + (wave & 3) * 256));
   };
-  // ---- factors of block B from raw buffer B % 3 into factor buffer B & 1 (waves 6 and 7: one sample per lane)
+  // ---- factors of block B from raw buffer B % 3 into factor buffer B % 3 (waves 6 and 7: one sample per lane)
   auto stage_factors = [&](int B) {
     if (wave < 6) return;  // uniform
     const int e = (int)threadIdx.x - 6 * 64;  // entry: chunk-in-block e >> 5, sample e & 31
     const double *raw = reinterpret_cast<const double *>(lds + OFF_RAW + (B % 3) * G_RAW);
+#ifdef TXM_G_TIMING
+    G_TICK(2);
+    double r0 = raw[e];
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0));
+    G_TICK(5);
+    const double du = (r0 - pu) * inv_du;
+#else
     const double du = (raw[e] - pu) * inv_du;
+#endif
     double pw = WEIGHTED ? raw[G_BS * 32 + e] * inv_w : 1.0;
-    double *f = reinterpret_cast<double *>(lds + OFF_F + (B & 1) * (2 * G_FU) + ((e >> 4) & 1) * G_FU) + (((e >> 5) * 16 + (e & 15)) * NPT);
+    double *f = reinterpret_cast<double *>(lds + OFF_F + (B % 3) * (2 * G_FU) + ((e >> 4) & 1) * G_FU) + (((e >> 5) * 16 + (e & 15)) * NPT);
     if constexpr (NPT > JN) f[JN] = pw;  // plain w for the y row set
 #pragma unroll
     for (int k = 0; k < J0; ++k) pw *= du;
@@ -270,51 +303,88 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // factors of block 0 visible; chunk 0's x slot free
   x_request(0);                                                    // chunk G_XR into slot 0
+  G_TICK(0);
 
   // ================= the blocks =================
   // Step s = B * 4 + p contracts chunk s (count words: ring buffer B & 1, X words: the wave's regions), slices chunk
-  // s + 1 (x from ring slot (p + 1) & 3, factors from buffer B & 1 line p) and requests chunk s + 5 into that slot.
+  // s + 1 (x from ring slot (p + 1) & 3, factors from buffer B % 3 line p) and requests chunk s + 5 into that slot.
+  //
+  // Software pipeline, no extra registers: the operands of step s + 1 are read INSIDE step s into the registers step s has
+  // just finished with -- count operand q behind the last row set's MFMA on quarter q, the B operand of row set fi behind
+  // that row set's stores (a wave's LDS operations execute in order) -- so a step starts with its operands in registers
+  // instead of a wait for eleven LDS reads.  (First cut: reads at the top of the step; the two waves of a SIMD leave every
+  // barrier in phase, so their waits coincided: matrix pipe 55 % busy, profiles/r05a_pmc_i8g.json.)  The block's barrier
+  // therefore sits INSIDE its last step, before the last row set: behind it the count words of the next block (landed:
+  // every wave waited for its pieces) are read for that block's first step.
+  //
   // vmcnt: a wave's DMAs complete in order.  Issue order: [block start: 2 count pieces, 1 raw piece], then per step NX x
   // pieces at its end.  The x of chunk s + 1 was requested at the end of step s - 4; newer than it at the top of step s
   // are the x pieces of steps s - 3 .. s - 1 (3 NX) and the three pieces of the one block start among the last four
-  // steps (this step's own when p = 0): 3 NX + 3 at every p.  At the end of a block its block-start pieces are older than
-  // the 4 NX x pieces of its steps.
+  // steps (this step's own when p = 0): 3 NX + 3 at every p.  At the barrier the block-start pieces are older than the
+  // 3 NX x pieces of the block's first three steps.
+  // L2-sharing hint (as in resample_i8t_kernel; bounded, no result depends on it): the replicate groups of a window run on
+  // one XCD and read the same x -- every tile (8 blocks) wave 0 publishes the tiles this group has finished and sleeps while
+  // it is more than G_LEAD tiles ahead of the slowest started group, so that the window's x is streamed from HBM once
+  uint32_t *pg = a.progress != nullptr ? a.progress + (size_t)win * 16 : nullptr;
+  v4i A[4];
+  v2i Bt[NS][2];
+  {
+    const uint32_t a_va0 = (uint32_t)OFF_A + (uint32_t)lane * 16u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) A[q] = *(lds_cv4)(lds + a_va0 + q * 1024);
+#pragma unroll
+    for (int fi = 0; fi < NS; ++fi) {
+      Bt[fi][0] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB));
+      Bt[fi][1] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB + 128));
+    }
+  }
 #pragma unroll 1
   for (int B = 0; B < nblk; ++B) {
+    if (pg != nullptr && wave == 0 && (B & 7) == 0) {  // uniform
+      const uint32_t done = (uint32_t)(B >> 3) + 1u;
+      if (lane == 0) __hip_atomic_store(&pg[grp & 15], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll 1
+      for (int spin = 0; spin < I8_THROTTLE_SPINS; ++spin) {
+        if (done <= g_min_progress(pg) + G_LEAD) break;
+        __builtin_amdgcn_s_sleep(32);
+      }
+    }
+    G_TICK(1);
     a_request(B + 1);
     raw_request(B + 2);
+    G_TICK(2);
     stage_factors(B + 1);
-    const uint32_t a_va = (uint32_t)(OFF_A + (B & 1) * (G_BS * G_KSTEP_BYTES)) + (uint32_t)lane * 16u;
-    uint32_t f_va = (uint32_t)(OFF_F + (B & 1) * (2 * G_FU) + ps * NPT * 8);
+    G_TICK(7);
+    // count words: this block's steps 1..3 from buffer B & 1, the next block's step 0 from the other buffer
+    uint32_t a_va = (uint32_t)(OFF_A + (B & 1) * (G_BS * G_KSTEP_BYTES)) + (uint32_t)lane * 16u;
+    uint32_t a_vn = (uint32_t)(OFF_A + ((B + 1) & 1) * (G_BS * G_KSTEP_BYTES)) + (uint32_t)lane * 16u;
+    uint32_t f_va = (uint32_t)(OFF_F + (B % 3) * (2 * G_FU) + ps * NPT * 8);
     uint32_t x_va = xring + (uint32_t)(ps * 32 + cl * 8);
-    asm volatile("" : "+v"(f_va), "+v"(x_va));  // opaque bases: the reads below take 16-bit immediate offsets
+    asm volatile("" : "+v"(f_va), "+v"(x_va), "+v"(a_va), "+v"(a_vn));  // opaque bases: the reads below take 16-bit immediate offsets
     t_static_for<G_BS>([&](auto pc) {
       constexpr int p = decltype(pc)::value;
       constexpr int slot = (p + 1) & 3;
+      G_TICK(3);
       g_wait_vm<3 * NX + 3>();
-      // operands of chunk s
-      v2i Bt[NS][2];
-#pragma unroll
-      for (int fi = 0; fi < NS; ++fi) {
-        Bt[fi][0] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB));
-        Bt[fi][1] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB + 128));
-      }
-      v4i A[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) A[q] = *(lds_cv4)(lds + a_va + p * G_KSTEP_BYTES + q * 1024);
-      // x of chunk s + 1
+      G_TICK(4);
+      // x of chunk s + 1 (y: read where its row set starts -- four registers fewer live across the power row sets)
       double dx[2], dy[2] = {0.0, 0.0};
 #pragma unroll
-      for (int uu = 0; uu < 2; ++uu) {
-        dx[uu] = (*(lds_cd)(lds + x_va + slot * 1024 + uu * 512) - px) * sc;
-        if constexpr (YS) dy[uu] = (*(lds_cd)(lds + x_va + (OFF_Y - OFF_X) + slot * 1024 + uu * 512) - py) * scy;
-      }
+      for (int uu = 0; uu < 2; ++uu) dx[uu] = (*(lds_cd)(lds + x_va + slot * 1024 + uu * 512) - px) * sc;
       t_static_for<NS>([&](auto fic) {
         constexpr int fi = decltype(fic)::value;
-        const v4i Bv = {Bt[fi][0][0], Bt[fi][0][1], Bt[fi][1][0], Bt[fi][1][1]};
+        constexpr bool last = fi == NS - 1;
+        if constexpr (p == G_BS - 1 && last) {
+          G_TICK(3);
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * NX) : "memory");
+          asm volatile("s_barrier" ::: "memory");  // the block's barrier
+          G_TICK(6);
+        }
+        if constexpr (YS && fi == JN) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) t_mfma<true>(acc[fi][q], A[q], Bv);
-        // the words of chunk s + 1, row set fi: behind the reads that took chunk s's (LDS operations of a wave execute in order)
+          for (int uu = 0; uu < 2; ++uu) dy[uu] = (*(lds_cd)(lds + x_va + (OFF_Y - OFF_X) + slot * 1024 + uu * 512) - py) * scy;
+        }
+        // factors of the sliced chunk, row set fi (read ahead of the MFMAs that cover their latency)
         double f[2];
 #pragma unroll
         for (int uu = 0; uu < 2; ++uu) {
@@ -326,17 +396,29 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
             f[uu] = *(lds_cd)(lds + f_va + uu * G_FU + (p * 16 * NPT + fi) * 8);
           }
         }
+        const v4i Bv = {Bt[fi][0][0], Bt[fi][0][1], Bt[fi][1][0], Bt[fi][1][1]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          t_mfma<true>(acc[fi][q], A[q], Bv);
+          if constexpr (last) {  // quarter q's count operand of the NEXT step into the registers just used for the last time
+            if constexpr (p == G_BS - 1) A[q] = *(lds_cv4)(lds + a_vn + q * 1024);
+            else A[q] = *(lds_cv4)(lds + a_va + (p + 1) * G_KSTEP_BYTES + q * 1024);
+          }
+        }
+        // the words of chunk s + 1, row set fi, and -- behind the stores -- the next step's B operand of the row set
         if constexpr (YS && fi == JN) produce_row(fic, f, dy);
         else produce_row(fic, f, dx);
+        Bt[fi][0] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB));
+        Bt[fi][1] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB + 128));
       });
       x_request(slot);  // chunk s + 5 (slot of chunk s + 1, just read)
     });
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 * NX) : "memory");
   }
 
   // ================= flush: int32 accumulators of the window -> its slot of the partial sums =================
   // D layout of v_mfma_i32_32x32x32_i8: column = lane & 31, row = 8 * (reg / 4) + 4 * (lane >> 5) + reg % 4
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (pg != nullptr && threadIdx.x == 0) __hip_atomic_store(&pg[grp & 15], 0xfffffff0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   auto odig_of = [](int w, int c) { return 4 * (w & 1) + c; };  // the u-row digit column c of wave w carries in its dead byte
   auto flush_tile = [&](v16i &T, int q, int rs) {
     uint32_t z = 0;
@@ -390,6 +472,11 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   for (int fi = 0; fi < NS; ++fi)
 #pragma unroll
     for (int q = 0; q < 4; ++q) flush_tile(acc[fi][q], q, fi);
+#ifdef TXM_G_TIMING
+  G_TICK(0);
+  if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 1064))
+    for (int k = 0; k < 8; ++k) a.wtab[a.nwin * I8_WT_STRIDE + ((blockIdx.x ? 1 : 0) * T_WAVES + wave) * 8 + k] = (double)tm[k];
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -397,8 +484,9 @@ template <int J0, int JN, bool WEIGHTED, bool YS>
 static int launch_pass_g(const I8Args &a, int K, const unsigned char *table, int64_t rep_begin, int n_grp, hipStream_t st) {
   constexpr int NS = JN + (YS ? 1 : 0);
   const size_t lds = (size_t)T_WAVES * NS * T_PB + 2 * G_BS * G_KSTEP_BYTES + (size_t)(YS ? 2 : 1) * T_WAVES * G_XR * 1024 + 3 * G_RAW +
-                     2 * 2 * G_FU + G_REPS * sizeof(uint32_t);
+                     3 * 2 * G_FU + G_REPS * sizeof(uint32_t);
   const dim3 grid((unsigned)(cdiv(a.nwin, 8) * 8 * n_grp));
+  if (a.progress != nullptr) TXM_HIP(hipMemsetAsync(a.progress, 0, (size_t)cdiv(a.nwin, 8) * 8 * 16 * sizeof(uint32_t), st));
   TXM_SET_MAX_LDS((&resample_i8g_kernel<J0, JN, WEIGHTED, YS>), lds);
   hipLaunchKernelGGL((resample_i8g_kernel<J0, JN, WEIGHTED, YS>), grid, dim3(T_BLOCK), lds, st, a, K, table, rep_begin, n_grp);
   TXM_LAUNCH_CHECK();

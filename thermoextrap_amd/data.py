@@ -144,6 +144,34 @@ def unstack_dataset(arr, layout) -> Dataset:
     return Dataset(out)
 
 
+def _concat_rec(a, b, dim):
+    """Two labelled sample arrays joined along ``dim`` (host or device resident; the dims of ``a`` rule)."""
+    from .moments import DeviceDataArray
+
+    if isinstance(a, DeviceDataArray) or isinstance(b, DeviceDataArray):
+        import torch
+
+        from . import engine
+
+        ta = a.tensor if isinstance(a, DeviceDataArray) else engine.to_device(as_labelled(a).values)
+        tb = b.tensor if isinstance(b, DeviceDataArray) else engine.to_device(as_labelled(b).values)
+        da = tuple(a.dims)
+        db = tuple(b.dims)
+        if set(da) != set(db):
+            raise ValueError(f"dims differ: {da} vs {db}")
+        tb = tb.permute([db.index(d) for d in da])
+        return DeviceDataArray(torch.cat([ta, tb], dim=da.index(dim)), da)
+    if not is_labelled(a) and not is_labelled(b):  # plain 1-D arrays (weights)
+        return np.concatenate([np.asarray(a), np.asarray(b)])
+    la, lb = as_labelled(a, dims=(dim,)), as_labelled(b, dims=(dim,))
+    if set(la.dims) != set(lb.dims):
+        raise ValueError(f"dims differ: {la.dims} vs {lb.dims}")
+    lb = lb.transpose(*la.dims)
+    out = DataArray(np.concatenate([np.asarray(la.values), np.asarray(lb.values)], axis=la.dims.index(dim)), la.dims)
+    out._inherit({k: v for k, v in la._coords.items() if dim not in v[0]})
+    return out
+
+
 def _need_dataarray(x, name=None):
     if not _labelled(x):
         raise TypeError(f"type({name})={type(x)} must be a DataArray.")
@@ -725,6 +753,23 @@ class DataCentralMoments(DataCentralMomentsBase):
         return self.new_like(dxduave=self.dxduave.reduce(**kws),
                              meta=self.meta.reduce(data=self, meta_kws=meta_kws, **kws))
 
+    def push_vals(self, xv, uv, weight=None, dim=MISSING, axis=MISSING):
+        """Streaming accumulation (north_star; cmomy ``push_vals``, which thermoextrap itself never calls -- SURVEY 0.7):
+        a new object whose state is this one's merged with the comoments of the chunk ``xv[rec, val...]``, ``uv[rec]``
+        (``weight[rec]``) -- one reduction of the chunk and one merge kernel, the old samples are not needed.  The state
+        must not carry a record dimension (reduce it first); ``DataCentralMoments.from_vals`` of a first chunk, then
+        ``push_vals`` of the others, equals ``from_vals`` of all samples to rounding."""
+        if self.x_is_u:
+            raise NotImplementedError("push_vals with x_is_u")
+        if dim is MISSING and axis is MISSING:
+            dim = self.rec_dim
+        if self.rec_dim in self.dxduave.val_dims:
+            raise ValueError(f"push_vals needs a state without the record dimension {self.rec_dim!r}: reduce() it first")
+        st = cmomy.CentralMomentsData(self.dxduave.device_values.clone(), mom_ndim=2, dims=self.dxduave.dims)
+        st._coords = dict(self.dxduave._coords)
+        st.push_vals(xv, uv, weight=weight, dim=dim, axis=axis)
+        return self.new_like(dxduave=st)
+
     def resample(self, sampler, dim=MISSING, axis=MISSING, rep_dim="rep", parallel=None, meta_kws=None, **kwargs):
         """Block bootstrap of the records (reference data.py:1000-1055)."""
         if dim is MISSING and axis is MISSING:
@@ -929,6 +974,23 @@ class DataCentralMomentsVals(DataCentralMomentsBase):
 
     def __len__(self):
         return int(self.uv.sizes[self.rec_dim])
+
+    def push_vals(self, xv, uv, weight=None):
+        """Append a chunk of samples (``xv``, ``uv`` along ``rec_dim``; ``weight`` iff this object has weights): the new
+        object holds the concatenated samples and the MERGED state -- the chunk is reduced and merged into the old state
+        (txm_push_vals), the old samples are not read again (cmomy ``push_vals``; north_star's streaming accumulation)."""
+        if self.x_is_u:
+            raise NotImplementedError("push_vals with x_is_u")
+        if (weight is None) != (self.weight is None):
+            raise ValueError("give a weight for the chunk exactly when the data object has weights")
+        if self.rec_dim in self.dxduave.val_dims:
+            raise ValueError("push_vals on a resampled / record-carrying state")
+        st = cmomy.CentralMomentsData(self.dxduave.device_values.clone(), mom_ndim=2, dims=self.dxduave.dims)
+        st._coords = dict(self.dxduave._coords)
+        st.push_vals(xv, uv, weight=weight, dim=self.rec_dim)
+        cat = lambda a, b: _concat_rec(a, b, self.rec_dim)  # noqa: E731
+        return self.new_like(uv=cat(self.uv, uv), xv=cat(self.xv, xv), weight=None if weight is None else cat(self.weight, weight),
+                             dxduave=st)
 
     def resample(self, sampler, dim=MISSING, axis=MISSING, rep_dim="rep", parallel=None, meta_kws=None, **kwargs):
         """Sample-level bootstrap: draws the sampler, then

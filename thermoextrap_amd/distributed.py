@@ -85,6 +85,40 @@ def broadcast_int(value: int, src: int = 0, group=None) -> int:
     return int(t.item())
 
 
+def broadcast_tensor(t: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
+    """Rank ``src``'s values of ``t`` on every rank (in place for the others; returns ``t``)."""
+    rank, w = world()
+    if w == 1:
+        return t
+    if t.is_cuda and dist.get_backend(group) == "gloo":  # rehearsal on a box without RCCL peers: through host memory
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+        return t
+    dist.broadcast(t, src=src, group=group)
+    return t
+
+
+def sharded_reduce(x: torch.Tensor, u: torch.Tensor, order: int, w: torch.Tensor | None = None, group=None, ops=None) -> torch.Tensor:
+    """SAMPLE-sharded reduce (SURVEY 8(e) partition (4)): every rank holds a shard ``x [N_r, C]``, ``u [N_r]`` (``w``) of one
+    long sample array -- the plain reduce is the HBM-bound leg of the path, and N / world samples per rank put every
+    GPU's HBM stacks to work.  Rank 0's pivot estimate is broadcast, every rank takes the power sums of ITS samples about
+    that pivot (they add exactly like the samples), ONE all-gather of the ``[C, 2, K]`` sums (a few KB) and a fixed-order
+    addition + shift give every rank the same state, bit for bit -- the state of the concatenated samples
+    (``cmomy.wrap_reduce_vals`` over the whole array: reference data.py:1632-1640) to rounding.  No bulk data moves.
+
+    ``ops``: (pivot, sums, finish) callables standing in for the engine's (the gloo tests run the collective logic on the CPU)."""
+    from . import engine
+
+    pivot_fn, sums_fn, finish_fn = ops if ops is not None else (
+        engine.reduce_pivot, lambda x_, u_, o_, p_, w_: engine.reduce_sums(x_, u_, o_, p_, w=w_), engine.sums_to_state)
+    piv = pivot_fn(x, u)                      # every rank estimates (same launch shape); rank 0's is the one used
+    piv = broadcast_tensor(piv, 0, group)
+    sums = sums_fn(x, u, order, piv, w)
+    stack = all_gather_slabs(sums.unsqueeze(0), None if world()[1] == 1 else [1] * world()[1], group)
+    return finish_fn(stack, piv)
+
+
 def replicate_offsets(nrep: int, world_size: int) -> list[int]:
     """First stream replicate of every rank's slab: rank r computes replicates
     ``[offsets[r], offsets[r] + counts[r])`` of ONE stream (one seed), so the gathered result is the one-rank

@@ -101,6 +101,93 @@ def reduce_vals(x: torch.Tensor, u: torch.Tensor, order: int, w: torch.Tensor | 
     return out[0] if squeeze else out
 
 
+def _rowmajor_operands(x, u, w):
+    """(x2, ls, lc, u, w, N, C, squeeze) for the sample-matrix entry points: (N, C) or (N,), either layout of reduce_vals."""
+    _check_f64_cuda(x, "x")
+    _check_f64_cuda(u, "u")
+    squeeze = x.dim() == 1
+    x2 = x.unsqueeze(1) if squeeze else x
+    if x2.dim() != 2:
+        raise ValueError("x must be (N,) or (N, C)")
+    N, C = x2.shape
+    if u.shape != (N,):
+        raise ValueError(f"u must have shape ({N},), got {tuple(u.shape)}")
+    u = u.contiguous()
+    if w is not None:
+        _check_f64_cuda(w, "w")
+        if w.shape != (N,):
+            raise ValueError("w must have shape (N,)")
+        w = w.contiguous()
+    if C == 1:
+        x2 = x2.contiguous()
+        ls, lc = 1, 1
+    elif x2.stride(1) == 1 and (N == 1 or x2.stride(0) >= C):
+        ls, lc = (x2.stride(0) if N > 1 else C), 1
+    elif x2.stride(0) == 1 and (C == 1 or x2.stride(1) >= N):
+        ls, lc = 1, x2.stride(1)
+    else:
+        x2 = x2.contiguous()
+        ls, lc = C, 1
+    return x2, ls, lc, u, w, N, C, squeeze
+
+
+def reduce_pivot(x: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+    """The library's pivot estimate {pivot_u, pivot_x[...]} for a (shard of a) sample matrix: (1 + C,) (txm_reduce_vals_pivot)."""
+    L = _L()
+    x2, ls, lc, u, _, N, C, _ = _rowmajor_operands(x, u, None)
+    piv = torch.empty(1 + C, dtype=F64, device="cuda")
+    check(L.txm_reduce_vals_pivot(_ptr(x2), ls, lc, _ptr(u), N, C, _ptr(piv), _stream()), "txm_reduce_vals_pivot")
+    return piv
+
+
+def reduce_sums(x: torch.Tensor, u: torch.Tensor, order: int, pivot: torch.Tensor, w: torch.Tensor | None = None) -> torch.Tensor:
+    """Weight-scaled power sums of the samples about ``pivot``: (C, 2, K) -- sums about one pivot add like the samples
+    (txm_reduce_vals_sums): shards of a sample-sharded reduce, chunks of a stream."""
+    L = _L()
+    x2, ls, lc, u, w, N, C, _ = _rowmajor_operands(x, u, w)
+    _check_f64_cuda(pivot, "pivot")
+    pivot = pivot.contiguous()
+    if pivot.numel() != 1 + C:
+        raise ValueError("pivot must have 1 + C entries")
+    out = torch.empty((C, 2, order + 1), dtype=F64, device="cuda")
+    ws = workspace(L.txm_reduce_vals_ws_bytes(N, C, order))
+    check(L.txm_reduce_vals_sums(_ptr(x2), ls, lc, _ptr(u), _ptr(w), N, C, order, _ptr(pivot), _ptr(out), _ptr(ws), ws.numel(),
+                                 _stream()), "txm_reduce_vals_sums")
+    return out
+
+
+def sums_to_state(sums: torch.Tensor, pivot: torch.Tensor) -> torch.Tensor:
+    """(n, C, 2, K) stacks of sums about ``pivot`` (or one (C, 2, K)) -> the cmomy state (C, 2, K) of all their samples,
+    the stacks added in index order (txm_sums_to_state)."""
+    L = _L()
+    _check_f64_cuda(sums, "sums")
+    s = sums.contiguous()
+    if s.dim() == 3:
+        s = s.unsqueeze(0)
+    n, C, two, K = s.shape
+    if two != 2 or pivot.numel() != 1 + C:
+        raise ValueError("sums must be (n, C, 2, K) with a (1 + C,) pivot")
+    out = torch.empty((C, 2, K), dtype=F64, device="cuda")
+    check(L.txm_sums_to_state(_ptr(s), n, _ptr(pivot.contiguous()), C, K - 1, _ptr(out), _stream()), "txm_sums_to_state")
+    return out
+
+
+def push_vals(state: torch.Tensor, x: torch.Tensor, u: torch.Tensor, w: torch.Tensor | None = None) -> torch.Tensor:
+    """Accumulate the samples (x, u[, w]) into ``state`` (C, 2, K) IN PLACE (cmomy push_vals; zeros = the empty
+    accumulator) and return it (txm_push_vals)."""
+    L = _L()
+    _check_f64_cuda(state, "state")
+    x2, ls, lc, u, w, N, C, squeeze = _rowmajor_operands(x, u, w)
+    st = state.unsqueeze(0) if (squeeze and state.dim() == 2) else state
+    if st.dim() != 3 or st.shape[0] != C or st.shape[1] != 2 or not st.is_contiguous():
+        raise ValueError(f"state must be a contiguous ({C}, 2, K) tensor, got {tuple(state.shape)}")
+    order = st.shape[2] - 1
+    ws = workspace(L.txm_push_vals_ws_bytes(N, C, order))
+    check(L.txm_push_vals(_ptr(st), _ptr(x2), ls, lc, _ptr(u), _ptr(w), N, C, order, _ptr(ws), ws.numel(), _stream()),
+          "txm_push_vals")
+    return state
+
+
 def reduce_vals_1d(u: torch.Tensor, mom: int, w: torch.Tensor | None = None) -> torch.Tensor:
     """u: (R, N) rows contiguous, or (N,).  Returns (R, mom+1) / (mom+1,)."""
     L = _L()

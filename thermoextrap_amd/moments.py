@@ -391,6 +391,35 @@ class CentralMomentsData:
         out = engine.resample_data(t, None, t.shape[-1] - 1)[0]
         return self._like(out.reshape(*oshape, 2, t.shape[-1]), tuple(others) + self.mom_dims)
 
+    def push_vals(self, x, *y, weight=None, axis=MISSING, dim=MISSING, **kw) -> "CentralMomentsData":
+        """cmomy ``CentralMomentsData.push_vals(x, u, weight=, dim=)``: accumulate new samples into this object IN PLACE
+        (north_star's streaming accumulation; thermoextrap itself never calls it -- SURVEY 0.7).  ``x``: samples along
+        ``dim`` with this object's value dims as the other dims, ``y[0]``: u along ``dim``.  A state of zeros is the empty
+        accumulator.  One reduction of the chunk + one merge kernel (txm_push_vals)."""
+        del kw
+        if self.mom_ndim != 2 or len(y) != 1:
+            raise NotImplementedError("push_vals: comoment states with exactly one y array")
+        xt, xdims = _dev_and_dims(x)
+        red = _resolve_dim(xdims, dim, axis)
+        ut, udims = _dev_and_dims(y[0])
+        if udims != (red,):
+            raise NotImplementedError("push_vals: uv must be 1-D along the sample dim")
+        cols = tuple(d for d in xdims if d != red)
+        if cols != self.val_dims:
+            raise ValueError(f"value dims of x {cols} do not match the state's {self.val_dims}")
+        N = xt.shape[xdims.index(red)]
+        wt = None
+        if weight is not None:
+            wt = _dev_and_dims(weight)[0] if (is_labelled(weight) or isinstance(weight, DeviceDataArray)) else engine.to_device(np.asarray(weight))
+        x2 = xt.movedim(xdims.index(red), 0)
+        x2 = x2.reshape(N, -1) if x2.dim() > 1 else x2
+        st = self._dev.reshape(-1, 2, self._dev.shape[-1])
+        if not st.is_contiguous() or st.data_ptr() != self._dev.data_ptr():
+            raise ValueError("push_vals needs a contiguous state")
+        engine.push_vals(st, x2 if x2.dim() == 2 else x2, ut.contiguous(), w=wt)
+        self._host = None
+        return self
+
     def resample_and_reduce(self, *, sampler, dim=MISSING, axis=MISSING, rep_dim="rep", parallel=None, **kw):
         """Block bootstrap (data.py:1048-1052): out dims = (other value dims with
         `dim` replaced by rep_dim in place, moments)."""

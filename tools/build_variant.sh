@@ -9,10 +9,10 @@ mkdir -p tools/build
 O=tools/build/$(basename "$OUT" .so)_$(basename "$SRC" .hip).o
 EXTRA=""
 if [ "$SRC" = txm_sampler.hip ]; then EXTRA="-ffp-contract=off"; fi
-if [ "$SRC" = txm_resample_i8t.hip ] || [ "$SRC" = txm_resample_i8w.hip ]; then EXTRA="-mllvm -amdgpu-mfma-vgpr-form -Wno-inline-asm"; fi   # as thermoextrap_amd/_build.py
+if [ "$SRC" = txm_resample_i8t.hip ] || [ "$SRC" = txm_resample_i8g.hip ]; then EXTRA="-mllvm -amdgpu-mfma-vgpr-form -Wno-inline-asm"; fi   # as thermoextrap_amd/_build.py
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-pass-failed $EXTRA "$@" -c $C/$SRC -o $O
 OBJS=""
-for f in txm_api txm_reduce txm_sampler txm_small txm_resample txm_resample_i8 txm_resample_i8t txm_resample_i8w txm_perturb; do
+for f in $(python3 -c "from thermoextrap_amd._build import SOURCES; print(' '.join(s[:-4] for s in SOURCES))"); do
   if [ "$f.hip" = "$SRC" ]; then OBJS="$OBJS $O"; else OBJS="$OBJS $C/build/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS
