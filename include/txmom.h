@@ -242,7 +242,8 @@ int txm_sampler_count_table(const txm_sampler_spec *spec_host, const uint32_t *c
 #define TXM_PATH_AUTO (-1)
 #define TXM_PATH_FP64 0
 #define TXM_PATH_INT8 1
-#define TXM_PATH_INT8_FUSED 2 /* the int8 path with the sampler drawn inside the contraction kernel (the round-3/4 kernel; what narrow states always run): for tests and A/B timing */
+#define TXM_PATH_INT8_FUSED 2 /* int8 path, wide states on the kernel that draws the per-sample counts in place (txm_resample_i8t.hip) */
+#define TXM_PATH_INT8_TABLE 3 /* int8 path, wide states on the count-table kernel wherever it applies (txm_resample_i8g.hip) */
 typedef struct txm_resample_opts {
   int32_t path;
   int32_t prep_valid;
@@ -259,6 +260,12 @@ int txm_resample_vals_info(const void *ws, int64_t N, int64_t C, int64_t nrep, i
                            int64_t *info_host, txm_stream stream);
 size_t txm_resample_prep_bytes(int64_t N, int64_t C, int64_t nrep, int order);
 size_t txm_resample_vals_ws_bytes(int64_t N, int64_t C, int64_t nrep, int order);
+/* the same for a call that will pass txm_resample_opts.path = `path` and a second matrix iff has_y: the int8 path's count-table
+ * kernel (wide states; txm_resample_vals_ws_bytes = path TXM_PATH_AUTO, has_y 0) keeps one byte per (replicate padded to 128,
+ * sample) in the workspace -- 12.8 GB per 128 replicates at N = 1e8.  A call given less workspace than this, but at least
+ * what TXM_PATH_INT8_FUSED needs, runs the kernel that draws the counts in place: same bits, other speed.  Callers bound the
+ * workspace by bootstrapping replicate slabs (spec.rep0): rows [a, b) of a call equal the (b - a)-replicate call at rep0 = a. */
+size_t txm_resample_vals_ws_bytes_opts(int64_t N, int64_t C, int64_t nrep, int order, int path, int has_y);
 /* extra workspace, BEHIND txm_resample_vals_ws_bytes(), that a call with opts.y needs (ws_bytes >= the sum); a call
  * without opts.y needs none of it (~2 GB at N = 1e8, C = 32, nrep = 1000) */
 size_t txm_resample_y_ws_bytes(int64_t N, int64_t C, int64_t nrep);

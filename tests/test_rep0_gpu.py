@@ -262,3 +262,42 @@ def test_second_matrix_means_equal_separate_order0_bootstrap(eng, orc):
     f = eng.DeviceSampler(12, 2, N).freq().cpu().numpy()
     yw = (y.cpu().numpy() * (f[1] * w.cpu().numpy())[:, None]).sum(0) / (f[1] * w.cpu().numpy()).sum()
     np.testing.assert_allclose(ym[1].cpu().numpy(), yw, rtol=1e-12)
+
+
+def test_workspace_budget_slabs_equal_the_unslabbed_rows_bit_for_bit(txm):
+    """engine.resample_vals bounds the library workspace (per-window partial sums, the int8 path's count table) by bootstrapping
+    the replicates in slabs of whole 128-replicate groups when it exceeds engine.WORKSPACE_BUDGET_BYTES: the slabs are the rows
+    of the unslabbed result, bit for bit, on every kernel, with and without a second matrix; one pre-pass block serves them all."""
+    import torch
+
+    from thermoextrap_amd import engine as eng
+
+    N, C = 1_200_000, 32
+    g = torch.Generator(device="cuda").manual_seed(4)
+    u = 174.85 + 5.31 * torch.randn(N, generator=g, dtype=torch.float64, device="cuda")
+    x = 0.2 + 1e-3 * u[:, None] + 0.05 * torch.randn(N, C, generator=g, dtype=torch.float64, device="cuda")
+    y = 0.5 * x + 1.0
+    L = eng._L()
+    for nrep, order, path, withy in ((1000, 2, None, False), (1000, 4, None, False), (700, 6, "int8_table", True), (600, 4, "int8_fused", False),
+                                    (520, 3, "fp64", False), (900, 1, None, True)):
+        s = eng.DeviceSampler(77, nrep, N, rep0=3)
+        kw = dict(sampler=s, path=path, y=y if withy else None)
+        old = eng.WORKSPACE_BUDGET_BYTES
+        try:
+            eng.WORKSPACE_BUDGET_BYTES = 1 << 50
+            whole = eng.resample_vals(x, u, order, **kw)
+            # a budget that forces at least three slabs
+            need = L.txm_resample_vals_ws_bytes_opts(N, C, nrep, order, eng._call_path(path), int(withy))
+            eng.WORKSPACE_BUDGET_BYTES = need // 3
+            assert eng._slab_size(L, N, C, nrep, order, eng._call_path(path), withy) < nrep
+            prep = eng.ResamplePrep()
+            parts = eng.resample_vals(x, u, order, prep=prep, **kw)
+            again = eng.resample_vals(x, u, order, prep=prep, **kw)
+        finally:
+            eng.WORKSPACE_BUDGET_BYTES = old
+        a, b, c = (whole, parts, again) if not withy else (whole[0], parts[0], again[0])
+        assert torch.equal(a, b) and torch.equal(a, c), (nrep, order, path)
+        if withy:
+            assert torch.equal(whole[1], parts[1]), (nrep, order, path)
+        if path != "fp64":
+            assert prep.misses == 1 and prep.hits >= 3, (prep.misses, prep.hits)

@@ -89,6 +89,7 @@ SIGNATURES = {
     "txm_resample_y_ws_bytes": (c_size, [c_i64, c_i64, c_i64]),
     "txm_resample_i8_supported": (c_int, [c_i64, c_i64, c_i64, c_int]),
     "txm_resample_vals_ws_bytes": (c_size, [c_i64, c_i64, c_i64, c_int]),
+    "txm_resample_vals_ws_bytes_opts": (c_size, [c_i64, c_i64, c_i64, c_int, c_int, c_int]),
     "txm_resample_vals": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_i64, c_i64, c_int, c_i64,
                                   c_void_p, ct.POINTER(SamplerSpec), c_void_p, c_void_p, c_void_p,
                                   ct.POINTER(ResampleOpts), c_void_p, c_size, c_void_p]),

@@ -757,7 +757,7 @@ struct I8Plan {
   size_t off_fbx, off_fbu, off_prog, prog_bytes, off_stats, off_prep;
   // the per-sample count table of the call's replicates (txm_count_table.hip; wide states: the contraction kernel without a
   // sampler inside, txm_resample_i8g.hip) -- 0 bytes for shapes that never take that kernel
-  size_t off_table, table_bytes, off_gprog;  // (+ sixteen progress words per window: the L2-sharing hint of that kernel)
+  size_t off_table, table_bytes, off_gprog, total_table;  // (+ sixteen progress words per window: the L2-sharing hint of that kernel)
   // second sample matrix (txm_resample_opts.y) carried by the int8 kernel: its per-window partial sums, the FP64
   // fallback's sums for it, the sums themselves [nrep][C] (2 doubles each) and its pre-pass tables inside the prep block
   size_t off_py, off_fby, prep_ypiv, prep_ywt, prep_yflag;
@@ -810,10 +810,13 @@ static I8Plan plan_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   p.off_py = p.off_stats + align_up((size_t)cdiv(p.ntiles, p.win_tiles < 16 ? p.win_tiles : 16) * 100 * sizeof(double), 256);
   p.off_fby = p.off_py + align_up((size_t)p.nwin * p.nrep_pad * 8 * I8_CPAD * sizeof(double), 256);
   p.off_prep = p.off_fby + align_up((size_t)p.fb.n_chunks * p.fb.nrep_pad * p.fb.C_pad * sizeof(double), 256);
-  p.off_table = p.off_prep + align_up(p.prep_total, 256);
+  // the count table sits LAST: `total` is the size without it, `total_table` with it -- a call runs the table kernel when
+  // the rule (table_kernel_pays) or the caller asks for it AND the workspace it was given reaches total_table
+  p.off_gprog = p.off_prep + align_up(p.prep_total, 256);
+  p.off_table = p.off_gprog + align_up((size_t)cdiv(p.nwin, 8) * 8 * 16 * sizeof(uint32_t), 256);
   p.table_bytes = (C > 16 && N >= SM_T) ? count_table_bytes(p.ntiles, nrep) : 0;
-  p.off_gprog = p.off_table + align_up(p.table_bytes, 256);
-  p.total = p.off_gprog + (p.table_bytes ? align_up((size_t)cdiv(p.nwin, 8) * 8 * 16 * sizeof(uint32_t), 256) : 0);
+  p.total = p.off_table;
+  p.total_table = p.off_table + align_up(p.table_bytes, 256);
   return p;
 }
 
@@ -833,11 +836,28 @@ static constexpr bool throttle_on() {
 #endif
 }
 
+// Wide states on the int8 path: which of its two contraction kernels.  They agree bit for bit (the same int32 sums, the same
+// flush), so this is a rule on speed alone -- measured on MI355X, pre-pass block kept, ms per call fused / table
+// (tools/i8g_sweep.py, profiles/r05_sweep.txt; N = 1e8, C = 32, nrep = 1000):
+//   order 0: 92.5 / 74.1   1: 95.1 / 82.9   2: 115.8 / 99.3   3: 134.2 / 137.2   4: 162.8 / 162.7   5: 231.7 / 174.0
+//   6: 259.9 / 217.7   7: 268.2 / 226.4;   with a second matrix (N = 1e7, nrep = 256): order 1: 4.47 / 3.94, 4: 8.36 / 5.97,
+//   6: 8.79 / 7.58.
+// The table kernel takes at most three row sets per pass and pays the count-table generator (28 ms per 1e11 counts) once per
+// call: orders 3 and 4 -- four and five row sets, two passes against the fused kernel's one -- are a tie and stay on the
+// fused kernel (no table in the workspace); every other order, and every call with a second matrix, is 13 - 40 % faster.
+// Replicates come in groups of 128 there, 64 on the fused kernel: a call whose padding to 128 wastes much more than its
+// padding to 64 stays fused (nrep = 64: 1.80 / 2.66 ms; 130: 3.45 / 3.92; 100: 2.87 / 2.93; 200, 256, 1000: the table above).
+static bool table_kernel_pays(int64_t nrep, int K, bool has_y) {
+  const int64_t pad128 = cdiv(nrep, G_REPS) * G_REPS, pad64 = cdiv(nrep, I8_REPS) * I8_REPS;
+  if (4 * pad128 > 5 * pad64) return false;
+  return has_y || (K != 4 && K != 5);
+}
+
 static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K, int call_path = TXM_PATH_AUTO) {
   if (!i8_supported(N, C, nrep, K)) return false;
   const int ov = call_path != TXM_PATH_AUTO ? call_path : path_override();
   if (ov == TXM_PATH_FP64) return false;
-  if (ov == TXM_PATH_INT8 || ov == TXM_PATH_INT8_FUSED) return true;
+  if (ov == TXM_PATH_INT8 || ov == TXM_PATH_INT8_FUSED || ov == TXM_PATH_INT8_TABLE) return true;
   // measured on MI355X (tools/i8_sweep.py, N = 1e7; tools/ab_order.py, N = 1e8): C <= 16 runs one 16-column FP64
   // block and stays ahead; with two blocks the int8 kernel wins from one full replicate group on at order >= 3
   // (order 4: 1.2x at 64 replicates, 1.5x at 128, 1.6x from 400), from 128 replicates at orders 1 and 2 (nrep = 128:
@@ -867,7 +887,7 @@ static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K, int call_path = TX
 using namespace txm;
 
 extern "C" int txm_set_resample_path(int path) {
-  TXM_REQUIRE(path == -1 || path == TXM_PATH_FP64 || path == TXM_PATH_INT8 || path == TXM_PATH_INT8_FUSED, "set_resample_path: %d is not a path", path);
+  TXM_REQUIRE(path == -1 || path == TXM_PATH_FP64 || path == TXM_PATH_INT8 || path == TXM_PATH_INT8_FUSED || path == TXM_PATH_INT8_TABLE, "set_resample_path: %d is not a path", path);
   g_path_override = path;
   return TXM_OK;
 }
@@ -944,14 +964,26 @@ static size_t y_extra_bytes(int64_t N, int64_t C, int64_t nrep) {
   return align_up((size_t)nrep * C * 2 * sizeof(double), 256) + y_main_bytes(N, C, nrep);
 }
 
-extern "C" size_t txm_resample_vals_ws_bytes(int64_t N, int64_t C, int64_t nrep, int order) {
+// path / has_y: what the call will pass in txm_resample_opts -- they decide whether the int8 path's count table (one byte
+// per replicate and sample, replicates padded to 128) is part of the workspace: TXM_PATH_AUTO / TXM_PATH_INT8 follow the
+// library's rule (table_kernel_pays), TXM_PATH_INT8_TABLE always asks for it, TXM_PATH_FP64 / _INT8_FUSED never.  A call
+// handed less than this runs the kernel without the table.
+extern "C" size_t txm_resample_vals_ws_bytes_opts(int64_t N, int64_t C, int64_t nrep, int order, int path, int has_y) {
   if (N < 1 || C < 1 || nrep < 1 || order < 0 || order > TXM_MAX_ORDER) return 0;
   size_t n = plan_resample(N, C, nrep, order + 1).total;
   if (i8_supported(N, C, nrep, order + 1)) {
-    const size_t m = plan_i8(N, C, nrep, order + 1).total;
+    const I8Plan q = plan_i8(N, C, nrep, order + 1);
+    const int eff = path != TXM_PATH_AUTO ? path : path_override();
+    const bool table = q.table_bytes != 0 && eff != TXM_PATH_FP64 && eff != TXM_PATH_INT8_FUSED &&
+                       (eff == TXM_PATH_INT8_TABLE || table_kernel_pays(nrep, order + 1, has_y != 0));
+    const size_t m = table ? q.total_table : q.total;
     if (m > n) n = m;
   }
   return align_up(n, 256);
+}
+
+extern "C" size_t txm_resample_vals_ws_bytes(int64_t N, int64_t C, int64_t nrep, int order) {
+  return txm_resample_vals_ws_bytes_opts(N, C, nrep, order, TXM_PATH_AUTO, 0);
 }
 
 // ... and the scratch a call with opts.y needs BEHIND those bytes when the kernel of the main call does not carry the
@@ -1095,8 +1127,10 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
     // wide states: the per-sample counts of the call's replicates as a table in HBM (built once, shared by the column groups
     // and the passes) and the contraction kernel without a sampler inside (txm_resample_i8g.hip).  Misaligned operands and
     // TXM_PATH_INT8_FUSED keep the kernel that draws in place; narrow states and narrow tail groups always run it.
-    const bool fused_only = path == TXM_PATH_INT8_FUSED || (path == TXM_PATH_AUTO && path_override() == TXM_PATH_INT8_FUSED);
-    const bool table_call = !fused_only && q.table_bytes != 0 && i8g_applicable(x, ldx_s, C, y, ldy_s);
+    const int eff_path = path != TXM_PATH_AUTO ? path : path_override();
+    const bool fused_only = eff_path == TXM_PATH_INT8_FUSED;
+    const bool table_call = !fused_only && q.table_bytes != 0 && ws_bytes >= q.total_table && i8g_applicable(x, ldx_s, C, y, ldy_s) &&
+                            (eff_path == TXM_PATH_INT8_TABLE || table_kernel_pays(nrep, K, y != nullptr));
     const bool with_y = y != nullptr && (table_call || i8t_carries_y(C, K));
     if (ws_bytes < q.total) {
       set_error("resample_vals: workspace too small (%zu < %zu)", ws_bytes, q.total);
@@ -1326,12 +1360,12 @@ extern "C" int txm_resample_vals(const double *x, int64_t ldx_s, int64_t ldx_c, 
   o.path = TXM_PATH_AUTO; o.prep_valid = 0; o.prep = nullptr; o.prep_bytes = 0; o.info = nullptr;
   o.y = nullptr; o.ldy_s = 0; o.out_y = nullptr;
   if (opts) o = *opts;
-  TXM_REQUIRE(o.path == TXM_PATH_AUTO || o.path == TXM_PATH_FP64 || o.path == TXM_PATH_INT8 || o.path == TXM_PATH_INT8_FUSED,
+  TXM_REQUIRE(o.path == TXM_PATH_AUTO || o.path == TXM_PATH_FP64 || o.path == TXM_PATH_INT8 || o.path == TXM_PATH_INT8_FUSED || o.path == TXM_PATH_INT8_TABLE,
               "resample_vals: opts.path %d is not a path", (int)o.path);
   TXM_REQUIRE((o.y == nullptr) == (o.out_y == nullptr), "resample_vals: opts.y and opts.out_y go together");
   TXM_REQUIRE(o.y == nullptr || o.ldy_s >= C, "resample_vals: opts.ldy_s < C");
   hipStream_t st = (hipStream_t)stream;
-  const size_t main_bytes = txm_resample_vals_ws_bytes(N, C, nrep, order);
+  const size_t main_bytes = txm_resample_vals_ws_bytes_opts(N, C, nrep, order, o.path, o.y != nullptr);
   const size_t avail = ws_bytes < main_bytes ? ws_bytes : main_bytes;
   bool y_done = false;
   int rc = resample_vals_impl(x, ldx_s, u, w, N, C, order, nrep, freq, spec, counts, pivot, out, o.path, o.prep,
@@ -1437,7 +1471,7 @@ static bool use_i8_batched(int64_t S, int64_t N, int64_t C, int64_t nrep, int K,
   if (!i8_supported(N, C, nrep, K) || i8t_narrow_nq(C, K) == 0) return false;
   const int ov = call_path != TXM_PATH_AUTO ? call_path : path_override();
   if (ov == TXM_PATH_FP64) return false;
-  if (ov == TXM_PATH_INT8 || ov == TXM_PATH_INT8_FUSED) return true;
+  if (ov == TXM_PATH_INT8 || ov == TXM_PATH_INT8_FUSED || ov == TXM_PATH_INT8_TABLE) return true;
   // A rule on the STATE's shape only -- never on how many states share the launch: the states of a collection must take the
   // same kernel whichever rank (or workspace-bounded group) they are bootstrapped in, or a sharded run would differ from the
   // one-GPU run in the last bits.  The single-state rule for narrow states (use_i8): long series at any replicate count,
@@ -1627,7 +1661,7 @@ extern "C" int txm_resample_vals_batched_opts(const txm_state_ptrs *states_host,
                                               const txm_sampler_spec *spec, const uint32_t *counts, double *out,
                                               const txm_resample_opts *opts, void *ws, size_t ws_bytes, txm_stream stream) {
   const int call_path = opts ? opts->path : TXM_PATH_AUTO;
-  TXM_REQUIRE(call_path == TXM_PATH_AUTO || call_path == TXM_PATH_FP64 || call_path == TXM_PATH_INT8 || call_path == TXM_PATH_INT8_FUSED,
+  TXM_REQUIRE(call_path == TXM_PATH_AUTO || call_path == TXM_PATH_FP64 || call_path == TXM_PATH_INT8 || call_path == TXM_PATH_INT8_FUSED || call_path == TXM_PATH_INT8_TABLE,
               "resample_vals_batched: opts.path %d is not a path", call_path);
   TXM_REQUIRE(!(opts && (opts->y || opts->out_y)), "resample_vals_batched: no second sample matrix on the batched entry");
   TXM_REQUIRE(states_host && out && ws, "resample_vals_batched: null pointer");

@@ -26,8 +26,13 @@
 namespace txm {
 
 constexpr int G_BS = 4;  // k-steps per block (one barrier per block)
-constexpr int G_XR = 4;  // chunks in a wave's x ring (= G_BS: ring slots are compile-time offsets)
+constexpr int G_XR = 4;  // chunks in a wave's x ring when x is requested step by step (second-matrix passes; = G_BS)
 static_assert(G_XR == G_BS && G_BS == 4, "the wait counts below are written for blocks of four k-steps");
+// ... and when a block's four x chunks are requested together with its count words (passes without a second matrix): eight.
+// Why: on gfx950 a wave's DS instructions queue BEHIND its outstanding LDS-DMA pieces -- a ds_read issued after a
+// global_load_lds waited ~800-1100 cycles for it (phase clocks of the first cut, profiles/r05_experiments.md) -- so one x piece
+// per k-step stalled every step's LDS reads for an L2 round trip.  One DMA event per block instead of five.
+constexpr int G_XRB = 8;
 constexpr int G_FU = 2176;           // bytes between the factor lines of a lane's two 16-sample units (> 2040: no ds_read2 pairing)
 constexpr int G_RAW = 2 * G_BS * 256;  // one raw buffer: u then w of a block's chunks
 #ifndef TXM_G_LEAD
@@ -37,9 +42,15 @@ constexpr uint32_t G_LEAD = TXM_G_LEAD;  // tiles a replicate group may run ahea
 
 // LDS-DMA: 16 (4) bytes per lane from saddr + voff to the LDS address in M0 + 16 (4) * lane
 __device__ __forceinline__ void g_dma16(const void *sbase, uint32_t voff, uint32_t lds_dst) {
+#ifdef TXM_G_NO_DMA  // ablation build
+  return;
+#endif
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_dst) : "memory", "m0");
 }
 __device__ __forceinline__ void g_dma4(const void *sbase, uint32_t voff, uint32_t lds_dst) {
+#ifdef TXM_G_NO_DMA
+  return;
+#endif
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_dst) : "memory", "m0");
 }
 // sixteen progress words of a window, read past the scalar cache (glc): SMEM counts on lgkmcnt, so a poll does not touch
@@ -70,9 +81,11 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   constexpr int NX = YS ? 2 : 1;                                 // x-ring DMAs per k-step
   constexpr int WREG = NS * T_PB;
   constexpr int OFF_A = T_WAVES * WREG;                           // [2][G_BS][4096] count words
-  constexpr int OFF_X = OFF_A + 2 * G_BS * G_KSTEP_BYTES;         // [wave][G_XR][32 samples][4 columns] doubles
-  constexpr int OFF_Y = OFF_X + T_WAVES * G_XR * 1024;
-  constexpr int OFF_RAW = OFF_Y + (YS ? T_WAVES * G_XR * 1024 : 0);  // [3][u | w][G_BS * 32] doubles
+  constexpr bool XBLK = !YS;                                      // x requested per block (8-slot ring) / per step (4 slots, + y)
+  constexpr int XRN = XBLK ? G_XRB : G_XR;
+  constexpr int OFF_X = OFF_A + 2 * G_BS * G_KSTEP_BYTES;         // [wave][XRN][32 samples][4 columns] doubles
+  constexpr int OFF_Y = OFF_X + T_WAVES * XRN * 1024;
+  constexpr int OFF_RAW = OFF_Y + (YS ? T_WAVES * XRN * 1024 : 0);  // [3][u | w][G_BS * 32] doubles
   constexpr int OFF_F = OFF_RAW + 3 * G_RAW;                      // [3][unit][G_FU]: factors, line (chunk-in-block, sample) x NPT
   constexpr int OFF_FS = OFF_F + 3 * 2 * G_FU;                    // [128] draws per replicate in the window
   static_assert(G_BS * 16 * NPT * 8 <= G_FU, "factor lines");
@@ -145,14 +158,32 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // (L & 1) of row L >> 1
   const uint32_t xvoff = (uint32_t)(((lane >> 1) * a.ldx_s + a.col0 + 4 * qsrc) * 8 + (lane & 1) * 16);
   const uint32_t yvoff = YS ? (uint32_t)(((lane >> 1) * a.ldy_s + a.col0 + 4 * qsrc) * 8 + (lane & 1) * 16) : 0u;
-  const uint32_t xring = (uint32_t)(OFF_X + wave * G_XR * 1024), yring = (uint32_t)(OFF_Y + wave * G_XR * 1024);
+  const uint32_t xring = (uint32_t)(OFF_X + wave * XRN * 1024), yring = (uint32_t)(OFF_Y + wave * XRN * 1024);
   int cq = 0;  // chunk of the next x request (uniform)
   const char *xq = reinterpret_cast<const char *>(a.x + chunk_sample(0) * a.ldx_s);
   const char *yq = YS ? reinterpret_cast<const char *>(a.y + chunk_sample(0) * a.ldy_s) : nullptr;
   const int64_t xstep = 32 * a.ldx_s * 8, ystep = YS ? 32 * a.ldy_s * 8 : 0;
+  // Who issues the DMA pieces (passes without a second matrix): the OLDER wave of every SIMD -- waves 0..3; wave w + 4 shares
+  // wave w's SIMD and loses the issue arbitration to it, so the younger waves set the pace of a block (phase clocks: step
+  // bodies 917 against 713 cycles) while the older ones wait a quarter of their time at the barrier.  The older waves therefore
+  // request everything (a piece costs its issuer ~100 cycles: 56 pieces per block and CU), also their partner's x columns, and
+  // stage the factors; landing is published by the block's barrier, behind every issuer's vmcnt(0).
+  const bool loader = !XBLK || wave < 4;  // uniform
+  const int qsrc2 = 4 * (wave + 4) < a.C ? wave + 4 : 0;
+  const uint32_t xvoff2 = (uint32_t)(((lane >> 1) * a.ldx_s + a.col0 + 4 * qsrc2) * 8 + (lane & 1) * 16);
   auto x_request = [&](int slot) {  // chunk cq -> ring slot; chunks past the window re-read its last one
-    g_dma16(xq, xvoff, xring + (uint32_t)slot * 1024u);
-    if constexpr (YS) g_dma16(yq, yvoff, yring + (uint32_t)slot * 1024u);
+#ifdef TXM_G_NO_XDMA  // ablation build
+    if (slot >= 0) { ++cq; return; }
+#endif
+    if constexpr (XBLK) {
+      if (loader) {
+        g_dma16(xq, xvoff, xring + (uint32_t)slot * 1024u);
+        g_dma16(xq, xvoff2, xring + (uint32_t)(4 * XRN * 1024) + (uint32_t)slot * 1024u);  // wave + 4's ring
+      }
+    } else {
+      g_dma16(xq, xvoff, xring + (uint32_t)slot * 1024u);
+      if constexpr (YS) g_dma16(yq, yvoff, yring + (uint32_t)slot * 1024u);
+    }
     ++cq;
     if (cq < nsteps) {
       if ((cq & 31) == 0) {  // a new tile (the slid last one does not follow its predecessor in memory)
@@ -168,26 +199,46 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // ---- count words of block B -> ring buffer B & 1: the wave's two 1-KiB pieces
   auto a_request = [&](int B) {
     const int Bc = B < nblk ? B : nblk - 1;
-    const unsigned char *src = tab + (size_t)Bc * (G_BS * G_KSTEP_BYTES) + (size_t)wave * 2048;
-    const uint32_t dst = (uint32_t)(OFF_A + (B & 1) * (G_BS * G_KSTEP_BYTES) + wave * 2048);
-    g_dma16(src, (uint32_t)lane * 16u, dst);
-    g_dma16(src + 1024, (uint32_t)lane * 16u, dst + 1024u);
+#ifdef TXM_G_NO_ADMA  // ablation build
+    if (Bc >= 0) return;
+#endif
+    if constexpr (XBLK) {  // four 1-KiB pieces per loader wave
+      if (!loader) return;
+      const unsigned char *src = tab + (size_t)Bc * (G_BS * G_KSTEP_BYTES) + (size_t)wave * 4096;
+      const uint32_t dst = (uint32_t)(OFF_A + (B & 1) * (G_BS * G_KSTEP_BYTES) + wave * 4096);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) g_dma16(src + i * 1024, (uint32_t)lane * 16u, dst + (uint32_t)i * 1024u);
+    } else {
+      const unsigned char *src = tab + (size_t)Bc * (G_BS * G_KSTEP_BYTES) + (size_t)wave * 2048;
+      const uint32_t dst = (uint32_t)(OFF_A + (B & 1) * (G_BS * G_KSTEP_BYTES) + wave * 2048);
+      g_dma16(src, (uint32_t)lane * 16u, dst);
+      g_dma16(src + 1024, (uint32_t)lane * 16u, dst + 1024u);
+    }
   };
   // ---- raw u / w of factor block B (the chunks B * G_BS + 1 .. B * G_BS + G_BS, i.e. what block B's k-steps slice):
   // waves 0..3 one chunk of u each, waves 4..7 one chunk of w (u again when unweighted: never read)
   auto raw_request = [&](int B) {
     int c = B * G_BS + 1 + (wave & 3);
     if (c > nsteps - 1) c = nsteps - 1;
-    const double *src = ((WEIGHTED && wave >= 4) ? a.w : a.u) + chunk_sample(c);
-    g_dma4(src, (uint32_t)lane * 4u, (uint32_t)(OFF_RAW + (B % 3) * G_RAW + (wave >> 2) * (G_BS * 256) + (wave & 3) * 256));
+    if constexpr (XBLK) {  // loader wave w: chunk w of u, and of w
+      if (!loader) return;
+      const int64_t i0 = chunk_sample(c);
+      g_dma4(a.u + i0, (uint32_t)lane * 4u, (uint32_t)(OFF_RAW + (B % 3) * G_RAW + wave * 256));
+      if constexpr (WEIGHTED) g_dma4(a.w + i0, (uint32_t)lane * 4u, (uint32_t)(OFF_RAW + (B % 3) * G_RAW + G_BS * 256 + wave * 256));
+    } else {
+      const double *src = ((WEIGHTED && wave >= 4) ? a.w : a.u) + chunk_sample(c);
+      g_dma4(src, (uint32_t)lane * 4u, (uint32_t)(OFF_RAW + (B % 3) * G_RAW + (wave >> 2) * (G_BS * 256) + (wave & 3) * 256));
+    }
   };
-  // ---- factors of block B from raw buffer B % 3 into factor buffer B % 3 (waves 6 and 7: one sample per lane)
+  // ---- factors of block B from raw buffer B % 3 into factor buffer B % 3 (two waves, one sample per lane: waves 0 and 1 where
+  // the older waves load, else waves 6 and 7)
   auto stage_factors = [&](int B) {
-    if (wave < 6) return;  // uniform
-    const int e = (int)threadIdx.x - 6 * 64;  // entry: chunk-in-block e >> 5, sample e & 31
+    constexpr int SW = XBLK ? 0 : 6;  // first staging wave
+    if (wave < SW || wave >= SW + 2) return;  // uniform
+    const int e = (int)threadIdx.x - SW * 64;  // entry: chunk-in-block e >> 5, sample e & 31
     const double *raw = reinterpret_cast<const double *>(lds + OFF_RAW + (B % 3) * G_RAW);
 #ifdef TXM_G_TIMING
-    G_TICK(2);
+    G_TICK(1);
     double r0 = raw[e];
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0));
     G_TICK(5);
@@ -229,7 +280,11 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       lo[uu] = (uint32_t)bits ^ 0x80808080u;
       hi[uu] = (uint32_t)(bits >> 32) ^ 0x00008080u;
     }
+#ifdef TXM_G_NO_OVERLAY  // ablation build
+    if (false) {
+#else
     if (fi < JN && ofi == fi) {  // wave-uniform: this wave carries digits of the row set's u-row monomial in byte 7
+#endif
       // (the permute as a volatile asm: the compiler must keep the branch -- if-converted, all eight waves executed the
       // overlay of all three row sets, 30 vector instructions per k-step instead of 10 on six waves)
 #pragma unroll
@@ -271,13 +326,19 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   raw_request(0);
   raw_request(1);
   a_request(0);
+  if constexpr (XBLK) {  // chunk c lives in slot (c - 1) & 7: chunk 0 in slot 7, block 0's chunks 1..4 in slots 0..3
+    x_request(7);
 #pragma unroll
-  for (int c = 0; c < G_XR; ++c) x_request(c);
+    for (int c = 0; c < G_BS; ++c) x_request(c);
+  } else {
+#pragma unroll
+    for (int c = 0; c < G_XR; ++c) x_request(c);
+  }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   stage_factors(0);
   {
     // the X words of chunk 0 (no matrix work yet)
-    const uint32_t xa = xring + (uint32_t)(ps * 32 + cl * 8);
+    const uint32_t xa = xring + (uint32_t)(ps * 32 + cl * 8) + (XBLK ? 7u * 1024u : 0u);
     double dx[2], dy[2] = {0.0, 0.0};
 #pragma unroll
     for (int uu = 0; uu < 2; ++uu) {
@@ -302,7 +363,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     });
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // factors of block 0 visible; chunk 0's x slot free
-  x_request(0);                                                    // chunk G_XR into slot 0
+  if constexpr (!XBLK) x_request(0);                               // chunk G_XR into slot 0
   G_TICK(0);
 
   // ================= the blocks =================
@@ -326,6 +387,9 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // one XCD and read the same x -- every tile (8 blocks) wave 0 publishes the tiles this group has finished and sleeps while
   // it is more than G_LEAD tiles ahead of the slowest started group, so that the window's x is streamed from HBM once
   uint32_t *pg = a.progress != nullptr ? a.progress + (size_t)win * 16 : nullptr;
+#ifdef TXM_G_PRIO  // experiment: the younger wave of every SIMD at a higher issue priority
+  if (wave >= 4) __builtin_amdgcn_s_setprio(TXM_G_PRIO);
+#endif
   v4i A[4];
   v2i Bt[NS][2];
   {
@@ -350,22 +414,28 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       }
     }
     G_TICK(1);
-    a_request(B + 1);
-    raw_request(B + 2);
-    G_TICK(2);
+    // (the staging reads first: a DS read issued right behind the block's DMA pieces waited ~1000 cycles for them on the two
+    // staging waves -- phase clocks, profiles/r05_experiments.md)
     stage_factors(B + 1);
     G_TICK(7);
+    a_request(B + 1);
+    raw_request(B + 2);
+    if constexpr (XBLK) {  // the next block's x: chunks 4 (B + 1) + 1 .. + 4 into the ring half this block does not read
+#pragma unroll
+      for (int i = 0; i < G_BS; ++i) x_request(4 * ((B + 1) & 1) + i);
+    }
+    G_TICK(2);
     // count words: this block's steps 1..3 from buffer B & 1, the next block's step 0 from the other buffer
     uint32_t a_va = (uint32_t)(OFF_A + (B & 1) * (G_BS * G_KSTEP_BYTES)) + (uint32_t)lane * 16u;
     uint32_t a_vn = (uint32_t)(OFF_A + ((B + 1) & 1) * (G_BS * G_KSTEP_BYTES)) + (uint32_t)lane * 16u;
     uint32_t f_va = (uint32_t)(OFF_F + (B % 3) * (2 * G_FU) + ps * NPT * 8);
-    uint32_t x_va = xring + (uint32_t)(ps * 32 + cl * 8);
+    uint32_t x_va = xring + (uint32_t)(ps * 32 + cl * 8) + (XBLK ? (uint32_t)((B & 1) * 4096) : 0u);
     asm volatile("" : "+v"(f_va), "+v"(x_va), "+v"(a_va), "+v"(a_vn));  // opaque bases: the reads below take 16-bit immediate offsets
     t_static_for<G_BS>([&](auto pc) {
       constexpr int p = decltype(pc)::value;
-      constexpr int slot = (p + 1) & 3;
+      constexpr int slot = XBLK ? p : ((p + 1) & 3);
       G_TICK(3);
-      g_wait_vm<3 * NX + 3>();
+      if constexpr (!XBLK) g_wait_vm<3 * NX + 3>();
       G_TICK(4);
       // x of chunk s + 1 (y: read where its row set starts -- four registers fewer live across the power row sets)
       double dx[2], dy[2] = {0.0, 0.0};
@@ -376,8 +446,13 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         constexpr bool last = fi == NS - 1;
         if constexpr (p == G_BS - 1 && last) {
           G_TICK(3);
-          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * NX) : "memory");
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(XBLK ? 0 : 3 * NX) : "memory");
+#ifndef TXM_G_NO_BARRIER  // (ablation build: no barrier)
           asm volatile("s_barrier" ::: "memory");  // the block's barrier
+#endif
+#ifdef TXM_G_SKEW  // experiment: the younger wave of every SIMD leaves the barrier later (phase shift against its partner)
+          if (wave >= 4) __builtin_amdgcn_s_sleep(TXM_G_SKEW);
+#endif
           G_TICK(6);
         }
         if constexpr (YS && fi == JN) {
@@ -405,13 +480,25 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
             else A[q] = *(lds_cv4)(lds + a_va + (p + 1) * G_KSTEP_BYTES + q * 1024);
           }
         }
+#ifdef TXM_G_SCHED  // experiment: ask the scheduler for MFMA / VALU / DS interleaving inside the row set
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, TXM_G_SCHED, 0);  // a few VALU
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // a DS read
+        }
+#endif
         // the words of chunk s + 1, row set fi, and -- behind the stores -- the next step's B operand of the row set
+#ifndef TXM_G_NO_PRODUCE  // (ablation build: no slicing, no stores)
         if constexpr (YS && fi == JN) produce_row(fic, f, dy);
         else produce_row(fic, f, dx);
+#else
+        asm volatile("" ::"v"(f[0]), "v"(f[1]), "v"(dx[0]), "v"(dx[1]), "v"(dy[0]));
+#endif
         Bt[fi][0] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB));
         Bt[fi][1] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB + 128));
       });
-      x_request(slot);  // chunk s + 5 (slot of chunk s + 1, just read)
+      if constexpr (!XBLK) x_request(slot);  // chunk s + 5 (slot of chunk s + 1, just read)
     });
   }
 
@@ -483,7 +570,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 template <int J0, int JN, bool WEIGHTED, bool YS>
 static int launch_pass_g(const I8Args &a, int K, const unsigned char *table, int64_t rep_begin, int n_grp, hipStream_t st) {
   constexpr int NS = JN + (YS ? 1 : 0);
-  const size_t lds = (size_t)T_WAVES * NS * T_PB + 2 * G_BS * G_KSTEP_BYTES + (size_t)(YS ? 2 : 1) * T_WAVES * G_XR * 1024 + 3 * G_RAW +
+  const size_t lds = (size_t)T_WAVES * NS * T_PB + 2 * G_BS * G_KSTEP_BYTES + (size_t)(YS ? 2 * G_XR : G_XRB) * T_WAVES * 1024 + 3 * G_RAW +
                      3 * 2 * G_FU + G_REPS * sizeof(uint32_t);
   const dim3 grid((unsigned)(cdiv(a.nwin, 8) * 8 * n_grp));
   if (a.progress != nullptr) TXM_HIP(hipMemsetAsync(a.progress, 0, (size_t)cdiv(a.nwin, 8) * 8 * 16 * sizeof(uint32_t), st));

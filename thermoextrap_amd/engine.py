@@ -272,6 +272,15 @@ class DeviceSampler:
     def rep0(self):
         return self.spec.rep0
 
+    def rows(self, a: int, b: int) -> "DeviceSampler":
+        """Replicates [a, b) of this sampler as a sampler of their own (a view: the same count rows, stream offset rep0 + a)."""
+        if not 0 <= a < b <= self.spec.nrep:
+            raise ValueError(f"rows [{a}, {b}) outside [0, {self.spec.nrep})")
+        v = object.__new__(DeviceSampler)
+        v.spec = SamplerSpec(seed=self.spec.seed, nrep=b - a, ndat=self.spec.ndat, nsamp=self.spec.nsamp, rep0=self.spec.rep0 + a)
+        v.ntiles, v.counts, v._nws = self.ntiles, self.counts[a:b], self._nws
+        return v
+
     def freq(self) -> torch.Tensor:
         L = _L()
         out = torch.empty((self.spec.nrep, self.spec.ndat), dtype=torch.int64, device="cuda")
@@ -332,11 +341,47 @@ def _tkey(t):
     return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()))
 
 
+# Workspace of ONE library call of the device-sampler bootstrap (partial sums per scaling window, and the int8 path's count
+# table: one byte per replicate and sample) grows with nrep -- 3.9 GB + 102 GB at N = 1e8, nrep = 1000; ten times that at
+# nrep = 1e4.  resample_vals bounds it by bootstrapping the replicates in slabs of whole 128-replicate groups: rows [a, b) of
+# a call equal the (b - a)-replicate call at rep0 = a BIT FOR BIT (txm_sampler_spec.rep0), so the slabs ARE the rows of the
+# unslabbed result.  None: 45 % of the device's memory, at most 80 % of what is free at the first call.
+WORKSPACE_BUDGET_BYTES: int | None = None
+_budget_default: dict[int, int] = {}
+
+
+def workspace_budget() -> int:
+    if WORKSPACE_BUDGET_BYTES is not None:
+        return int(WORKSPACE_BUDGET_BYTES)
+    dev = torch.cuda.current_device()
+    if dev not in _budget_default:
+        free, total = torch.cuda.mem_get_info(dev)
+        _budget_default[dev] = int(min(0.45 * total, 0.8 * free))
+    return _budget_default[dev]
+
+
+def _slab_size(L, N, C, nrep, order, path, has_y) -> int:
+    """Replicates per library call: all of them when the call's workspace fits the budget, else the largest multiple of 128
+    that does (at least 128)."""
+    need = lambda n: L.txm_resample_vals_ws_bytes_opts(N, C, n, order, path, int(has_y)) + (L.txm_resample_y_ws_bytes(N, C, n) if has_y else 0)  # noqa: E731
+    budget = workspace_budget()
+    if need(nrep) <= budget or nrep <= 128:
+        return nrep
+    lo, hi = 1, (nrep + 127) // 128  # groups of 128; need() grows with n
+    while lo < hi:
+        mid = (lo + hi + 1) // 2
+        if need(min(mid * 128, nrep)) <= budget:
+            lo = mid
+        else:
+            hi = mid - 1
+    return min(lo * 128, nrep)
+
+
 def _call_path(path) -> int:
     """The kernel one device-sampler call takes: an explicit path, else the forced_path() context, else the
     library's shape rule (txm_resample_path, which honours txm_set_resample_path)."""
     eff = path if path is not None else _forced
-    if eff in ("fp64", "int8", "int8_fused"):
+    if eff in ("fp64", "int8", "int8_fused", "int8_table"):
         return _PATHS[eff]
     return -1
 
@@ -356,6 +401,7 @@ def resample_vals(
     info: torch.Tensor | None = None,
     y: torch.Tensor | None = None,
     prep_src: tuple | None = None,
+    _slab: int | None = None,
 ):
     """(nrep, C, 2, K) bootstrap states; x is (N, C) row-major (or (N,)).
 
@@ -419,6 +465,25 @@ def resample_vals(
             raise ValueError(f"out must be a contiguous ({nrep}, {C}, 2, {order + 1}) tensor, got {tuple(out.shape)}")
     opts = ResampleOpts()
     opts.path = _call_path(path)
+    if sampler is not None and _slab is None:
+        slab = _slab_size(L, N, C, nrep, order, opts.path, y is not None)
+        if slab < nrep:
+            # replicate slabs: the kernel FAMILY is decided once, for the whole call (the shape rule looks at nrep; a slab must
+            # not fall on the other side of it), then every slab is an ordinary call on its rows of the sampler
+            fam = opts.path
+            if fam == -1:
+                fam = 1 if L.txm_resample_path(N, C, nrep, order) == 1 else 0
+            ym = torch.empty((nrep, C), dtype=F64, device="cuda") if y is not None else None
+            for a in range(0, nrep, slab):
+                b = min(nrep, a + slab)
+                r = resample_vals(x, u, order, sampler=sampler.rows(a, b), w=w, pivot=pivot, out=out[a:b], path=path, prep=prep,
+                                  info=info, y=y, prep_src=prep_src if prep_src is not None else (x, u, w, pivot, y), _slab=fam)
+                if y is not None:
+                    ym[a:b] = r[1] if y.dim() > 1 else r[1][:, None]
+            res = out[:, 0] if squeeze else out
+            return (res, (ym[:, 0] if y.dim() == 1 else ym)) if y is not None else res
+    if _slab is not None:
+        opts.path = _slab if opts.path == -1 else opts.path
     ymean = y2 = None
     if y is not None:
         _check_f64_cuda(y, "y")
@@ -431,11 +496,13 @@ def resample_vals(
         opts.y, opts.ldy_s, opts.out_y = y2.data_ptr(), max(y2.stride(0) if N > 1 else C, C), ymean.data_ptr()
     key = None
     if prep is not None and freq is None:
-        takes_i8 = (opts.path in (1, 2) and L.txm_resample_i8_supported(N, C, nrep, order) == 1) or (
+        takes_i8 = (opts.path in (1, 2, 3) and L.txm_resample_i8_supported(N, C, nrep, order) == 1) or (
             opts.path == -1 and L.txm_resample_path(N, C, nrep, order) == 1)
         if takes_i8:
             # (the path is part of the key: whether a second matrix's tables sit in the block depends on the kernel that carries it)
-            key = (src_key, N, C, nrep, order, opts.path)
+            # nrep is NOT part of it: pivot, window table, guard flags and fallback list do not depend on the replicate count,
+            # so the replicate slabs of one call (and calls with other counts) share the block
+            key = (src_key, N, C, order, opts.path)
             kept = prep.lookup(key)
             if kept is not None:  # same caller tensors, unedited: the operands of the call that filled the block
                 x2, u, w, pivot, y2 = kept
@@ -452,7 +519,8 @@ def resample_vals(
     if not (info.is_cuda and info.dtype == torch.int64 and info.numel() >= 4 and info.is_contiguous()):
         raise TypeError("info must be a contiguous int64 CUDA tensor with >= 4 elements")
     opts.info = info.data_ptr()
-    ws = workspace(L.txm_resample_vals_ws_bytes(N, C, nrep, order) + (L.txm_resample_y_ws_bytes(N, C, nrep) if y is not None else 0))
+    ws = workspace(L.txm_resample_vals_ws_bytes_opts(N, C, nrep, order, opts.path, int(y is not None))
+                   + (L.txm_resample_y_ws_bytes(N, C, nrep) if y is not None else 0))
     check(
         L.txm_resample_vals(_ptr(x2), ls, 1, _ptr(u), _ptr(w), N, C, order, nrep, _ptr(freq), spec_p, counts_p,
                             _ptr(pivot), _ptr(out), ct.byref(opts), _ptr(ws), ws.numel(), _stream()),
@@ -547,7 +615,7 @@ def resample_vals_batched(xs, us, order: int, *, nrep: int, sampler: DeviceSampl
         nb = L.txm_resample_batched_prep_bytes(S, N, C, nrep, order)
         # bind (and afterwards commit) the block only when THIS call runs the int8 path -- the library's own predicates, as the
         # single call does: a call that ran the FP64 kernel never fills the block, and a later int8 call would read it as valid
-        takes_i8 = bool(nb) and (opts.path in (1, 2) or (opts.path == -1 and L.txm_resample_batched_path(S, N, C, nrep, order) == 1))
+        takes_i8 = bool(nb) and (opts.path in (1, 2, 3) or (opts.path == -1 and L.txm_resample_batched_path(S, N, C, nrep, order) == 1))
         if takes_i8:
             key = (tuple(_tkey(t) for t in src[0]), tuple(_tkey(t) for t in src[1]),
                    None if src[2] is None else tuple(_tkey(t) for t in src[2]), S, N, C, nrep, order)
@@ -589,12 +657,12 @@ def resample_path(N: int, C: int, nrep: int, order: int) -> str:
     L = _L()
     if _forced == "fp64":
         return "fp64"
-    if _forced in ("int8", "int8_fused"):  # wherever the int8 kernel supports the shape: the library's own predicate
+    if _forced in ("int8", "int8_fused", "int8_table"):  # wherever the int8 kernel supports the shape: the library's own predicate
         return "int8" if L.txm_resample_i8_supported(int(N), int(C), int(nrep), int(order)) == 1 else "fp64"
     return "int8" if L.txm_resample_path(int(N), int(C), int(nrep), int(order)) == 1 else "fp64"
 
 
-_PATHS = {None: -1, "auto": -1, "fp64": 0, "int8": 1, "int8_fused": 2}
+_PATHS = {None: -1, "auto": -1, "fp64": 0, "int8": 1, "int8_fused": 2, "int8_table": 3}
 _forced: str | None = None
 
 

@@ -16,11 +16,12 @@ import _toolenv; _toolenv.apply()
 x, u = make_data(N, C, 1000, torch)
 s = engine.DeviceSampler(0, nrep, N)
 out = torch.empty((nrep, C, 2, order + 1), dtype=torch.float64, device="cuda")
-engine.resample_vals(x, u, order, sampler=s, out=out); torch.cuda.synchronize()
+KP = os.environ.get("TXM_KPATH")  # e.g. int8_table / int8_fused: the kernel of the wide int8 path
+engine.resample_vals(x, u, order, sampler=s, out=out, path=KP); torch.cuda.synchronize()
 ts = []
 for _ in range(5):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); engine.resample_vals(x, u, order, sampler=s, out=out); e1.record(); torch.cuda.synchronize()
+    e0.record(); engine.resample_vals(x, u, order, sampler=s, out=out, path=KP); e1.record(); torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1))
 fl = 2.0 * N * nrep * (order + 1) * (C + 1)
 t = sorted(ts)[len(ts) // 2]

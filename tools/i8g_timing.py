@@ -16,10 +16,10 @@ txa.require_gpu(0)
 x, u = make_data(N, C, 0, torch)
 s = eng.DeviceSampler(1, nrep, N)
 prep = eng.ResamplePrep()
-eng.resample_vals(x, u, order, sampler=s, prep=prep, path="int8")
+eng.resample_vals(x, u, order, sampler=s, prep=prep, path="int8_table")
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record(); eng.resample_vals(x, u, order, sampler=s, prep=prep, path="int8"); e1.record(); torch.cuda.synchronize()
+e0.record(); eng.resample_vals(x, u, order, sampler=s, prep=prep, path="int8_table"); e1.record(); torch.cuda.synchronize()
 print(f"call {e0.elapsed_time(e1):.2f} ms", eng.resample_info())
 ntiles = -(-N // 1024)
 win = 256
