@@ -55,6 +55,7 @@ typedef void *txm_stream;
 /* ---- runtime ------------------------------------------------------------ */
 int txm_abi_version(void);
 int txm_sampler_stream_version(void); /* the device sampler stream this build draws (tables are a function of it) */
+const char *txm_csrc_sha(void); /* sha256 (16 hex digits) over thermoextrap_amd/csrc/*.hip|*.h this library was compiled from */
 const char *txm_last_error(void);
 /* Select the device for the calling thread and check it is a gfx950 part. */
 int txm_init(int device);
@@ -197,17 +198,28 @@ int txm_sampler_count_table(const txm_sampler_spec *spec_host, const uint32_t *c
  * out: [nrep][C][2][K]  (rep-major, i.e. already `.transpose(rep_dim, ...)`,
  * data.py:1812).
  *
- * Scale mode has two kernels behind it and the library picks one per call:
+ * Scale mode has two kernel families behind it and the library picks one per call:
  *   TXM_PATH_FP64  the contraction on the FP64 matrix pipe (any order, any C);
- *   TXM_PATH_INT8  the same sums on the int8 matrix pipe: per window of 65536 samples every
- *                  monomial is scaled by the window maximum, rounded ONCE to a 51-bit
- *                  fixed-point integer (error <= 2^-51 of the window maximum, unbiased),
- *                  split into seven signed 8-bit digits and accumulated exactly in int32
- *                  (order 0..7; 32 columns per launch, orders above 4 in two passes over
- *                  the sampler stream; taken when every 32-column group holds more than 16 columns and
- *                  nrep >= 64 (order >= 3), 128 (orders 1, 2) or 384 (order 0); states with C <= 8
- *                  (C <= 16) observables carry four (two) powers per column and take it from order 2
- *                  and 128 (64) replicates on).
+ *   TXM_PATH_INT8  the same sums on the int8 matrix pipe (orders 0..7, N >= 1024): per SCALING WINDOW -- 262144 samples on
+ *                  long series (N >= 2^26), 65536 / 16384 / 4096 on shorter ones, a function of N alone -- every monomial is
+ *                  scaled by the window maximum, rounded ONCE to a 51-bit fixed-point integer (error <= 2^-51 of the window
+ *                  maximum, unbiased), split into seven signed 8-bit digits and accumulated exactly in int32; 32 columns
+ *                  per launch.
+ *   The rule of TXM_PATH_AUTO (txm_resample_path; tests/test_abi_cpu.py calls it on both sides of every threshold named here):
+ *     - needs N >= 262144 and order <= 7;
+ *     - NARROW states, C <= 16 observables in the call: order >= 1, and N >= 786432 at ANY replicate count or, below that,
+ *       nrep >= 128 (order 0 stays FP64);
+ *     - WIDE states, C > 16 (a last group of 1..16 columns behind full 32-column groups is allowed from order 1; at order 0
+ *       it keeps the call on FP64): long series (N >= 786432) from nrep >= 32 at order >= 1 and nrep >= 100 at order 0;
+ *       shorter series from nrep >= 64 at order >= 3, 128 at orders 1-2, 384 at order 0.
+ *   Inside the int8 path two contraction kernels serve wide states and agree BIT FOR BIT (same int32 sums, same flush):
+ *     - the kernel that draws the per-sample counts in place (64 replicates per workgroup; orders 0-4 one pass over the
+ *       sampler stream, 5-7 two): orders 3 and 4 without a second matrix, replicate counts that pad badly to 128
+ *       (4 * ceil128(nrep) > 5 * ceil64(nrep)), misaligned operands (x not 16-byte aligned or an odd row pitch), and
+ *       every narrow state;
+ *     - the count-table kernel (128 replicates per workgroup, at most three row sets per pass over ONE table of per-sample
+ *       counts, txm_sampler_count_table; every call with a second matrix rides it): all other wide calls whose workspace
+ *       holds the table (txm_resample_vals_ws_bytes_opts).  TXM_PATH_INT8_FUSED / TXM_PATH_INT8_TABLE force one of them.
  *                  PRECISION GUARD (data dependent, automatic): the pre-pass also takes, per window, a robust
  *                  typical magnitude of the top-power monomial (the smallest of 64 group means of
  *                  |w du^order dx_c|); a window whose scale exceeds 275 sqrt(n) times it -- a heavy tail, an
@@ -216,14 +228,15 @@ int txm_sampler_count_table(const txm_sampler_spec *spec_host, const uint32_t *c
  *                  the two sets of partial sums are added.  Ordinary data flags nothing.
  * txm_resample_path reports the shape-based choice.  The kernel of ONE CALL is chosen by txm_resample_opts.path
  * (TXM_PATH_AUTO = that rule); txm_set_resample_path is a process-wide default for TXM_PATH_AUTO calls kept for tests
- * and A/B timing (initial value: the environment variable TXM_I8=0 / TXM_I8=1, read once) -- calls that pass a path
+ * and A/B timing (initially TXM_PATH_AUTO; the library reads NO environment variable) -- calls that pass a path
  * share no mutable state and are re-entrant per (workspace, stream).
  *
  * txm_resample_opts (HOST struct, NULL = all defaults):
- *   path        TXM_PATH_AUTO / TXM_PATH_FP64 / TXM_PATH_INT8 for this call.
+ *   path        TXM_PATH_AUTO / TXM_PATH_FP64 / TXM_PATH_INT8 (/ _INT8_FUSED / _INT8_TABLE: which int8 kernel serves wide states) for this call.
  *   info        DEVICE pointer to 4 int64 (nullable), written on the stream, no synchronisation:
  *               [0] path taken, [1] scaling windows x column groups, [2] how many of them the precision guard sent
- *               to the FP64 kernel, [3] 1 when the pre-pass tables came from `prep` (below) instead of being computed.
+ *               to the FP64 kernel, [3] bit 0: the pre-pass tables came from `prep` (below) instead of being computed; bit 1: the wide
+ *               column groups ran the count-table kernel (else the kernel that draws in place).
  *   prep, prep_bytes, prep_valid
  *               The int8 path's pre-pass (pivot + per-window scale table, guard flags and fallback list) depends on
  *               (x, u, w, pivot, N, C, nrep, order) only -- not on the sampler -- and costs one more read of the samples.

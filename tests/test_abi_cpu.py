@@ -170,6 +170,65 @@ def test_workspace_and_path_queries_are_pure_host_logic(lib, monkeypatch):
     assert lib.txm_resample_path(big, 32, 1000, 4) == 1
 
 
+def test_dispatch_rule_matches_the_header_thresholds(lib):
+    """include/txmom.h states the rule of TXM_PATH_AUTO in numbers; this calls txm_resample_path (and the batched predicate, and
+    the workspace query that follows the int8 path's kernel choice) on BOTH sides of every threshold named there, so that the
+    contract and the code cannot drift apart again (round-4 verdict: the header still described round 2's rule)."""
+    assert lib.txm_set_resample_path(-1) == 0
+    P = lib.txm_resample_path
+    LONG, SHORT = 786432, 262144
+    # needs N >= 262144 and order <= 7
+    assert P(SHORT, 32, 1000, 4) == 1 and P(SHORT - 1, 32, 1000, 4) == 0
+    assert P(LONG, 32, 1000, 7) == 1 and P(LONG, 32, 1000, 8) == 0
+    # narrow states (C <= 16): order >= 1; long series at any replicate count, shorter ones from 128 replicates
+    for C in (1, 4, 8, 16):
+        assert P(LONG, C, 1, 1) == 1 and P(LONG, C, 1000, 0) == 0
+        assert P(LONG - 1, C, 127, 3) == 0 and P(LONG - 1, C, 128, 3) == 1
+        assert P(SHORT, C, 128, 1) == 1 and P(SHORT - 1, C, 128, 1) == 0
+    assert P(LONG, 16, 4, 2) == 1 and P(LONG, 17, 4, 2) == 0   # 17 columns: a wide state, 32 replicates needed
+    # wide states (C > 16), long series: order >= 1 from 32 replicates, order 0 from 100
+    for C in (17, 32, 64, 48):
+        assert P(LONG, C, 31, 1) == 0 and P(LONG, C, 32, 1) == 1
+        assert P(LONG, C, 31, 7) == 0 and P(LONG, C, 32, 7) == 1
+    assert P(LONG, 32, 99, 0) == 0 and P(LONG, 32, 100, 0) == 1
+    # ... shorter series: order >= 3 from 64, orders 1-2 from 128, order 0 from 384
+    assert P(LONG - 1, 32, 63, 3) == 0 and P(LONG - 1, 32, 64, 3) == 1
+    assert P(LONG - 1, 32, 127, 2) == 0 and P(LONG - 1, 32, 128, 2) == 1
+    assert P(LONG - 1, 32, 127, 1) == 0 and P(LONG - 1, 32, 128, 1) == 1
+    assert P(LONG - 1, 32, 383, 0) == 0 and P(LONG - 1, 32, 384, 0) == 1
+    # a last group of 1..16 columns behind full groups: allowed from order 1, keeps an order-0 call on FP64
+    assert P(LONG, 40, 1000, 1) == 1 and P(LONG, 40, 1000, 0) == 0 and P(LONG, 49, 1000, 0) == 1
+    # the batched entry: the narrow-state rule, whatever the number of states in the launch
+    B = lib.txm_resample_batched_path
+    for S in (1, 64):
+        assert B(S, LONG, 4, 1, 1) == 1 and B(S, LONG, 4, 100, 0) == 0
+        assert B(S, LONG - 1, 4, 127, 3) == 0 and B(S, LONG - 1, 4, 128, 3) == 1
+        assert B(S, LONG, 32, 100, 3) == 0                    # wide states: the batched int8 launch does not serve them
+    # which int8 kernel serves a wide call, seen through the workspace it asks for: the count table (one byte per sample and
+    # replicate padded to 128) is part of it for every order but 3 and 4, for every call with a second matrix, and never
+    # when the padding to 128 replicates wastes more than 5/4 of the padding to 64
+    W = lib.txm_resample_vals_ws_bytes_opts
+    N = 10_000_000
+    ntiles = -(-N // 1024)
+    table = lambda nrep: -(-nrep // 128) * ntiles * 131072  # noqa: E731
+    AUTO, FP64, INT8, FUSED, TABLE = -1, 0, 1, 2, 3
+    for order in range(8):
+        base = W(N, 32, 1000, order, FUSED, 0)
+        with_table = W(N, 32, 1000, order, TABLE, 0)
+        assert table(1000) <= with_table - base < table(1000) + 4096
+        auto = W(N, 32, 1000, order, AUTO, 0)
+        assert auto == (base if order in (3, 4) else with_table), order
+        assert W(N, 32, 1000, order, AUTO, 1) == with_table            # a second matrix always rides the table kernel
+        assert W(N, 32, 1000, order, INT8, 0) == auto and lib.txm_resample_vals_ws_bytes(N, 32, 1000, order) == auto
+    assert W(N, 32, 64, 2, AUTO, 0) == W(N, 32, 64, 2, FUSED, 0)        # 64 replicates: padding to 128 doubles the work
+    assert W(N, 32, 130, 2, AUTO, 0) == W(N, 32, 130, 2, FUSED, 0)      # 130 -> 256 against 192
+    assert W(N, 32, 100, 2, AUTO, 0) == W(N, 32, 100, 2, TABLE, 0)      # 100 -> 128 either way
+    assert W(N, 32, 260, 2, AUTO, 0) == W(N, 32, 260, 2, TABLE, 0)      # 260 -> 384 against 320
+    assert W(N, 8, 1000, 2, TABLE, 0) == W(N, 8, 1000, 2, FUSED, 0)     # narrow states never use the table
+    assert W(N, 32, 1000, 2, FP64, 0) <= W(N, 32, 1000, 2, FUSED, 0)
+    assert lib.txm_sampler_count_table_bytes(N, 1000) == table(1000)
+
+
 def test_graft_entry_build_runs(lib):
     """The driver's build check: __graft_entry__.build() compiles (a no-op when the library is current), loads and checks
     the ABI version the binding expects -- it carried a literal 1 into the round that made the ABI 2."""

@@ -366,3 +366,46 @@ def test_batched_default_dispatch_rule(eng):
     xs, us, _ = states(2, 1_000_000, 4, 23)
     eng.resample_vals_batched(xs, us, 2, nrep=8, sampler=eng.DeviceSampler(3, 2 * 8, 1_000_000))
     assert eng.batched_info()["path"] == "int8"
+
+
+def test_c5_bench_shape_int8_batched_vs_oracle(txm, eng, orc):
+    """BASELINE config 5 at the shape tools/bench_states.py times -- 64 states x 1e6 samples x 4 observables, order 3,
+    nrep = 100 -- through input_GP_from_states on the DEFAULT dispatch, which is the batched int8 launch there (N >= 786432):
+    the replicate states of seeded (state, replicate) pairs, all four columns, against the oracle's extended-precision
+    definition on the frequency rows of the same stream (state s owns stream replicates s * nrep ...), 1e-12 of each
+    comoment's scale; the GP tuple's derivative rows against the oracle's derivative formulas on the un-resampled states and
+    its covariance blocks against np.cov of the replicate derivatives.  (Round-4 verdict: the test named "fullsize" ran
+    N = 2e5 per state, which the rule sends to the FP64 kernel.)"""
+    from oracle import derivs_oracle as dorc
+
+    xtrap = txm
+    S, N, C, order, nrep, seed = 64, 1_000_000, 4, 3, 100, 9091
+    coll, xs, us, _ = _collection(xtrap, S, N, C, order, 61)
+    spec = {"nrep": nrep, "device": True, "seed": seed}
+    x_all, y_all, cov_all = xtrap.gpr_input.input_GP_from_states(coll, n_rep=nrep, sampler=spec)
+    assert eng.batched_info()["path"] == "int8"
+    n_ord = order + 1
+    assert x_all.shape == (S * n_ord, 2) and y_all.shape == (S * n_ord, C) and cov_all.shape == (C, S * n_ord, S * n_ord)
+    boot = coll.resample(spec)                       # the same spec: the same replicates
+    assert eng.batched_info()["path"] == "int8"
+    rng = np.random.default_rng(seed)
+    pairs = [(0, 0), (S - 1, nrep - 1)] + [(int(rng.integers(S)), int(rng.integers(nrep))) for _ in range(6)]
+    worst = 0.0
+    for s, r in pairs:
+        fr = eng.DeviceSampler(seed, 1, N, rep0=s * nrep + r).freq().cpu().numpy()
+        assert fr.sum() == N
+        xh, uh = xs[s].cpu().numpy(), us[s].cpu().numpy()
+        t = orc.truth_cov_multi(xh, uh, order, fr)[0]
+        sc = scale(xs[s], us[s], order + 1).cpu().numpy()
+        got = np.asarray(boot[s].data.values.values)[r]
+        worst = max(worst, float((np.abs(got - t) / (np.abs(t) + sc)).max()))
+    print(f"c5 bench shape, int8 batched: max scaled error over {len(pairs)} (state, replicate) pairs x {C} columns: {worst:.3e}")
+    assert worst <= 1e-12, worst
+    # the tuple: derivative rows of the un-resampled states (oracle formulas), covariance blocks = np.cov over the replicates
+    res = boot.map_concat("derivs", norm=False).values
+    for s in (0, 31, S - 1):
+        want = dorc.derivs_x_ave(xs[s].cpu().numpy(), us[s].cpu().numpy(), order)
+        np.testing.assert_allclose(y_all[s * n_ord:(s + 1) * n_ord], want, rtol=1e-8, atol=1e-12)
+        blk = cov_all[:, s * n_ord:(s + 1) * n_ord, s * n_ord:(s + 1) * n_ord]
+        np.testing.assert_allclose(blk, np.array([np.cov(res[s, :, :, k]) for k in range(C)]), rtol=1e-7, atol=1e-300)
+    assert (cov_all[:, :n_ord, n_ord:2 * n_ord] == 0).all()

@@ -154,8 +154,15 @@ def test_prep_block_is_computed_once_per_data_object(txm, eng):
         assert torch.equal(a, b)
         prep = data._cache["resample_prep"]
         assert (prep.hits, prep.misses) == (1, 1)
-        c = data.resample({"nrep": 64, "seed": 9, "device": True}).dxduave.device_values   # another shape: recomputed
-        assert not eng.resample_info()["prep_reused"] and c.shape[0] == 64
+        # another replicate count: the tables do not depend on it (round 5: replicate slabs share one block) -- reused, and the
+        # rows are those of a cold call; another ORDER is another set of tables
+        c = data.resample({"nrep": 64, "seed": 9, "device": True}).dxduave.device_values
+        assert eng.resample_info()["prep_reused"] and c.shape[0] == 64
+        assert torch.equal(c, eng.resample_vals(x, u, order, sampler=eng.DeviceSampler(9, 64, N)))
+        eng.resample_vals(x, u, order - 1, sampler=eng.DeviceSampler(9, nrep, N), prep=prep)
+        assert not eng.resample_info()["prep_reused"]
+        data.resample(spec)   # (the block now holds the order - 1 tables: this call recomputes, the one after it reuses)
+        assert not eng.resample_info()["prep_reused"]
         x[1234, 5] += 1.0                                                                       # in-place edit
         d = data.resample(spec).dxduave.device_values
         assert not eng.resample_info()["prep_reused"] and not torch.equal(d, a)

@@ -16,7 +16,6 @@ CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libtxmom.so"
 SOURCES = ["txm_api.hip", "txm_reduce.hip", "txm_sampler.hip", "txm_small.hip", "txm_resample.hip", "txm_resample_i8.hip",
            "txm_resample_i8t.hip", "txm_resample_i8g.hip", "txm_count_table.hip", "txm_perturb.hip"]
-HEADERS = ["txm_common.h", "txm_pivot.h", "txm_sampler.h", "txm_resample_i8.h", "txm_i8t_common.h", "txm_i8g.h", "../../include/txmom.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed"]
 # per-file flags.  txm_resample_i8t.hip: 11 int32 accumulator tiles (176 registers) per wave at two waves per SIMD only
 # fit when the 256 registers are ONE file -- MFMA accumulators in VGPRs, no AGPR split (see the file's header)
@@ -35,11 +34,33 @@ def _hipcc() -> str:
     return "hipcc"
 
 
-def needs_build() -> bool:
+def csrc_sha() -> str:
+    """sha256 (16 hex digits) over the kernel sources: what a built library carries (txm_csrc_sha) and what ties a
+    committed profile to the code it was measured on (bench.py)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h"))):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def built_sha() -> str | None:
+    """The source hash embedded in the built library (read from the file, no dlopen), None when there is none."""
     if not LIB.exists():
-        return True
-    t = LIB.stat().st_mtime
-    return any((CSRC / f).stat().st_mtime > t for f in SOURCES + HEADERS)
+        return None
+    blob = LIB.read_bytes()
+    i = blob.find(b"TXM_CSRC_SHA=")
+    if i < 0:
+        return None
+    return blob[i + 13:i + 29].decode(errors="replace")
+
+
+def needs_build() -> bool:
+    """True when there is no library or it was not compiled from the sources in the tree -- decided by the hash the
+    library carries, not by file times (a checkout, a copy or a snapshot keeps no usable times)."""
+    return built_sha() != csrc_sha()
 
 
 def build_library(force: bool = False, verbose: bool = False) -> Path:
@@ -48,10 +69,14 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     objdir = CSRC / "build"
     objdir.mkdir(exist_ok=True)
     cc = _hipcc()
+    sha = csrc_sha()
 
     def compile_one(src: str) -> Path:
         obj = objdir / (src.replace(".hip", ".o"))
-        cmd = [cc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", str(CSRC / src), "-o", str(obj)]
+        extra = list(EXTRA_FLAGS.get(src, []))
+        if src == "txm_api.hip":
+            extra.append(f'-DTXM_CSRC_SHA="{sha}"')
+        cmd = [cc, *FLAGS, *extra, "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

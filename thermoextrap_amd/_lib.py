@@ -52,6 +52,7 @@ class PolyTable(ct.Structure):
 SIGNATURES = {
     "txm_abi_version": (c_int, []),
     "txm_sampler_stream_version": (c_int, []),
+    "txm_csrc_sha": (ct.c_char_p, []),
     "txm_last_error": (ct.c_char_p, []),
     "txm_init": (c_int, [c_int]),
     "txm_device_count": (c_int, [ct.POINTER(c_int)]),

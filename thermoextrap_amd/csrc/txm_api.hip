@@ -28,6 +28,15 @@ int num_cus() { return g_num_cus; }
 
 using namespace txm;
 
+// The hash of the kernel sources this library was built from (thermoextrap_amd/_build.py passes it when it compiles this
+// file; "unknown" for a hand-made build).  The marker string is what _build.needs_build() looks for in the binary -- a
+// library whose hash is not the tree's is rebuilt whatever the file times say -- and txm_csrc_sha() what bench.py reports.
+#ifndef TXM_CSRC_SHA
+#define TXM_CSRC_SHA "unknown"
+#endif
+extern "C" const char txm_csrc_sha_marker[] = "TXM_CSRC_SHA=" TXM_CSRC_SHA;
+extern "C" const char *txm_csrc_sha(void) { return txm_csrc_sha_marker + 13; }
+
 extern "C" int txm_abi_version(void) { return TXM_ABI_VERSION; }
 extern "C" int txm_sampler_stream_version(void) { return TXM_SAMPLER_STREAM_VERSION; }
 

@@ -903,7 +903,7 @@ __global__ void i8_info_kernel(const unsigned char *prep_groups, size_t group_st
     info[0] = TXM_PATH_INT8;
     info[1] = nwin * ngroups;
     info[2] = flagged;
-    info[3] = from_prep;
+    info[3] = from_prep;  // bit 0: tables came from the caller's block; bit 1: wide groups ran the count-table kernel
   }
 }
 __global__ void fp64_info_kernel(int64_t *info) {
@@ -1290,7 +1290,7 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
       TXM_HIP(hipMemcpyAsync((char *)ws + q.off_prep, pb, q.prep_total, hipMemcpyDeviceToDevice, st));
     if (info != nullptr) {
       hipLaunchKernelGGL(i8_info_kernel, dim3(1), dim3(64), 0, st, pb + q.prep_group0, q.prep_group_stride, q.prep_nlist,
-                         q.ngroups, q.nwin, have_tables ? 1 : 0, info);
+                         q.ngroups, q.nwin, (have_tables ? 1 : 0) | (have_table ? 2 : 0), info);
       TXM_LAUNCH_CHECK();
     }
     return TXM_OK;

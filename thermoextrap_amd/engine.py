@@ -648,7 +648,7 @@ def batched_info() -> dict:
     if info is None:
         return {}
     v = info.cpu().tolist()
-    return {"path": "int8" if v[0] == 1 else "fp64", "windows": int(v[1]), "windows_fp64": int(v[2]), "prep_reused": bool(v[3])}
+    return {"path": "int8" if v[0] == 1 else "fp64", "windows": int(v[1]), "windows_fp64": int(v[2]), "prep_reused": bool(v[3] & 1)}
 
 
 def resample_path(N: int, C: int, nrep: int, order: int) -> str:
@@ -686,7 +686,7 @@ def forced_path(path: str | None):
 
 def resample_info(N: int | None = None, C: int | None = None, nrep: int | None = None, order: int | None = None) -> dict:
     """What the last `resample_vals` call on the current stream did: {"path", "windows", "windows_fp64",
-    "prep_reused"} -- "windows_fp64" counts the scaling windows (x column groups) that the precision guard of the
+    "prep_reused", "kernel"} -- "kernel": which contraction served the wide column groups ("int8_table" / "int8_fused" / "fp64"); "windows_fp64" counts the scaling windows (x column groups) that the precision guard of the
     int8 path handed to the FP64 kernel.  Reads the info words the library wrote on the stream
     (txm_resample_opts.info); synchronises.  The shape arguments are accepted for compatibility and ignored."""
     _L()
@@ -695,7 +695,7 @@ def resample_info(N: int | None = None, C: int | None = None, nrep: int | None =
         raise RuntimeError("no resample_vals call has been made on this stream")
     v = info.cpu().tolist()
     return {"path": "int8" if v[0] == 1 else "fp64", "windows": int(v[1]), "windows_fp64": int(v[2]),
-            "prep_reused": bool(v[3])}
+            "prep_reused": bool(v[3] & 1), "kernel": ("fp64" if v[0] != 1 else "int8_table" if v[3] & 2 else "int8_fused")}
 
 
 def resample_data(data: torch.Tensor, freq: torch.Tensor | None, order: int) -> torch.Tensor:
