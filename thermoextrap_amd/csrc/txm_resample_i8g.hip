@@ -431,6 +431,11 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     uint32_t f_va = (uint32_t)(OFF_F + (B % 3) * (2 * G_FU) + ps * NPT * 8);
     uint32_t x_va = xring + (uint32_t)(ps * 32 + cl * 8) + (XBLK ? (uint32_t)((B & 1) * 4096) : 0u);
     asm volatile("" : "+v"(f_va), "+v"(x_va), "+v"(a_va), "+v"(a_vn));  // opaque bases: the reads below take 16-bit immediate offsets
+    // (Experiment, -DTXM_G_ANTIPHASE: the younger wave of every SIMD takes the block's barrier half a row set later than the
+    // older one -- behind the last row set's MFMAs -- so that out of the barrier one issues MFMAs while the other slices.
+    // The kernel's time is its LDS / vector / DMA time PLUS most of its MFMA time (ablations, profiles/r05_experiments.md),
+    // and waves in step on a shared matrix pipe looked like the reason; measured: 114.4 against 107.9 ms at order 2, 169.1
+    // against 163.7 at order 4 -- slower.  Left switched off.)
     t_static_for<G_BS>([&](auto pc) {
       constexpr int p = decltype(pc)::value;
       constexpr int slot = XBLK ? p : ((p + 1) & 3);
@@ -444,16 +449,22 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       t_static_for<NS>([&](auto fic) {
         constexpr int fi = decltype(fic)::value;
         constexpr bool last = fi == NS - 1;
-        if constexpr (p == G_BS - 1 && last) {
+        auto block_sync = [&]() {
           G_TICK(3);
           asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(XBLK ? 0 : 3 * NX) : "memory");
 #ifndef TXM_G_NO_BARRIER  // (ablation build: no barrier)
           asm volatile("s_barrier" ::: "memory");  // the block's barrier
 #endif
-#ifdef TXM_G_SKEW  // experiment: the younger wave of every SIMD leaves the barrier later (phase shift against its partner)
-          if (wave >= 4) __builtin_amdgcn_s_sleep(TXM_G_SKEW);
-#endif
           G_TICK(6);
+        };
+#ifdef TXM_G_ANTIPHASE  // experiment build (measured: +6 %, see above)
+        constexpr bool ANTI = true;
+#else
+        constexpr bool ANTI = false;
+#endif
+        const bool late_sync = ANTI && wave >= 4;  // uniform
+        if constexpr (p == G_BS - 1 && last) {
+          if (!late_sync) block_sync();
         }
         if constexpr (YS && fi == JN) {
 #pragma unroll
@@ -468,33 +479,38 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
           } else if constexpr (!WEIGHTED && J0 == 0 && fi == 0) {
             f[uu] = 1.0;
           } else {
+#ifdef TXM_G_NO_FREAD  // ablation build: no factor reads (constants)
+            f[uu] = 0.5 + 0.125 * fi;
+#else
             f[uu] = *(lds_cd)(lds + f_va + uu * G_FU + (p * 16 * NPT + fi) * 8);
+#endif
           }
         }
         const v4i Bv = {Bt[fi][0][0], Bt[fi][0][1], Bt[fi][1][0], Bt[fi][1][1]};
+        if constexpr (p == G_BS - 1 && last) {
+          // (ONE copy of the MFMAs for both kinds of wave -- a copy per kind cost the register allocator 450 spilled registers:
+          // only the barrier itself sits behind a branch; the next block's count words are read behind the later of the two)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          t_mfma<true>(acc[fi][q], A[q], Bv);
-          if constexpr (last) {  // quarter q's count operand of the NEXT step into the registers just used for the last time
-            if constexpr (p == G_BS - 1) A[q] = *(lds_cv4)(lds + a_vn + q * 1024);
-            else A[q] = *(lds_cv4)(lds + a_va + (p + 1) * G_KSTEP_BYTES + q * 1024);
+          for (int q = 0; q < 4; ++q) t_mfma<true>(acc[fi][q], A[q], Bv);
+          if (late_sync) block_sync();
+#pragma unroll
+          for (int q = 0; q < 4; ++q) A[q] = *(lds_cv4)(lds + a_vn + q * 1024);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            t_mfma<true>(acc[fi][q], A[q], Bv);
+            // quarter q's count operand of the NEXT step into the registers just used for the last time
+            if constexpr (last) A[q] = *(lds_cv4)(lds + a_va + (p + 1) * G_KSTEP_BYTES + q * 1024);
           }
         }
-#ifdef TXM_G_SCHED  // experiment: ask the scheduler for MFMA / VALU / DS interleaving inside the row set
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // one MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002, TXM_G_SCHED, 0);  // a few VALU
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // a DS read
-        }
-#endif
-        // the words of chunk s + 1, row set fi, and -- behind the stores -- the next step's B operand of the row set
+        // the words of chunk s + 1, row set fi
 #ifndef TXM_G_NO_PRODUCE  // (ablation build: no slicing, no stores)
         if constexpr (YS && fi == JN) produce_row(fic, f, dy);
         else produce_row(fic, f, dx);
 #else
         asm volatile("" ::"v"(f[0]), "v"(f[1]), "v"(dx[0]), "v"(dx[1]), "v"(dy[0]));
 #endif
+        // ... and -- behind the stores, behind the MFMAs that read the old ones -- the next step's B operand of the row set
         Bt[fi][0] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB));
         Bt[fi][1] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB + 128));
       });
