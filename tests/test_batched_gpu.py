@@ -409,3 +409,32 @@ def test_c5_bench_shape_int8_batched_vs_oracle(txm, eng, orc):
         blk = cov_all[:, s * n_ord:(s + 1) * n_ord, s * n_ord:(s + 1) * n_ord]
         np.testing.assert_allclose(blk, np.array([np.cov(res[s, :, :, k]) for k in range(C)]), rtol=1e-7, atol=1e-300)
     assert (cov_all[:, :n_ord, n_ord:2 * n_ord] == 0).all()
+
+
+def test_batched_prep_block_is_bound_only_by_int8_calls(eng):
+    """Round-4 advice (high): a batched call that ran the FP64 kernel (path="fp64", forced_path, or the rule choosing FP64) must
+    not commit the caller's pre-pass block -- it never filled it, and the next int8 call on the same tensors would have read
+    uninitialised pivots, window tables and fallback lists as valid.  FP64 first, int8 second, one ResamplePrep: the int8 call
+    computes the block (prep_reused False), equals the call without a block bit for bit, and only then is the block reused."""
+    S, N, C, order, nrep = 3, 300000, 4, 3, 128
+    xs, us, _ = states(S, N, C, 29)
+    smp = eng.DeviceSampler(8, S * nrep, N)
+    prep = eng.ResamplePrep()
+    ref8 = eng.resample_vals_batched(xs, us, order, nrep=nrep, sampler=smp, path="int8")
+    f = eng.resample_vals_batched(xs, us, order, nrep=nrep, sampler=smp, path="fp64", prep=prep)
+    assert eng.batched_info()["path"] == "fp64" and prep.key is None and prep.buf is None and (prep.hits, prep.misses) == (0, 0)
+    with eng.forced_path("fp64"):
+        f2 = eng.resample_vals_batched(xs, us, order, nrep=nrep, sampler=smp, prep=prep)
+    assert torch.equal(f, f2) and prep.key is None
+    a = eng.resample_vals_batched(xs, us, order, nrep=nrep, sampler=smp, path="int8", prep=prep)
+    info = eng.batched_info()
+    assert info["path"] == "int8" and not info["prep_reused"] and (prep.hits, prep.misses) == (0, 1)
+    assert torch.equal(a, ref8)
+    b = eng.resample_vals_batched(xs, us, order, nrep=nrep, sampler=smp, path="int8", prep=prep)
+    assert eng.batched_info()["prep_reused"] and torch.equal(b, ref8)
+    # the rule itself choosing FP64 (a short series): nothing is bound either
+    xs2, us2, _ = states(2, 100000, 4, 30)
+    p2 = eng.ResamplePrep()
+    eng.resample_vals_batched(xs2, us2, order, nrep=64, sampler=eng.DeviceSampler(8, 2 * 64, 100000), prep=p2)
+    assert eng.batched_info()["path"] == "fp64" and p2.key is None
+    # the same through a collection: forced FP64 first, the default (int8) afterwards

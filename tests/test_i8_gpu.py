@@ -394,7 +394,7 @@ def test_default_dispatch_derivs_within_1e10_of_oracle(eng, orc, kind):
     from thermoextrap_amd import symbolic as S
 
     series = xem.derivatives.series
-    worst_b = worst_rel = worst_kappa = 0.0
+    worst_b = worst_rel = worst_kappa = worst_old = 0.0
     for r in (0, 17, nrep - 1):
         fr = freq[r].astype(np.float64)
         ref = dor.derivs_x_ave(xh, uh, order, w=fr if wh is None else fr * wh)   # (order + 1, C)
@@ -407,8 +407,17 @@ def test_default_dispatch_derivs_within_1e10_of_oracle(eng, orc, kind):
         kappa, rel = B / np.abs(ref), err / np.abs(ref)
         ok = kappa <= 100.0
         assert np.all(rel[ok] < 1e-10), (kind, r, rel[ok].max(), info)
+        # round 3's criterion as well (round-4 advice: the bound above must add coverage, not replace it): 1e-10 relative on
+        # EVERY entry of every order, the denominator floored at the order's median |d_k| over the columns.  It holds on HEAD
+        # for all three kinds (worst 3e-15 .. 6e-15, GPU run of round 5) -- the switch to the bound in round 4 was made for
+        # the N = 1e8 test, where small derivatives sit far below their order's median, not because this assertion failed.
+        floor = np.maximum(np.abs(ref), np.median(np.abs(ref), axis=1, keepdims=True))
+        rel_old = err / floor
+        assert np.all(rel_old < 1e-10), (kind, r, rel_old.max(), info)
+        worst_old = max(worst_old, float(rel_old.max()))
         worst_b, worst_kappa, worst_rel = max(worst_b, (err / B).max()), max(worst_kappa, kappa.max()), max(worst_rel, rel[ok].max())
-    print(f"{kind}: max |err| / bound {worst_b:.3e}; max rel (kappa <= 100) {worst_rel:.3e}; worst kappa {worst_kappa:.3e}")
+    print(f"{kind}: max |err| / bound {worst_b:.3e}; max rel (kappa <= 100) {worst_rel:.3e}; worst kappa {worst_kappa:.3e}; "
+          f"round-3 criterion (median-floored relative error, limit 1e-10): worst {worst_old:.3e}")
 
 
 def test_from_resample_vals_matches_resample_and_oracle(eng, orc):

@@ -295,7 +295,57 @@ def apply_post_func(func: Poly, post_func) -> Poly:
         if post_func.startswith("pow_"):
             return func ** int(post_func.split("_")[-1])
         raise ValueError("post_func must be callable or in {minus_log, pow_1, pow_2, ...}")
+    # A callable.  The reference hands it the sympy function and differentiates what comes back (models.py:124-137), so
+    # callables written for it are sympy -> sympy (``lambda f: f**2``, ``lambda f: -sp.log(f)``): call it with a sympy symbol
+    # first and translate the expression -- a Laurent polynomial in f with rational coefficients, optionally one -log(f)
+    # term: what the table evaluator can represent.  A callable written for this package's Poly type gets the Poly.
+    import sympy as sp
+
+    fs = sp.Symbol("f", positive=True)
+    try:
+        expr = post_func(fs)
+    except Exception:  # noqa: BLE001 -- not a sympy-style callable
+        expr = None
+    if isinstance(expr, sp.Basic):
+        return poly_from_sympy(expr, fs, func)
     return post_func(func)
+
+
+def poly_from_sympy(expr, fs, func: Poly) -> Poly:
+    """``expr`` (sympy, in the symbol ``fs``) with ``func`` substituted for the symbol, as a Poly: sum_k c_k f^k with
+    integer k (negative allowed) and rational c_k, plus at most one ``-log(f)`` (coefficient exactly -1: what the table's
+    TXM_FUNC_MINUS_LOG flag evaluates).  Anything else (exp, sqrt, other functions of f) raises NotImplementedError."""
+    import sympy as sp
+    from fractions import Fraction
+
+    expr = sp.expand(expr)
+    out = None
+    rest = sp.Integer(0)
+    for term in sp.Add.make_args(expr):
+        if term.has(sp.log):
+            if sp.simplify(term + sp.log(fs)) != 0:
+                raise NotImplementedError(f"post_func: only a bare -log(f) term is supported, got {term}")
+            if out is not None:
+                raise NotImplementedError("post_func: more than one log term")
+            out = apply_post_func(func, "minus_log")
+        else:
+            rest += term
+    poly = None
+    for term in sp.Add.make_args(sp.expand(rest)):
+        if term == 0:
+            continue
+        c, k = term.as_coeff_exponent(fs)
+        if c.has(fs) or not (k.is_Integer and c.is_Rational):
+            raise NotImplementedError(f"post_func: {term} is not a rational multiple of an integer power of f")
+        cf = Fraction(int(c.p), int(c.q))
+        k = int(k)
+        t = (Poly.const(1) if k == 0 else func ** k) * cf
+        poly = t if poly is None else poly + t
+    if out is None:
+        if poly is None:
+            raise NotImplementedError("post_func returned 0")
+        return poly
+    return out if poly is None else out + poly
 
 
 # ---------------------------------------------------------------------------
