@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes over the int8 bootstrap kernel (GPU box):  bash tools/i8_pmc.sh [N] [nrep]
 cd "$(dirname "$0")/.."
-export TMPDIR=/tmp TXM_I8=1
+export TMPDIR=/tmp TXM_I8=${TXM_I8:-1}
 N=${1:-2e7}; NREP=${2:-1000}
 i=0
 for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" \
@@ -11,7 +11,7 @@ for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_I
   i=$((i+1))
   rm -rf gpurun_out/i8_pmc$i
   timeout -k 10 240 rocprofv3 --pmc $set --kernel-include-regex "${KREGEX:-resample_i8t?_kernel}" -d gpurun_out/i8_pmc$i -o pmc --output-format csv -- \
-      python3 tools/prof_driver.py $N $NREP 32 4 1 > gpurun_out/i8_pmc$i.log 2>&1 || { echo "pass $i failed"; tail -5 gpurun_out/i8_pmc$i.log; }
+      python3 tools/prof_driver.py $N $NREP 32 ${PMC_ORDER:-4} 1 > gpurun_out/i8_pmc$i.log 2>&1 || { echo "pass $i failed"; tail -5 gpurun_out/i8_pmc$i.log; }
 done
 python3 - <<'PY'
 import csv, glob, collections
@@ -29,7 +29,7 @@ tag = os.environ.get("PMC_TAG")
 if tag and c:
     q = 4.0  # SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)
     d = {"tag": tag, "kernel_regex": os.environ.get("KREGEX", "resample_i8t?_kernel"), "csrc_sha": csrc_sha(),
-         "workload": {"n_samp": int(float(os.environ.get("PMC_N", "2e7"))), "n_obs": 32, "order": 4, "nrep": int(os.environ.get("PMC_NREP", "1000"))},
+         "workload": {"n_samp": int(float(os.environ.get("PMC_N", "2e7"))), "n_obs": 32, "order": int(os.environ.get("PMC_ORDER", "4")), "nrep": int(os.environ.get("PMC_NREP", "1000"))},
          "command": "bash tools/i8_pmc.sh N NREP (four rocprofv3 --pmc passes of tools/prof_driver.py, one launch each; counters summed over the chip)",
          "counters": c,
          "derived": {
