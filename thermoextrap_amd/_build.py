@@ -24,7 +24,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-pass-faile
 # (-Wno-inline-asm: its store asm names M0 as clobbered -- it writes it -- and clang remarks on every instance that M0 is
 # a reserved register)
 _I8T = ["-mllvm", "-amdgpu-mfma-vgpr-form", "-Wno-inline-asm"]
-EXTRA_FLAGS = {"txm_resample_i8t.hip": _I8T, "txm_resample_i8g.hip": _I8T, "txm_sampler.hip": ["-ffp-contract=off"]}
+# txm_resample_i8g.hip: 12 accumulator tiles (192 of the 256 registers).  The greedy register allocator assigns "global" live
+# ranges first and the sixteen-register tiles into what is left; a stray scalar in the middle of the file then leaves no aligned
+# run of sixteen and whole tiles are spilled (any small edit flipped the kernel between 2 and 200+ spilled registers).  With
+# the widest register classes assigned first every instance builds with 0-9 spills, none inside the k-steps.
+_I8G = _I8T + ["-mllvm", "-greedy-regclass-priority-trumps-globalness=1"]
+EXTRA_FLAGS = {"txm_resample_i8t.hip": _I8T, "txm_resample_i8g.hip": _I8G, "txm_sampler.hip": ["-ffp-contract=off"]}
 
 
 def _hipcc() -> str:

@@ -67,6 +67,14 @@ __device__ __forceinline__ uint32_t g_min_progress(const uint32_t *pg) {
   }
   return m;
 }
+// the lane id, recomputed where it is used: addresses that are a function of the lane and are needed once a block (the DMA
+// offsets, the staging addresses) would otherwise be held in registers across the k-steps -- the kernel has none to spare,
+// they were spilled, and every reload put a scratch round trip + s_waitcnt vmcnt on the block's critical path
+__device__ __forceinline__ uint32_t g_lane_now() {
+  uint32_t l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
 template <int N>
 __device__ __forceinline__ void g_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -141,6 +149,9 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[e][q] = (v16i)(0);
 
+#ifdef TXM_G_CLOCKS  // diagnostic build: shader cycles (s_memtime) against the 100 MHz reference clock (s_memrealtime) over the kernel
+  const long long gc0 = clock64(), gr0 = wall_clock64();
+#endif
 #ifdef TXM_G_TIMING  // diagnostic build: cycles per phase of two workgroups (tools/i8g_timing.py)
   long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tk0 = clock64();
@@ -170,15 +181,16 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // stage the factors; landing is published by the block's barrier, behind every issuer's vmcnt(0).
   const bool loader = !XBLK || wave < 4;  // uniform
   const int qsrc2 = 4 * (wave + 4) < a.C ? wave + 4 : 0;
-  const uint32_t xvoff2 = (uint32_t)(((lane >> 1) * a.ldx_s + a.col0 + 4 * qsrc2) * 8 + (lane & 1) * 16);
   auto x_request = [&](int slot) {  // chunk cq -> ring slot; chunks past the window re-read its last one
 #ifdef TXM_G_NO_XDMA  // ablation build
     if (slot >= 0) { ++cq; return; }
 #endif
     if constexpr (XBLK) {
       if (loader) {
-        g_dma16(xq, xvoff, xring + (uint32_t)slot * 1024u);
-        g_dma16(xq, xvoff2, xring + (uint32_t)(4 * XRN * 1024) + (uint32_t)slot * 1024u);  // wave + 4's ring
+        const uint32_t ln = g_lane_now();
+        const uint32_t row = (ln >> 1) * (uint32_t)(a.ldx_s * 8) + (ln & 1) * 16u + (uint32_t)(a.col0 * 8);
+        g_dma16(xq, row + (uint32_t)(32 * qsrc), xring + (uint32_t)slot * 1024u);
+        g_dma16(xq, row + (uint32_t)(32 * qsrc2), xring + (uint32_t)(4 * XRN * 1024) + (uint32_t)slot * 1024u);  // wave + 4's ring
       }
     } else {
       g_dma16(xq, xvoff, xring + (uint32_t)slot * 1024u);
@@ -197,17 +209,18 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
   };
   // ---- count words of block B -> ring buffer B & 1: the wave's two 1-KiB pieces
-  auto a_request = [&](int B) {
+  auto a_request = [&](int B, int piece = -1) {
     const int Bc = B < nblk ? B : nblk - 1;
 #ifdef TXM_G_NO_ADMA  // ablation build
     if (Bc >= 0) return;
 #endif
-    if constexpr (XBLK) {  // four 1-KiB pieces per loader wave
+    if constexpr (XBLK) {  // four 1-KiB pieces per loader wave (piece >= 0: that one only)
       if (!loader) return;
       const unsigned char *src = tab + (size_t)Bc * (G_BS * G_KSTEP_BYTES) + (size_t)wave * 4096;
       const uint32_t dst = (uint32_t)(OFF_A + (B & 1) * (G_BS * G_KSTEP_BYTES) + wave * 4096);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) g_dma16(src + i * 1024, (uint32_t)lane * 16u, dst + (uint32_t)i * 1024u);
+      for (int i = 0; i < 4; ++i)
+        if (piece < 0 || piece == i) g_dma16(src + i * 1024, g_lane_now() * 16u, dst + (uint32_t)i * 1024u);
     } else {
       const unsigned char *src = tab + (size_t)Bc * (G_BS * G_KSTEP_BYTES) + (size_t)wave * 2048;
       const uint32_t dst = (uint32_t)(OFF_A + (B & 1) * (G_BS * G_KSTEP_BYTES) + wave * 2048);
@@ -223,8 +236,9 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if constexpr (XBLK) {  // loader wave w: chunk w of u, and of w
       if (!loader) return;
       const int64_t i0 = chunk_sample(c);
-      g_dma4(a.u + i0, (uint32_t)lane * 4u, (uint32_t)(OFF_RAW + (B % 3) * G_RAW + wave * 256));
-      if constexpr (WEIGHTED) g_dma4(a.w + i0, (uint32_t)lane * 4u, (uint32_t)(OFF_RAW + (B % 3) * G_RAW + G_BS * 256 + wave * 256));
+      const uint32_t l4 = g_lane_now() * 4u;
+      g_dma4(a.u + i0, l4, (uint32_t)(OFF_RAW + (B % 3) * G_RAW + wave * 256));
+      if constexpr (WEIGHTED) g_dma4(a.w + i0, l4, (uint32_t)(OFF_RAW + (B % 3) * G_RAW + G_BS * 256 + wave * 256));
     } else {
       const double *src = ((WEIGHTED && wave >= 4) ? a.w : a.u) + chunk_sample(c);
       g_dma4(src, (uint32_t)lane * 4u, (uint32_t)(OFF_RAW + (B % 3) * G_RAW + (wave >> 2) * (G_BS * 256) + (wave & 3) * 256));
@@ -233,9 +247,12 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // ---- factors of block B from raw buffer B % 3 into factor buffer B % 3 (two waves, one sample per lane: waves 0 and 1 where
   // the older waves load, else waves 6 and 7)
   auto stage_factors = [&](int B) {
-    constexpr int SW = XBLK ? 0 : 6;  // first staging wave
+#ifndef TXM_G_SW
+#define TXM_G_SW 6
+#endif
+    constexpr int SW = TXM_G_SW;  // first staging wave
     if (wave < SW || wave >= SW + 2) return;  // uniform
-    const int e = (int)threadIdx.x - SW * 64;  // entry: chunk-in-block e >> 5, sample e & 31
+    const int e = (int)g_lane_now() + (wave - SW) * 64;  // entry: chunk-in-block e >> 5, sample e & 31
     const double *raw = reinterpret_cast<const double *>(lds + OFF_RAW + (B % 3) * G_RAW);
 #ifdef TXM_G_TIMING
     G_TICK(1);
@@ -253,7 +270,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     for (int k = 0; k < J0; ++k) pw *= du;
 #pragma unroll
     for (int jj = 0; jj < JN; ++jj) {
-      f[jj] = pw;
+      if (WEIGHTED || J0 + jj > 0) f[jj] = pw;  // (the constant 1 of an unweighted power 0 is never read)
       pw *= du;
     }
   };
@@ -270,8 +287,10 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
                    "n"(off + 256 + T_PLANE + 128)
                  : "memory", "m0");
   };
-  // the words of row set fi for this lane's two samples: f[uu] = the sample factor, d[uu] = dx (or dy)
-  auto produce_row = [&](auto fic, const double (&f)[2], const double (&d)[2]) {
+  // the words of row set fi for this lane's two samples: f[uu] = the sample factor, d[uu] = dx (or dy).  `ahead()` runs
+  // between the last use of f / d and the stores: the LDS reads the NEXT slot consumes are issued there, so that they sit in
+  // front of this slot's four stores and two operand reads in the wave's (in-order) LDS queue
+  auto produce_row = [&](auto fic, double (&f)[2], const double (&d)[2], auto &&ahead) {
     constexpr int fi = decltype(fic)::value;
     uint32_t lo[2], hi[2];
 #pragma unroll
@@ -295,6 +314,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         hi[uu] = (hi[uu] & 0x00ffffffu) | (dig ^ oxor);
       }
     }
+    ahead();
     store_x2(lo[0], hi[0], lo[1], hi[1], fi * T_PB);
   };
 
@@ -358,8 +378,8 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
           f[uu] = pw;
         }
       }
-      if constexpr (YS && fi == JN) produce_row(fic, f, dy);
-      else produce_row(fic, f, dx);
+      if constexpr (YS && fi == JN) produce_row(fic, f, dy, [] {});
+      else produce_row(fic, f, dx, [] {});
     });
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // factors of block 0 visible; chunk 0's x slot free
@@ -390,8 +410,28 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #ifdef TXM_G_PRIO  // experiment: the younger wave of every SIMD at a higher issue priority
   if (wave >= 4) __builtin_amdgcn_s_setprio(TXM_G_PRIO);
 #endif
+  // ---- what a slot reads one slot AHEAD (see below): the factors of the next row set, the raw x of the next chunk
+  auto read_factors = [&](auto pnc, auto finc, uint32_t fb, double (&f)[2]) {
+    constexpr int pn = decltype(pnc)::value, fin = decltype(finc)::value;
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) {
+      if constexpr (YS && fin == JN) {
+        if constexpr (WEIGHTED) f[uu] = *(lds_cd)(lds + fb + uu * G_FU + (pn * 16 * NPT + (J0 == 0 ? 0 : JN)) * 8);
+        else f[uu] = 1.0;
+      } else if constexpr (!WEIGHTED && J0 == 0 && fin == 0) {
+        f[uu] = 1.0;
+      } else {
+        f[uu] = *(lds_cd)(lds + fb + uu * G_FU + (pn * 16 * NPT + fin) * 8);
+      }
+    }
+  };
   v4i A[4];
   v2i Bt[NS][2];
+  double f[2], xr[2], yr[2] = {0.0, 0.0};
+  // loop-carried bases (opaque below: the reads take 16-bit immediate offsets): the factor buffer of the block, and the x ring
+  // (half of the block when a block's chunks are requested together)
+  uint32_t f_va = (uint32_t)(OFF_F + ps * NPT * 8);
+  uint32_t x_va = xring + (uint32_t)(ps * 32 + cl * 8);
   {
     const uint32_t a_va0 = (uint32_t)OFF_A + (uint32_t)lane * 16u;
 #pragma unroll
@@ -401,6 +441,9 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       Bt[fi][0] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB));
       Bt[fi][1] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB + 128));
     }
+    read_factors(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, f_va, f);
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) xr[uu] = *(lds_cd)(lds + x_va + (XBLK ? 0 : 1024) + uu * 512);  // chunk 1
   }
 #pragma unroll 1
   for (int B = 0; B < nblk; ++B) {
@@ -418,103 +461,187 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // staging waves -- phase clocks, profiles/r05_experiments.md)
     stage_factors(B + 1);
     G_TICK(7);
-    a_request(B + 1);
     raw_request(B + 2);
-    if constexpr (XBLK) {  // the next block's x: chunks 4 (B + 1) + 1 .. + 4 into the ring half this block does not read
+#ifdef TXM_G_BURST  // (experiment build: the next block's count words and x requested here, 14 pieces per loader wave at once)
+    constexpr bool SPREAD = false;
+#else
+    constexpr bool SPREAD = XBLK && NS >= 2;  // (one row set: a step is short, two bursts of 6 cost more than one of 12: 77.7 -> 75.6 ms at order 0)
+#endif
+    if constexpr (!SPREAD) {
+      a_request(B + 1);
+      if constexpr (XBLK) {  // the next block's x: chunks 4 (B + 1) + 1 .. + 4 into the ring half this block does not read
 #pragma unroll
-      for (int i = 0; i < G_BS; ++i) x_request(4 * ((B + 1) & 1) + i);
+        for (int i = 0; i < G_BS; ++i) x_request(4 * ((B + 1) & 1) + i);
+      }
     }
+    // SPREAD: the eight requests of the next block (four count pieces, four x chunks = 12 pieces per loader wave) go out one or
+    // two per slot over the slots of steps 0 and 1 -- a burst of 56 KiB per CU filled the vector memory pipeline and held
+    // its issuers for ~2000 cycles a block (the DMA cost 20 of the pass's 75 ms; additive ablation, profiles/r05_experiments.md)
+    constexpr int ISSUE_SLOTS = 2 * NS;
+    auto issue_items = [&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if constexpr (SPREAD && k < ISSUE_SLOTS) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j * ISSUE_SLOTS / 8 == k) {
+            if ((j & 1) == 0) a_request(B + 1, j >> 1);  // interleaved: count piece, x chunk, count piece, ...
+            else x_request(4 * ((B + 1) & 1) + (j >> 1));
+          }
+      }
+    };
     G_TICK(2);
     // count words: this block's steps 1..3 from buffer B & 1, the next block's step 0 from the other buffer
     uint32_t a_va = (uint32_t)(OFF_A + (B & 1) * (G_BS * G_KSTEP_BYTES)) + (uint32_t)lane * 16u;
     uint32_t a_vn = (uint32_t)(OFF_A + ((B + 1) & 1) * (G_BS * G_KSTEP_BYTES)) + (uint32_t)lane * 16u;
-    uint32_t f_va = (uint32_t)(OFF_F + (B % 3) * (2 * G_FU) + ps * NPT * 8);
-    uint32_t x_va = xring + (uint32_t)(ps * 32 + cl * 8) + (XBLK ? (uint32_t)((B & 1) * 4096) : 0u);
-    asm volatile("" : "+v"(f_va), "+v"(x_va), "+v"(a_va), "+v"(a_vn));  // opaque bases: the reads below take 16-bit immediate offsets
-    // (Experiment, -DTXM_G_ANTIPHASE: the younger wave of every SIMD takes the block's barrier half a row set later than the
-    // older one -- behind the last row set's MFMAs -- so that out of the barrier one issues MFMAs while the other slices.
-    // The kernel's time is its LDS / vector / DMA time PLUS most of its MFMA time (ablations, profiles/r05_experiments.md),
-    // and waves in step on a shared matrix pipe looked like the reason; measured: 114.4 against 107.9 ms at order 2, 169.1
-    // against 163.7 at order 4 -- slower.  Left switched off.)
+    asm volatile("" : "+v"(f_va), "+v"(x_va), "+v"(a_va), "+v"(a_vn));
+    // SLOT = one row set of one step: its four MFMAs, then the words of chunk s + 1 for that row set.  A wave issues in order,
+    // and its LDS operations complete in order: a read consumed right where it was issued -- the first cuts read a slot's factors
+    // behind the stores and operand reads of the slot before and waited for them three MFMAs later, and read x at the top of the
+    // step -- DRAINS the wave's whole LDS queue under the load of eight waves, four times a step, with the matrix pipe idle:
+    // the kernel's time was its LDS time PLUS its MFMA time (ablations, profiles/r05_experiments.md), although the two do
+    // overlap on this chip when nothing waits (tools/mfma_lds_overlap_probe.hip: 12 MFMAs + 24 LDS operations per wave take
+    // 0.39 us interleaved against 0.37 + 0.34 alone).  So every read is issued ONE SLOT AHEAD of its use and IN FRONT of that
+    // slot's stores: the next slot's factors between the last use of this slot's and its stores (same registers), the raw x
+    // of the next step behind the last slot's operand reads (into the registers of dx, dead by then), y in the slot before its
+    // row set; the waits the compiler derives are lgkmcnt(6) and up -- nothing drains but the block's barrier.
+    // (An experiment that let the younger wave of a SIMD take the barrier behind the last row set's MFMAs -- the waves of a
+    // SIMD out of phase -- was slower: 114.4 against 107.9 ms at order 2.)
     t_static_for<G_BS>([&](auto pc) {
       constexpr int p = decltype(pc)::value;
-      constexpr int slot = XBLK ? p : ((p + 1) & 3);
-      G_TICK(3);
-      if constexpr (!XBLK) g_wait_vm<3 * NX + 3>();
-      G_TICK(4);
-      // x of chunk s + 1 (y: read where its row set starts -- four registers fewer live across the power row sets)
       double dx[2], dy[2] = {0.0, 0.0};
-#pragma unroll
-      for (int uu = 0; uu < 2; ++uu) dx[uu] = (*(lds_cd)(lds + x_va + slot * 1024 + uu * 512) - px) * sc;
       t_static_for<NS>([&](auto fic) {
         constexpr int fi = decltype(fic)::value;
         constexpr bool last = fi == NS - 1;
-        auto block_sync = [&]() {
+        if constexpr (p == G_BS - 1 && last) {
           G_TICK(3);
           asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(XBLK ? 0 : 3 * NX) : "memory");
 #ifndef TXM_G_NO_BARRIER  // (ablation build: no barrier)
           asm volatile("s_barrier" ::: "memory");  // the block's barrier
 #endif
           G_TICK(6);
+        }
+        auto ahead = [&]() {
+          if constexpr (!last) {
+            read_factors(pc, std::integral_constant<int, fi + 1>{}, f_va, f);
+          } else if constexpr (p < G_BS - 1) {
+            read_factors(std::integral_constant<int, p + 1>{}, std::integral_constant<int, 0>{}, f_va, f);
+          } else {  // behind the barrier: the next block's buffer
+            f_va = (uint32_t)(OFF_F + ((B + 1) % 3) * (2 * G_FU) + ps * NPT * 8);
+            asm volatile("" : "+v"(f_va));
+            read_factors(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, f_va, f);
+          }
+          if constexpr (YS && fi == JN - 1) {  // y of the chunk being sliced (same ring slot as its x)
+#pragma unroll
+            for (int uu = 0; uu < 2; ++uu) yr[uu] = *(lds_cd)(lds + x_va + (OFF_Y - OFF_X) + ((p + 1) & 3) * 1024 + uu * 512);
+          }
+          if constexpr (last) {  // raw x of chunk s + 2, which the next step slices (dx is dead: into its registers)
+            if constexpr (XBLK) {
+              if constexpr (p == G_BS - 1) {  // the other half of the ring (landed: every loader waited before the barrier)
+                x_va = xring + (uint32_t)(ps * 32 + cl * 8) + (uint32_t)(((B + 1) & 1) * 4096);
+                asm volatile("" : "+v"(x_va));
+              }
+#pragma unroll
+              for (int uu = 0; uu < 2; ++uu) xr[uu] = *(lds_cd)(lds + x_va + (p == G_BS - 1 ? 0 : p + 1) * 1024 + uu * 512);
+            } else {
+              // vmcnt: chunk s + 2 was requested at the end of step s - 3; newer than it are the x (+ y) pieces of steps s - 2
+              // and s - 1 and the three pieces of a block start at the top of step s - 2, s - 1 or s (none when p = 3)
+              g_wait_vm<2 * NX + (p == G_BS - 1 ? 0 : 3)>();
+#pragma unroll
+              for (int uu = 0; uu < 2; ++uu) xr[uu] = *(lds_cd)(lds + x_va + ((p + 2) & 3) * 1024 + uu * 512);
+            }
+          }
         };
-#ifdef TXM_G_ANTIPHASE  // experiment build (measured: +6 %, see above)
-        constexpr bool ANTI = true;
-#else
-        constexpr bool ANTI = false;
+        const v4i Bv = {Bt[fi][0][0], Bt[fi][0][1], Bt[fi][1][0], Bt[fi][1][1]};
+        // The slot, INTERLEAVED: a piece of the slicing behind every MFMA (pinned: the scheduler otherwise issues the four
+        // MFMAs back to back, and a wave that waits for the matrix pipe between two of its own MFMAs issues nothing else).
+        auto mfma_q = [&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          t_mfma<true>(acc[fi][q], A[q], Bv);
+          // quarter q's count operand of the NEXT step into the registers just used for the last time
+#ifndef TXM_G_NO_AREAD  // (ablation build)
+          if constexpr (last) A[q] = *(lds_cv4)(lds + (p == G_BS - 1 ? a_vn : a_va + (p + 1) * G_KSTEP_BYTES) + q * 1024);
 #endif
-        const bool late_sync = ANTI && wave >= 4;  // uniform
-        if constexpr (p == G_BS - 1 && last) {
-          if (!late_sync) block_sync();
+        };
+#ifdef TXM_G_NO_PIN
+#define G_PIN() do {} while (0)
+#else
+#define G_PIN() __builtin_amdgcn_sched_barrier(0)
+#endif
+        G_PIN();
+        mfma_q(std::integral_constant<int, 0>{});
+        G_PIN();
+        issue_items(std::integral_constant<int, p * NS + fi>{});
+        G_PIN();
+        // (a) the fixed-point words of chunk s + 1, row set fi
+        if constexpr (fi == 0) {
+#pragma unroll
+          for (int uu = 0; uu < 2; ++uu) dx[uu] = (xr[uu] - px) * sc;
         }
         if constexpr (YS && fi == JN) {
 #pragma unroll
-          for (int uu = 0; uu < 2; ++uu) dy[uu] = (*(lds_cd)(lds + x_va + (OFF_Y - OFF_X) + slot * 1024 + uu * 512) - py) * scy;
+          for (int uu = 0; uu < 2; ++uu) dy[uu] = (yr[uu] - py) * scy;
         }
-        // factors of the sliced chunk, row set fi (read ahead of the MFMAs that cover their latency)
-        double f[2];
+        uint32_t lo[2], hi[2];
 #pragma unroll
         for (int uu = 0; uu < 2; ++uu) {
-          if constexpr (YS && fi == JN) {
-            f[uu] = !WEIGHTED ? 1.0 : *(lds_cd)(lds + f_va + uu * G_FU + (p * 16 * NPT + (J0 == 0 ? 0 : JN)) * 8);
-          } else if constexpr (!WEIGHTED && J0 == 0 && fi == 0) {
-            f[uu] = 1.0;
-          } else {
-#ifdef TXM_G_NO_FREAD  // ablation build: no factor reads (constants)
-            f[uu] = 0.5 + 0.125 * fi;
+#ifdef TXM_G_NO_SLICE  // (ablation build: constants are stored)
+          lo[uu] = 0x01020304u + uu;
+          hi[uu] = 0x04030201u + uu;
+          asm volatile("" : "+v"(lo[uu]), "+v"(hi[uu]));
 #else
-            f[uu] = *(lds_cd)(lds + f_va + uu * G_FU + (p * 16 * NPT + fi) * 8);
+          const double dd = (YS && fi == JN) ? dy[uu] : dx[uu];
+          const uint64_t bits = (uint64_t)__double_as_longlong(fma(f[uu], dd, T_MAGIC));
+          lo[uu] = (uint32_t)bits;
+          hi[uu] = (uint32_t)(bits >> 32);
 #endif
+        }
+        G_PIN();
+        mfma_q(std::integral_constant<int, 1>{});
+        G_PIN();
+#ifndef TXM_G_NO_SLICE
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) {
+          lo[uu] ^= 0x80808080u;
+          hi[uu] ^= 0x00008080u;
+        }
+#endif
+        G_PIN();
+        // (b) the u-row overlay (wave-uniform branch, kept by the volatile permute), then the reads of the NEXT slot
+#if !defined(TXM_G_NO_OVERLAY) && !defined(TXM_G_NO_SLICE)
+        if (fi < JN && ofi == fi) {
+#pragma unroll
+          for (int uu = 0; uu < 2; ++uu) {
+            const uint64_t ub = (uint64_t)__double_as_longlong(__builtin_ldexp(f[uu], 50) + T_MAGIC);
+            uint32_t dig;
+            asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(dig) : "v"((uint32_t)(ub >> 32)), "v"((uint32_t)ub), "v"(osel));
+            hi[uu] = (hi[uu] & 0x00ffffffu) | (dig ^ oxor);
           }
         }
-        const v4i Bv = {Bt[fi][0][0], Bt[fi][0][1], Bt[fi][1][0], Bt[fi][1][1]};
-        if constexpr (p == G_BS - 1 && last) {
-          // (ONE copy of the MFMAs for both kinds of wave -- a copy per kind cost the register allocator 450 spilled registers:
-          // only the barrier itself sits behind a branch; the next block's count words are read behind the later of the two)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) t_mfma<true>(acc[fi][q], A[q], Bv);
-          if (late_sync) block_sync();
-#pragma unroll
-          for (int q = 0; q < 4; ++q) A[q] = *(lds_cv4)(lds + a_vn + q * 1024);
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            t_mfma<true>(acc[fi][q], A[q], Bv);
-            // quarter q's count operand of the NEXT step into the registers just used for the last time
-            if constexpr (last) A[q] = *(lds_cv4)(lds + a_va + (p + 1) * G_KSTEP_BYTES + q * 1024);
-          }
-        }
-        // the words of chunk s + 1, row set fi
-#ifndef TXM_G_NO_PRODUCE  // (ablation build: no slicing, no stores)
-        if constexpr (YS && fi == JN) produce_row(fic, f, dy);
-        else produce_row(fic, f, dx);
-#else
-        asm volatile("" ::"v"(f[0]), "v"(f[1]), "v"(dx[0]), "v"(dx[1]), "v"(dy[0]));
 #endif
-        // ... and -- behind the stores, behind the MFMAs that read the old ones -- the next step's B operand of the row set
+        G_PIN();
+#ifndef TXM_G_NO_AHEAD  // (ablation build: no factor / x / y reads)
+        ahead();
+#endif
+        G_PIN();
+        mfma_q(std::integral_constant<int, 2>{});
+        G_PIN();
+        // (c) the stores
+#ifndef TXM_G_NO_PRODUCE  // (ablation build: no stores)
+        store_x2(lo[0], hi[0], lo[1], hi[1], fi * T_PB);
+#else
+        asm volatile("" ::"v"(lo[0]), "v"(hi[0]), "v"(lo[1]), "v"(hi[1]));
+#endif
+        G_PIN();
+        mfma_q(std::integral_constant<int, 3>{});
+        G_PIN();
+        // (d) behind the stores, behind the MFMAs that read the old ones: the next step's B operand of the row set
+#ifndef TXM_G_NO_TRREAD  // (ablation build)
         Bt[fi][0] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB));
         Bt[fi][1] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB + 128));
+#endif
+        G_PIN();
       });
-      if constexpr (!XBLK) x_request(slot);  // chunk s + 5 (slot of chunk s + 1, just read)
+      if constexpr (!XBLK) x_request((p + 1) & 3);  // chunk s + 5 (slot of chunk s + 1: x read a step ago, y in this one)
     });
   }
 
@@ -575,6 +702,13 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   for (int fi = 0; fi < NS; ++fi)
 #pragma unroll
     for (int q = 0; q < 4; ++q) flush_tile(acc[fi][q], q, fi);
+#ifdef TXM_G_CLOCKS
+  if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 1064)) {
+    double *o = a.wtab + a.nwin * I8_WT_STRIDE + ((blockIdx.x ? 1 : 0) * T_WAVES + wave) * 8;
+    o[0] = (double)(clock64() - gc0);
+    o[1] = (double)(wall_clock64() - gr0);
+  }
+#endif
 #ifdef TXM_G_TIMING
   G_TICK(0);
   if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 1064))
@@ -628,8 +762,14 @@ int launch_resample_i8g(const I8Args &a, int K, bool weighted, const unsigned ch
     } else rc = weighted ? launch_pass_g<J0_, JN_, true, false>(a, K, table, rep_begin, n_grp, st)                \
                        : launch_pass_g<J0_, JN_, false, false>(a, K, table, rep_begin, n_grp, st);              \
   }
+#ifdef TXM_G_ONLY03  // (ablation builds: one instance, seconds to compile)
+    if (j0 == 0 && jn == 3 && !y_here && !weighted) rc = launch_pass_g<0, 3, false, false>(a, K, table, rep_begin, n_grp, st);
+#elif defined(TXM_G_ONLY01)
+    if (j0 == 0 && jn == 1 && !y_here && !weighted) rc = launch_pass_g<0, 1, false, false>(a, K, table, rep_begin, n_grp, st);
+#else
     G_CASE(0, 1) G_CASE(0, 2) G_CASE(0, 3) G_CASE(2, 1) G_CASE(2, 2) G_CASE(3, 1) G_CASE(3, 2) G_CASE(3, 3)
     G_CASE(5, 1) G_CASE(5, 2) G_CASE(6, 1) G_CASE(6, 2)
+#endif
 #undef G_CASE
     if (rc != TXM_OK) {
       if (rc == TXM_ERR_INVALID) set_error("resample_i8g: no pass for powers %d..%d", j0, j0 + jn - 1);
