@@ -167,8 +167,6 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   };
   // ---- x ring: the wave's own four columns of a chunk, [32 samples][4 columns] doubles, lane L fetches the 16-byte half
   // (L & 1) of row L >> 1
-  const uint32_t xvoff = (uint32_t)(((lane >> 1) * a.ldx_s + a.col0 + 4 * qsrc) * 8 + (lane & 1) * 16);
-  const uint32_t yvoff = YS ? (uint32_t)(((lane >> 1) * a.ldy_s + a.col0 + 4 * qsrc) * 8 + (lane & 1) * 16) : 0u;
   const uint32_t xring = (uint32_t)(OFF_X + wave * XRN * 1024), yring = (uint32_t)(OFF_Y + wave * XRN * 1024);
   int cq = 0;  // chunk of the next x request (uniform)
   const char *xq = reinterpret_cast<const char *>(a.x + chunk_sample(0) * a.ldx_s);
@@ -193,8 +191,12 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         g_dma16(xq, row + (uint32_t)(32 * qsrc2), xring + (uint32_t)(4 * XRN * 1024) + (uint32_t)slot * 1024u);  // wave + 4's ring
       }
     } else {
-      g_dma16(xq, xvoff, xring + (uint32_t)slot * 1024u);
-      if constexpr (YS) g_dma16(yq, yvoff, yring + (uint32_t)slot * 1024u);
+      // (offsets recomputed from the lane id: held across the k-steps they were spilled in the second-matrix instances, and a
+      // scratch reload's s_waitcnt vmcnt -- the wave's DMA pieces complete in order with it -- drained the x / y prefetch every step)
+      const uint32_t ln = g_lane_now();
+      const uint32_t cb = (ln & 1) * 16u + (uint32_t)((a.col0 + 4 * qsrc) * 8);
+      g_dma16(xq, (ln >> 1) * (uint32_t)(a.ldx_s * 8) + cb, xring + (uint32_t)slot * 1024u);
+      if constexpr (YS) g_dma16(yq, (ln >> 1) * (uint32_t)(a.ldy_s * 8) + cb, yring + (uint32_t)slot * 1024u);
     }
     ++cq;
     if (cq < nsteps) {
@@ -224,8 +226,9 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     } else {
       const unsigned char *src = tab + (size_t)Bc * (G_BS * G_KSTEP_BYTES) + (size_t)wave * 2048;
       const uint32_t dst = (uint32_t)(OFF_A + (B & 1) * (G_BS * G_KSTEP_BYTES) + wave * 2048);
-      g_dma16(src, (uint32_t)lane * 16u, dst);
-      g_dma16(src + 1024, (uint32_t)lane * 16u, dst + 1024u);
+      const uint32_t l16 = g_lane_now() * 16u;
+      g_dma16(src, l16, dst);
+      g_dma16(src + 1024, l16, dst + 1024u);
     }
   };
   // ---- raw u / w of factor block B (the chunks B * G_BS + 1 .. B * G_BS + G_BS, i.e. what block B's k-steps slice):
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       if constexpr (WEIGHTED) g_dma4(a.w + i0, l4, (uint32_t)(OFF_RAW + (B % 3) * G_RAW + G_BS * 256 + wave * 256));
     } else {
       const double *src = ((WEIGHTED && wave >= 4) ? a.w : a.u) + chunk_sample(c);
-      g_dma4(src, (uint32_t)lane * 4u, (uint32_t)(OFF_RAW + (B % 3) * G_RAW + (wave >> 2) * (G_BS * 256) + (wave & 3) * 256));
+      g_dma4(src, g_lane_now() * 4u, (uint32_t)(OFF_RAW + (B % 3) * G_RAW + (wave >> 2) * (G_BS * 256) + (wave & 3) * 256));
     }
   };
   // ---- factors of block B from raw buffer B % 3 into factor buffer B % 3 (two waves, one sample per lane: waves 0 and 1 where
@@ -426,7 +429,9 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
   };
   v4i A[4];
-  v2i Bt[NS][2];
+  // B operands: passes of >= 2 row sets hold TWO (this slot's and the next one's, read a slot ahead), not one per row set
+  constexpr bool BT2 = NS >= 2;
+  v2i Bt[BT2 ? 2 : 1][2];
   double f[2], xr[2], yr[2] = {0.0, 0.0};
   // loop-carried bases (opaque below: the reads take 16-bit immediate offsets): the factor buffer of the block, and the x ring
   // (half of the block when a block's chunks are requested together)
@@ -436,11 +441,8 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const uint32_t a_va0 = (uint32_t)OFF_A + (uint32_t)lane * 16u;
 #pragma unroll
     for (int q = 0; q < 4; ++q) A[q] = *(lds_cv4)(lds + a_va0 + q * 1024);
-#pragma unroll
-    for (int fi = 0; fi < NS; ++fi) {
-      Bt[fi][0] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB));
-      Bt[fi][1] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB + 128));
-    }
+    Bt[0][0] = T_TRREAD((lds_v2i)(lds + rd_off));
+    Bt[0][1] = T_TRREAD((lds_v2i)(lds + rd_off + 128));
     read_factors(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, f_va, f);
 #pragma unroll
     for (int uu = 0; uu < 2; ++uu) xr[uu] = *(lds_cd)(lds + x_va + (XBLK ? 0 : 1024) + uu * 512);  // chunk 1
@@ -551,7 +553,8 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
           }
         };
-        const v4i Bv = {Bt[fi][0][0], Bt[fi][0][1], Bt[fi][1][0], Bt[fi][1][1]};
+        constexpr int bcur = BT2 ? ((p * NS + fi) & 1) : 0;  // (a block has an even number of slots: the parity restarts with it)
+        const v4i Bv = {Bt[bcur][0][0], Bt[bcur][0][1], Bt[bcur][1][0], Bt[bcur][1][1]};
         // The slot, INTERLEAVED: a piece of the slicing behind every MFMA (pinned: the scheduler otherwise issues the four
         // MFMAs back to back, and a wave that waits for the matrix pipe between two of its own MFMAs issues nothing else).
         auto mfma_q = [&](auto qc) {
@@ -571,6 +574,13 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         mfma_q(std::integral_constant<int, 0>{});
         G_PIN();
         issue_items(std::integral_constant<int, p * NS + fi>{});
+        if constexpr (BT2) {
+          // the NEXT slot's B operand, a slot ahead: row set fi + 1's words of this chunk were stored a step ago, row set 0's words
+          // of the next chunk in this step's slot 0 (earlier in this wave's LDS queue either way)
+          constexpr int fn = (fi + 1) % NS;
+          Bt[bcur ^ 1][0] = T_TRREAD((lds_v2i)(lds + rd_off + fn * T_PB));
+          Bt[bcur ^ 1][1] = T_TRREAD((lds_v2i)(lds + rd_off + fn * T_PB + 128));
+        }
         G_PIN();
         // (a) the fixed-point words of chunk s + 1, row set fi
         if constexpr (fi == 0) {
@@ -636,8 +646,10 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         G_PIN();
         // (d) behind the stores, behind the MFMAs that read the old ones: the next step's B operand of the row set
 #ifndef TXM_G_NO_TRREAD  // (ablation build)
-        Bt[fi][0] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB));
-        Bt[fi][1] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB + 128));
+        if constexpr (!BT2) {  // one row set: the next step's operand, behind this step's stores
+          Bt[0][0] = T_TRREAD((lds_v2i)(lds + rd_off));
+          Bt[0][1] = T_TRREAD((lds_v2i)(lds + rd_off + 128));
+        }
 #endif
         G_PIN();
       });
