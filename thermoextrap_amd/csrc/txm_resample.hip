@@ -843,14 +843,17 @@ static constexpr bool throttle_on() {
 //   6: 259.9 / 217.7   7: 268.2 / 226.4;   with a second matrix (N = 1e7, nrep = 256): order 1: 4.47 / 3.94, 4: 8.36 / 5.97,
 //   6: 8.79 / 7.58.
 // The table kernel takes at most three row sets per pass and pays the count-table generator (28 ms per 1e11 counts) once per
-// call: orders 3 and 4 -- four and five row sets, two passes against the fused kernel's one -- are a tie and stay on the
-// fused kernel (no table in the workspace); every other order, and every call with a second matrix, is 13 - 40 % faster.
+// call; every call with a second matrix and every order but 3 is faster on it.  Orders 3 and 4 -- four and five row sets, two
+// passes against the fused kernel's one -- were ties on the kernel's first cut; after its re-cut (reads a slot ahead, no
+// spills; same box, fused / table, profiles/r05_orders34_ab.txt): order 4 168.3 / 163.2 (N = 1e8, nrep = 1000), 37.0 / 35.5
+// (2e7), 6.2 / 5.95 (1e7, nrep = 200), 1.55 / 1.42 (1e6, 384), 1.72 / 1.76 (3e6, 128); order 3 145.6 / 145.1, 31.8 / 31.9,
+// 5.47 / 5.55, 1.47 / 1.56 -- order 4 moves to the table kernel, order 3 stays fused (a tie, and no table in the workspace).
 // Replicates come in groups of 128 there, 64 on the fused kernel: a call whose padding to 128 wastes much more than its
 // padding to 64 stays fused (nrep = 64: 1.80 / 2.66 ms; 130: 3.45 / 3.92; 100: 2.87 / 2.93; 200, 256, 1000: the table above).
 static bool table_kernel_pays(int64_t nrep, int K, bool has_y) {
   const int64_t pad128 = cdiv(nrep, G_REPS) * G_REPS, pad64 = cdiv(nrep, I8_REPS) * I8_REPS;
   if (4 * pad128 > 5 * pad64) return false;
-  return has_y || (K != 4 && K != 5);
+  return has_y || K != 4;
 }
 
 static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K, int call_path = TXM_PATH_AUTO) {
