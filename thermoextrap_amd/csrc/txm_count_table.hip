@@ -93,7 +93,13 @@ __global__ __launch_bounds__(T_BLOCK) void count_table_kernel(const uint32_t *__
       const uint32_t *src = cntw + (8 * s + 4 * (L >> 5)) * I8_REPS + rl;
       uint4 v = make_uint4(src[0], src[I8_REPS], src[2 * I8_REPS], src[3 * I8_REPS]);
       if (rep0 + rl >= nrep) v = make_uint4(0, 0, 0, 0);
+#ifdef TXM_CT_PLAIN_STORE
       *reinterpret_cast<uint4 *>(out_t + (size_t)s * G_KSTEP_BYTES + (size_t)ql * 1024 + (size_t)L * 16) = v;
+#else
+      typedef uint32_t ct_v4u __attribute__((ext_vector_type(4)));
+      const ct_v4u vv = {v.x, v.y, v.z, v.w};
+      __builtin_nontemporal_store(vv, reinterpret_cast<ct_v4u *>(out_t + (size_t)s * G_KSTEP_BYTES + (size_t)ql * 1024 + (size_t)L * 16));
+#endif
     }
   }
 }
