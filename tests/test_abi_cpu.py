@@ -220,6 +220,10 @@ def test_dispatch_rule_matches_the_header_thresholds(lib):
         assert auto == (base if order == 3 else with_table), order
         assert W(N, 32, 1000, order, AUTO, 1) == with_table            # a second matrix always rides the table kernel
         assert W(N, 32, 1000, order, INT8, 0) == auto and lib.txm_resample_vals_ws_bytes(N, 32, 1000, order) == auto
+    assert W(N, 32, 128, 4, AUTO, 0) == W(N, 32, 128, 4, FUSED, 0)      # order 4: only from two replicate groups on
+    assert W(N, 32, 129, 4, AUTO, 0) == W(N, 32, 129, 4, FUSED, 0)      # (129 -> 256 against 192: pads badly)
+    assert W(N, 32, 200, 4, AUTO, 0) == W(N, 32, 200, 4, TABLE, 0)
+    assert W(N, 32, 128, 4, AUTO, 1) == W(N, 32, 128, 4, TABLE, 1)
     assert W(N, 32, 64, 2, AUTO, 0) == W(N, 32, 64, 2, FUSED, 0)        # 64 replicates: padding to 128 doubles the work
     assert W(N, 32, 130, 2, AUTO, 0) == W(N, 32, 130, 2, FUSED, 0)      # 130 -> 256 against 192
     assert W(N, 32, 100, 2, AUTO, 0) == W(N, 32, 100, 2, TABLE, 0)      # 100 -> 128 either way

@@ -853,7 +853,12 @@ static constexpr bool throttle_on() {
 static bool table_kernel_pays(int64_t nrep, int K, bool has_y) {
   const int64_t pad128 = cdiv(nrep, G_REPS) * G_REPS, pad64 = cdiv(nrep, I8_REPS) * I8_REPS;
   if (4 * pad128 > 5 * pad64) return false;
-  return has_y || K != 4;
+  if (has_y) return true;
+  // order 4 is only ~3 % ahead on the table kernel, and one 128-replicate group is 382 workgroups per 1e8 samples -- 1.5 rounds of
+  // the 256 CUs -- where two 64-replicate groups of the fused kernel are 3.0 (a 125-replicate slab, what one of 8 ranks runs in
+  // bench.py --mode replicas: 22.6 ms fused, 24.4 table)
+  if (K == 5) return pad128 >= 2 * G_REPS;
+  return K != 4;
 }
 
 static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K, int call_path = TXM_PATH_AUTO) {
