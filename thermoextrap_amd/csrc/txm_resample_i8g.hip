@@ -19,6 +19,8 @@
 //     double-buffered ring shared by the eight waves (one s_barrier per block), a wave's own x columns into a private
 //     ring three k-steps ahead, u and w two blocks ahead; the staged factors w du^j of a block are computed from them by
 //     two waves while the block before runs.
+//   * a pass of ONE row set (order 0) has registers to spare and takes TWO replicate groups per workgroup (256 replicates,
+//     eight tiles per wave): 74.4 -> 62.2 ms per call at N = 1e8, nrep = 1000.
 //   * grid = scaling windows x replicate groups; the int32 sums of a window are exact, the flush writes the same
 //     doubles into the same slots as resample_i8t_kernel: the two kernels agree BIT FOR BIT.
 #include "txm_i8g.h"
@@ -80,6 +82,13 @@ __device__ __forceinline__ void g_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// replicate groups (of 128) per workgroup: two in a pass of ONE row set without a second matrix (order 0), else one
+#ifdef TXM_G_ONE_GROUP  // (A/B build)
+template <int JN, bool YS> constexpr int G_GROUPS_PER_WG = 1;
+#else
+template <int JN, bool YS> constexpr int G_GROUPS_PER_WG = (JN == 1 && !YS) ? 2 : 1;
+#endif
+
 template <int J0, int JN, bool WEIGHTED, bool YS>
 __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void resample_i8g_kernel(
     const I8Args a, const int K, const unsigned char *__restrict__ table, const int64_t rep_begin, const int n_grp) {
@@ -88,14 +97,19 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   constexpr int NPT = JN + ((YS && WEIGHTED && J0 > 0) ? 1 : 0);  // staged factors per sample (the y row set needs plain w)
   constexpr int NX = YS ? 2 : 1;                                 // x-ring DMAs per k-step
   constexpr int WREG = NS * T_PB;
-  constexpr int OFF_A = T_WAVES * WREG;                           // [2][G_BS][4096] count words
+  // a pass of ONE row set has 128 of its 256 registers to spare: the workgroup then takes TWO replicate groups (256 replicates,
+  // eight accumulator tiles per wave), so that every x chunk and every sliced word serves twice the replicates
+  constexpr int G2 = G_GROUPS_PER_WG<JN, YS>;
+  constexpr int NQ = 4 * G2;                                      // replicate quarters (A operands, accumulator tiles per row set)
+  constexpr int A_STEP = G2 * G_KSTEP_BYTES;                      // count words of one k-step in the ring: [group][4096]
+  constexpr int OFF_A = T_WAVES * WREG;                           // [2][G_BS][A_STEP] count words
   constexpr bool XBLK = !YS;                                      // x requested per block (8-slot ring) / per step (4 slots, + y)
   constexpr int XRN = XBLK ? G_XRB : G_XR;
-  constexpr int OFF_X = OFF_A + 2 * G_BS * G_KSTEP_BYTES;         // [wave][XRN][32 samples][4 columns] doubles
+  constexpr int OFF_X = OFF_A + 2 * G_BS * A_STEP;                // [wave][XRN][32 samples][4 columns] doubles
   constexpr int OFF_Y = OFF_X + T_WAVES * XRN * 1024;
   constexpr int OFF_RAW = OFF_Y + (YS ? T_WAVES * XRN * 1024 : 0);  // [3][u | w][G_BS * 32] doubles
   constexpr int OFF_F = OFF_RAW + 3 * G_RAW;                      // [3][unit][G_FU]: factors, line (chunk-in-block, sample) x NPT
-  constexpr int OFF_FS = OFF_F + 3 * 2 * G_FU;                    // [128] draws per replicate in the window
+  constexpr int OFF_FS = OFF_F + 3 * 2 * G_FU;                    // [128 G2] draws per replicate in the window
   static_assert(G_BS * 16 * NPT * 8 <= G_FU, "factor lines");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   uint32_t *fsum = reinterpret_cast<uint32_t *>(lds + OFF_FS);
@@ -106,17 +120,21 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
   // ---- which window, which replicate group (the groups of a window share an XCD: b and b + 8 land on the same one)
   const int b = blockIdx.x;
-  const int64_t win = (int64_t)((b >> 3) / n_grp) * 8 + (b & 7);
-  const int grp = (b >> 3) % n_grp;
+  const int n_wgg = (n_grp + G2 - 1) / G2;  // replicate groups of the grid (G2 table groups each)
+  const int64_t win = (int64_t)((b >> 3) / n_wgg) * 8 + (b & 7);
+  const int grp = (b >> 3) % n_wgg;
   if (win >= a.nwin) return;
   if (a.wflag[win] != 0u) return;  // precision guard: this window goes to the FP64 kernel
-  const int64_t rep0 = rep_begin + (int64_t)grp * G_REPS;
+  const int64_t rep0 = rep_begin + (int64_t)grp * (G_REPS * G2);
   const int64_t WT = a.win_tiles;
   const int64_t t0 = win * WT;
   const int64_t t1 = t0 + WT < a.ntiles ? t0 + WT : a.ntiles;
   const int nsteps = (int)(t1 - t0) * T_STEPS;  // k-steps (32-sample chunks) of the window
   const int nblk = nsteps / G_BS;
-  const unsigned char *tab = table + ((size_t)grp * (size_t)a.ntiles + (size_t)t0) * G_TILE_BYTES;
+  const unsigned char *tab = table + ((size_t)(grp * G2) * (size_t)a.ntiles + (size_t)t0) * G_TILE_BYTES;
+  // the second table group of the workgroup (a call with an odd number of groups has none for its last workgroup: it reads the
+  // first one's words again, and its rows -- all past nrep -- are not flushed)
+  const size_t tab2 = (G2 == 2 && grp * G2 + 1 < n_grp) ? (size_t)a.ntiles * G_TILE_BYTES : 0;
 
   // ---- producer role: lane = (sample l >> 2 of a 16-sample unit, column l & 3 of the wave's quad)
   const int ps = lane >> 2, cl = lane & 3;
@@ -143,11 +161,11 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const double scy = YS ? wty[I8_WT_SC + ccol] : 0.0;
   const double py = YS ? a.ypivot[1 + a.col0 + ccol] : 0.0;
 
-  v16i acc[NS][4];
+  v16i acc[NS][NQ];
 #pragma unroll
   for (int e = 0; e < NS; ++e)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[e][q] = (v16i)(0);
+    for (int q = 0; q < NQ; ++q) acc[e][q] = (v16i)(0);
 
 #ifdef TXM_G_CLOCKS  // diagnostic build: shader cycles (s_memtime) against the 100 MHz reference clock (s_memrealtime) over the kernel
   const long long gc0 = clock64(), gr0 = wall_clock64();
@@ -219,12 +237,15 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if constexpr (XBLK) {  // four 1-KiB pieces per loader wave (piece >= 0: that one only)
       if (!loader) return;
       const unsigned char *src = tab + (size_t)Bc * (G_BS * G_KSTEP_BYTES) + (size_t)wave * 4096;
-      const uint32_t dst = (uint32_t)(OFF_A + (B & 1) * (G_BS * G_KSTEP_BYTES) + wave * 4096);
+      const uint32_t dst = (uint32_t)(OFF_A + (B & 1) * (G_BS * A_STEP) + wave * A_STEP);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (piece < 0 || piece == i) g_dma16(src + i * 1024, g_lane_now() * 16u, dst + (uint32_t)i * 1024u);
+      for (int g = 0; g < G2; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (piece < 0 || piece == i) g_dma16(src + g * tab2 + i * 1024, g_lane_now() * 16u, dst + (uint32_t)(g * 4096 + i * 1024));
     } else {
       const unsigned char *src = tab + (size_t)Bc * (G_BS * G_KSTEP_BYTES) + (size_t)wave * 2048;
+      static_assert(XBLK || G2 == 1, "two groups per workgroup only without a second matrix");
       const uint32_t dst = (uint32_t)(OFF_A + (B & 1) * (G_BS * G_KSTEP_BYTES) + wave * 2048);
       const uint32_t l16 = g_lane_now() * 16u;
       g_dma16(src, l16, dst);
@@ -326,7 +347,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
   // ================= prologue =================
   // draws per replicate in the window (the top digit's bias is removed with them at the flush)
-  if (threadIdx.x < G_REPS) {
+  if (threadIdx.x < G_REPS * G2) {
     const int64_t r = rep0 + threadIdx.x;
     uint32_t s = 0;
     if (r < a.nrep)
@@ -428,7 +449,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       }
     }
   };
-  v4i A[4];
+  v4i A[NQ];
   // B operands: passes of >= 2 row sets hold TWO (this slot's and the next one's, read a slot ahead), not one per row set
   constexpr bool BT2 = NS >= 2;
   v2i Bt[BT2 ? 2 : 1][2];
@@ -440,7 +461,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   {
     const uint32_t a_va0 = (uint32_t)OFF_A + (uint32_t)lane * 16u;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) A[q] = *(lds_cv4)(lds + a_va0 + q * 1024);
+    for (int q = 0; q < NQ; ++q) A[q] = *(lds_cv4)(lds + a_va0 + q * 1024);
     Bt[0][0] = T_TRREAD((lds_v2i)(lds + rd_off));
     Bt[0][1] = T_TRREAD((lds_v2i)(lds + rd_off + 128));
     read_factors(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, f_va, f);
@@ -493,8 +514,8 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     };
     G_TICK(2);
     // count words: this block's steps 1..3 from buffer B & 1, the next block's step 0 from the other buffer
-    uint32_t a_va = (uint32_t)(OFF_A + (B & 1) * (G_BS * G_KSTEP_BYTES)) + (uint32_t)lane * 16u;
-    uint32_t a_vn = (uint32_t)(OFF_A + ((B + 1) & 1) * (G_BS * G_KSTEP_BYTES)) + (uint32_t)lane * 16u;
+    uint32_t a_va = (uint32_t)(OFF_A + (B & 1) * (G_BS * A_STEP)) + (uint32_t)lane * 16u;
+    uint32_t a_vn = (uint32_t)(OFF_A + ((B + 1) & 1) * (G_BS * A_STEP)) + (uint32_t)lane * 16u;
     asm volatile("" : "+v"(f_va), "+v"(x_va), "+v"(a_va), "+v"(a_vn));
     // SLOT = one row set of one step: its four MFMAs, then the words of chunk s + 1 for that row set.  A wave issues in order,
     // and its LDS operations complete in order: a read consumed right where it was issued -- the first cuts read a slot's factors
@@ -562,7 +583,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
           t_mfma<true>(acc[fi][q], A[q], Bv);
           // quarter q's count operand of the NEXT step into the registers just used for the last time
 #ifndef TXM_G_NO_AREAD  // (ablation build)
-          if constexpr (last) A[q] = *(lds_cv4)(lds + (p == G_BS - 1 ? a_vn : a_va + (p + 1) * G_KSTEP_BYTES) + q * 1024);
+          if constexpr (last) A[q] = *(lds_cv4)(lds + (p == G_BS - 1 ? a_vn : a_va + (p + 1) * A_STEP) + q * 1024);
 #endif
         };
 #ifdef TXM_G_NO_PIN
@@ -571,7 +592,8 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #define G_PIN() __builtin_amdgcn_sched_barrier(0)
 #endif
         G_PIN();
-        mfma_q(std::integral_constant<int, 0>{});
+        mfma_q(std::integral_constant<int, 0 * G2>{});
+        if constexpr (G2 == 2) mfma_q(std::integral_constant<int, 0 * G2 + 1>{});
         G_PIN();
         issue_items(std::integral_constant<int, p * NS + fi>{});
         if constexpr (BT2) {
@@ -606,7 +628,8 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
         }
         G_PIN();
-        mfma_q(std::integral_constant<int, 1>{});
+        mfma_q(std::integral_constant<int, 1 * G2>{});
+        if constexpr (G2 == 2) mfma_q(std::integral_constant<int, 1 * G2 + 1>{});
         G_PIN();
 #ifndef TXM_G_NO_SLICE
 #pragma unroll
@@ -633,7 +656,8 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         ahead();
 #endif
         G_PIN();
-        mfma_q(std::integral_constant<int, 2>{});
+        mfma_q(std::integral_constant<int, 2 * G2>{});
+        if constexpr (G2 == 2) mfma_q(std::integral_constant<int, 2 * G2 + 1>{});
         G_PIN();
         // (c) the stores
 #ifndef TXM_G_NO_PRODUCE  // (ablation build: no stores)
@@ -642,7 +666,8 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         asm volatile("" ::"v"(lo[0]), "v"(hi[0]), "v"(lo[1]), "v"(hi[1]));
 #endif
         G_PIN();
-        mfma_q(std::integral_constant<int, 3>{});
+        mfma_q(std::integral_constant<int, 3 * G2>{});
+        if constexpr (G2 == 2) mfma_q(std::integral_constant<int, 3 * G2 + 1>{});
         G_PIN();
         // (d) behind the stores, behind the MFMAs that read the old ones: the next step's B operand of the row set
 #ifndef TXM_G_NO_TRREAD  // (ablation build)
@@ -713,7 +738,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
   for (int fi = 0; fi < NS; ++fi)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) flush_tile(acc[fi][q], q, fi);
+    for (int q = 0; q < NQ; ++q) flush_tile(acc[fi][q], q, fi);
 #ifdef TXM_G_CLOCKS
   if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 1064)) {
     double *o = a.wtab + a.nwin * I8_WT_STRIDE + ((blockIdx.x ? 1 : 0) * T_WAVES + wave) * 8;
@@ -732,9 +757,10 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 template <int J0, int JN, bool WEIGHTED, bool YS>
 static int launch_pass_g(const I8Args &a, int K, const unsigned char *table, int64_t rep_begin, int n_grp, hipStream_t st) {
   constexpr int NS = JN + (YS ? 1 : 0);
-  const size_t lds = (size_t)T_WAVES * NS * T_PB + 2 * G_BS * G_KSTEP_BYTES + (size_t)(YS ? 2 * G_XR : G_XRB) * T_WAVES * 1024 + 3 * G_RAW +
-                     3 * 2 * G_FU + G_REPS * sizeof(uint32_t);
-  const dim3 grid((unsigned)(cdiv(a.nwin, 8) * 8 * n_grp));
+  constexpr int G2 = G_GROUPS_PER_WG<JN, YS>;
+  const size_t lds = (size_t)T_WAVES * NS * T_PB + 2 * G_BS * G_KSTEP_BYTES * G2 + (size_t)(YS ? 2 * G_XR : G_XRB) * T_WAVES * 1024 + 3 * G_RAW +
+                     3 * 2 * G_FU + G_REPS * G2 * sizeof(uint32_t);
+  const dim3 grid((unsigned)(cdiv(a.nwin, 8) * 8 * cdiv(n_grp, G2)));
   if (a.progress != nullptr) TXM_HIP(hipMemsetAsync(a.progress, 0, (size_t)cdiv(a.nwin, 8) * 8 * 16 * sizeof(uint32_t), st));
   TXM_SET_MAX_LDS((&resample_i8g_kernel<J0, JN, WEIGHTED, YS>), lds);
   hipLaunchKernelGGL((resample_i8g_kernel<J0, JN, WEIGHTED, YS>), grid, dim3(T_BLOCK), lds, st, a, K, table, rep_begin, n_grp);

@@ -18,7 +18,10 @@ for order in range(0, 8):
 cases += [(300_000, 32, 130, 4, True, False), (1_000_003, 24, 100, 3, True, False), (555_555, 40, 64, 2, False, False),
           (300_000, 64, 70, 5, False, False), (2_000_000, 32, 257, 6, True, False), (300_000, 32, 64, 1, False, True),
           (400_001, 32, 100, 4, True, True), (300_000, 30, 90, 6, False, True), (300_000, 32, 33, 0, True, True),
-          (300_000, 20, 40, 7, True, True), (1_100_000, 32, 128, 2, False, True)]
+          (300_000, 20, 40, 7, True, True), (1_100_000, 32, 128, 2, False, True),
+          # order 0 = one row set: two replicate groups per workgroup (odd group counts, one group, weights, two column groups)
+          (300_000, 32, 300, 0, True, False), (500_000, 64, 129, 0, False, False), (300_000, 32, 1000, 0, False, False),
+          (1_000_003, 24, 100, 0, True, False), (300_000, 32, 640, 0, False, False)]
 for (N, C, nrep, order, weighted, withy) in cases:
     x, u = make_data(N, C, 7, torch)
     w = (torch.rand(N, dtype=torch.float64, device="cuda") + 0.5) if weighted else None
