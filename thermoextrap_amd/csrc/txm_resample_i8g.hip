@@ -82,12 +82,23 @@ __device__ __forceinline__ void g_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// replicate groups (of 128) per workgroup: two in a pass of ONE row set without a second matrix (order 0), else one
-#ifdef TXM_G_ONE_GROUP  // (A/B build)
-template <int JN, bool YS> constexpr int G_GROUPS_PER_WG = 1;
+// replicate QUARTERS (32 replicates = one MFMA row block = one 1-KiB piece of a table k-step) per workgroup: four (128 replicates),
+// and eight in a pass of ONE row set (order 0), which has the registers for eight accumulator tiles per wave: every x chunk, sliced
+// word and B operand then serves twice the replicates (74.4 -> 62.2 ms per call at the north-star size).  A workgroup's quarters
+// are addressed piece by piece and may straddle the table's 128-replicate groups -- six quarters in passes of two row sets (twelve
+// tiles, like three row sets at four) were built and measured: 7 % faster per replicate, but 1000 replicates are 32 quarters =
+// 5.33 workgroups of six, and the padding costs more: order 1 88.7 against 86.3 ms, order 3 146.9 / 141.9 (-DTXM_G_SIX_QUARTERS).
+#ifdef TXM_G_FOUR_QUARTERS  // (A/B build: 128 replicates per workgroup in every pass)
+template <int NS> constexpr int G_QUARTERS = 4;
+#elif defined(TXM_G_SIX_QUARTERS)  // (A/B build)
+template <int NS> constexpr int G_QUARTERS = NS == 1 ? 8 : NS == 2 ? 6 : 4;
 #else
-template <int JN, bool YS> constexpr int G_GROUPS_PER_WG = (JN == 1 && !YS) ? 2 : 1;
+template <int NS> constexpr int G_QUARTERS = NS == 1 ? 8 : 4;
 #endif
+
+// (in the six-quarter A/B build one instance does not fit its registers -- weighted order 0 with a second matrix -- and stays at four)
+template <int J0, int JN, bool WEIGHTED, bool YS>
+constexpr int G_NQ = (J0 == 0 && JN == 1 && WEIGHTED && YS) ? 4 : G_QUARTERS<JN + (YS ? 1 : 0)>;
 
 template <int J0, int JN, bool WEIGHTED, bool YS>
 __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void resample_i8g_kernel(
@@ -97,11 +108,10 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   constexpr int NPT = JN + ((YS && WEIGHTED && J0 > 0) ? 1 : 0);  // staged factors per sample (the y row set needs plain w)
   constexpr int NX = YS ? 2 : 1;                                 // x-ring DMAs per k-step
   constexpr int WREG = NS * T_PB;
-  // a pass of ONE row set has 128 of its 256 registers to spare: the workgroup then takes TWO replicate groups (256 replicates,
-  // eight accumulator tiles per wave), so that every x chunk and every sliced word serves twice the replicates
-  constexpr int G2 = G_GROUPS_PER_WG<JN, YS>;
-  constexpr int NQ = 4 * G2;                                      // replicate quarters (A operands, accumulator tiles per row set)
-  constexpr int A_STEP = G2 * G_KSTEP_BYTES;                      // count words of one k-step in the ring: [group][4096]
+  constexpr int NQ = G_NQ<J0, JN, WEIGHTED, YS>;                  // replicate quarters (A operands, accumulator tiles per row set)
+  constexpr int A_STEP = NQ * 1024;                               // count words of one k-step in the ring: [quarter][1024]
+  constexpr int PPW = G_BS * NQ / T_WAVES;                        // count pieces per wave and block when every wave requests its own
+  static_assert(G_BS * NQ % T_WAVES == 0, "count pieces per wave");
   constexpr int OFF_A = T_WAVES * WREG;                           // [2][G_BS][A_STEP] count words
   constexpr bool XBLK = !YS;                                      // x requested per block (8-slot ring) / per step (4 slots, + y)
   constexpr int XRN = XBLK ? G_XRB : G_XR;
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   constexpr int OFF_Y = OFF_X + T_WAVES * XRN * 1024;
   constexpr int OFF_RAW = OFF_Y + (YS ? T_WAVES * XRN * 1024 : 0);  // [3][u | w][G_BS * 32] doubles
   constexpr int OFF_F = OFF_RAW + 3 * G_RAW;                      // [3][unit][G_FU]: factors, line (chunk-in-block, sample) x NPT
-  constexpr int OFF_FS = OFF_F + 3 * 2 * G_FU;                    // [128 G2] draws per replicate in the window
+  constexpr int OFF_FS = OFF_F + 3 * 2 * G_FU;                    // [32 NQ] draws per replicate in the window
   static_assert(G_BS * 16 * NPT * 8 <= G_FU, "factor lines");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   uint32_t *fsum = reinterpret_cast<uint32_t *>(lds + OFF_FS);
@@ -120,21 +130,26 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
   // ---- which window, which replicate group (the groups of a window share an XCD: b and b + 8 land on the same one)
   const int b = blockIdx.x;
-  const int n_wgg = (n_grp + G2 - 1) / G2;  // replicate groups of the grid (G2 table groups each)
+  const int n_wgg = (4 * n_grp + NQ - 1) / NQ;  // replicate groups of the grid (NQ quarters each; the table's groups hold 4)
   const int64_t win = (int64_t)((b >> 3) / n_wgg) * 8 + (b & 7);
   const int grp = (b >> 3) % n_wgg;
   if (win >= a.nwin) return;
   if (a.wflag[win] != 0u) return;  // precision guard: this window goes to the FP64 kernel
-  const int64_t rep0 = rep_begin + (int64_t)grp * (G_REPS * G2);
+  const int64_t rep0 = rep_begin + (int64_t)grp * (32 * NQ);
   const int64_t WT = a.win_tiles;
   const int64_t t0 = win * WT;
   const int64_t t1 = t0 + WT < a.ntiles ? t0 + WT : a.ntiles;
   const int nsteps = (int)(t1 - t0) * T_STEPS;  // k-steps (32-sample chunks) of the window
   const int nblk = nsteps / G_BS;
-  const unsigned char *tab = table + ((size_t)(grp * G2) * (size_t)a.ntiles + (size_t)t0) * G_TILE_BYTES;
-  // the second table group of the workgroup (a call with an odd number of groups has none for its last workgroup: it reads the
-  // first one's words again, and its rows -- all past nrep -- are not flushed)
-  const size_t tab2 = (G2 == 2 && grp * G2 + 1 < n_grp) ? (size_t)a.ntiles * G_TILE_BYTES : 0;
+  const unsigned char *tab = table + (size_t)t0 * G_TILE_BYTES;  // the window in table group 0
+  // quarter Q of the workgroup = quarter (grp NQ + Q) of the call: piece (that & 3) of table group (that >> 2).  Past the call's
+  // last quarter (a last workgroup that is not full) the first quarter's words are read again; those rows -- all past nrep --
+  // are not flushed
+  auto q_off = [&](int Q) -> size_t {
+    int gq = grp * NQ + Q;
+    if (gq >= 4 * n_grp) gq = grp * NQ;
+    return (size_t)(gq >> 2) * (size_t)a.ntiles * G_TILE_BYTES + (size_t)(gq & 3) * 1024;
+  };
 
   // ---- producer role: lane = (sample l >> 2 of a 16-sample unit, column l & 3 of the wave's quad)
   const int ps = lane >> 2, cl = lane & 3;
@@ -234,22 +249,21 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #ifdef TXM_G_NO_ADMA  // ablation build
     if (Bc >= 0) return;
 #endif
-    if constexpr (XBLK) {  // four 1-KiB pieces per loader wave (piece >= 0: that one only)
+    if constexpr (XBLK) {  // loader wave w: the NQ 1-KiB pieces of the block's k-step w (piece >= 0: that one only)
       if (!loader) return;
-      const unsigned char *src = tab + (size_t)Bc * (G_BS * G_KSTEP_BYTES) + (size_t)wave * 4096;
+      const unsigned char *src = tab + (size_t)(Bc * G_BS + wave) * G_KSTEP_BYTES;
       const uint32_t dst = (uint32_t)(OFF_A + (B & 1) * (G_BS * A_STEP) + wave * A_STEP);
 #pragma unroll
-      for (int g = 0; g < G2; ++g)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (piece < 0 || piece == i) g_dma16(src + g * tab2 + i * 1024, g_lane_now() * 16u, dst + (uint32_t)(g * 4096 + i * 1024));
-    } else {
-      const unsigned char *src = tab + (size_t)Bc * (G_BS * G_KSTEP_BYTES) + (size_t)wave * 2048;
-      static_assert(XBLK || G2 == 1, "two groups per workgroup only without a second matrix");
-      const uint32_t dst = (uint32_t)(OFF_A + (B & 1) * (G_BS * G_KSTEP_BYTES) + wave * 2048);
+      for (int Q = 0; Q < NQ; ++Q)
+        if (piece < 0 || piece == Q) g_dma16(src + q_off(Q), g_lane_now() * 16u, dst + (uint32_t)(Q * 1024));
+    } else {  // every wave PPW of the block's G_BS x NQ pieces
       const uint32_t l16 = g_lane_now() * 16u;
-      g_dma16(src, l16, dst);
-      g_dma16(src + 1024, l16, dst + 1024u);
+#pragma unroll
+      for (int k = 0; k < PPW; ++k) {
+        const int i = wave * PPW + k, st = i / NQ, Q = i % NQ;
+        g_dma16(tab + (size_t)(Bc * G_BS + st) * G_KSTEP_BYTES + q_off(Q), l16,
+                (uint32_t)(OFF_A + (B & 1) * (G_BS * A_STEP) + st * A_STEP + Q * 1024));
+      }
     }
   };
   // ---- raw u / w of factor block B (the chunks B * G_BS + 1 .. B * G_BS + G_BS, i.e. what block B's k-steps slice):
@@ -347,7 +361,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
   // ================= prologue =================
   // draws per replicate in the window (the top digit's bias is removed with them at the flush)
-  if (threadIdx.x < G_REPS * G2) {
+  if (threadIdx.x < 32 * NQ) {
     const int64_t r = rep0 + threadIdx.x;
     uint32_t s = 0;
     if (r < a.nrep)
@@ -505,18 +519,18 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       constexpr int k = decltype(kc)::value;
       if constexpr (SPREAD && k < ISSUE_SLOTS) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (j * ISSUE_SLOTS / 8 == k) {
-            if ((j & 1) == 0) a_request(B + 1, j >> 1);  // interleaved: count piece, x chunk, count piece, ...
-            else x_request(4 * ((B + 1) & 1) + (j >> 1));
+        for (int j = 0; j < NQ + 4; ++j)
+          if (j * ISSUE_SLOTS / (NQ + 4) == k) {  // interleaved: count piece, x chunk, count piece, ... then the remaining count pieces
+            if (j < 8 && (j & 1) == 0) a_request(B + 1, j >> 1);
+            else if (j < 8) x_request(4 * ((B + 1) & 1) + (j >> 1));
+            else a_request(B + 1, j - 4);
           }
       }
     };
     G_TICK(2);
     // count words: this block's steps 1..3 from buffer B & 1, the next block's step 0 from the other buffer
     uint32_t a_va = (uint32_t)(OFF_A + (B & 1) * (G_BS * A_STEP)) + (uint32_t)lane * 16u;
-    uint32_t a_vn = (uint32_t)(OFF_A + ((B + 1) & 1) * (G_BS * A_STEP)) + (uint32_t)lane * 16u;
-    asm volatile("" : "+v"(f_va), "+v"(x_va), "+v"(a_va), "+v"(a_vn));
+    asm volatile("" : "+v"(f_va), "+v"(x_va), "+v"(a_va));
     // SLOT = one row set of one step: its four MFMAs, then the words of chunk s + 1 for that row set.  A wave issues in order,
     // and its LDS operations complete in order: a read consumed right where it was issued -- the first cuts read a slot's factors
     // behind the stores and operand reads of the slot before and waited for them three MFMAs later, and read x at the top of the
@@ -568,7 +582,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
             } else {
               // vmcnt: chunk s + 2 was requested at the end of step s - 3; newer than it are the x (+ y) pieces of steps s - 2
               // and s - 1 and the three pieces of a block start at the top of step s - 2, s - 1 or s (none when p = 3)
-              g_wait_vm<2 * NX + (p == G_BS - 1 ? 0 : 3)>();
+              g_wait_vm<2 * NX + (p == G_BS - 1 ? 0 : PPW + 1)>();
 #pragma unroll
               for (int uu = 0; uu < 2; ++uu) xr[uu] = *(lds_cd)(lds + x_va + ((p + 2) & 3) * 1024 + uu * 512);
             }
@@ -583,7 +597,14 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
           t_mfma<true>(acc[fi][q], A[q], Bv);
           // quarter q's count operand of the NEXT step into the registers just used for the last time
 #ifndef TXM_G_NO_AREAD  // (ablation build)
-          if constexpr (last) A[q] = *(lds_cv4)(lds + (p == G_BS - 1 ? a_vn : a_va + (p + 1) * A_STEP) + q * 1024);
+          if constexpr (last) {
+            if constexpr (p == G_BS - 1) {  // the other ring buffer: the next block's step 0 (address formed here, not held)
+              const uint32_t a_vn = (uint32_t)(OFF_A + ((B + 1) & 1) * (G_BS * A_STEP)) + g_lane_now() * 16u;
+              A[q] = *(lds_cv4)(lds + a_vn + q * 1024);
+            } else {
+              A[q] = *(lds_cv4)(lds + a_va + (p + 1) * A_STEP + q * 1024);
+            }
+          }
 #endif
         };
 #ifdef TXM_G_NO_PIN
@@ -592,8 +613,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #define G_PIN() __builtin_amdgcn_sched_barrier(0)
 #endif
         G_PIN();
-        mfma_q(std::integral_constant<int, 0 * G2>{});
-        if constexpr (G2 == 2) mfma_q(std::integral_constant<int, 0 * G2 + 1>{});
+        t_static_for<(0 + 1) * NQ / 4 - 0 * NQ / 4>([&](auto jc) { mfma_q(std::integral_constant<int, 0 * NQ / 4 + decltype(jc)::value>{}); });
         G_PIN();
         issue_items(std::integral_constant<int, p * NS + fi>{});
         if constexpr (BT2) {
@@ -628,8 +648,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
         }
         G_PIN();
-        mfma_q(std::integral_constant<int, 1 * G2>{});
-        if constexpr (G2 == 2) mfma_q(std::integral_constant<int, 1 * G2 + 1>{});
+        t_static_for<(1 + 1) * NQ / 4 - 1 * NQ / 4>([&](auto jc) { mfma_q(std::integral_constant<int, 1 * NQ / 4 + decltype(jc)::value>{}); });
         G_PIN();
 #ifndef TXM_G_NO_SLICE
 #pragma unroll
@@ -642,12 +661,16 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // (b) the u-row overlay (wave-uniform branch, kept by the volatile permute), then the reads of the NEXT slot
 #if !defined(TXM_G_NO_OVERLAY) && !defined(TXM_G_NO_SLICE)
         if (fi < JN && ofi == fi) {
+          // (selector and bias from the lane id, here: two registers fewer held across the k-steps)
+          const uint32_t od_l = 4u * (uint32_t)(wave & 1) + (g_lane_now() & 3u);
+          const uint32_t osel_l = od_l < 7u ? ((od_l << 24) | 0x000c0c0cu) : 0x0c0c0c0cu;
+          const uint32_t oxor_l = od_l < 6u ? 0x80000000u : 0u;
 #pragma unroll
           for (int uu = 0; uu < 2; ++uu) {
             const uint64_t ub = (uint64_t)__double_as_longlong(__builtin_ldexp(f[uu], 50) + T_MAGIC);
             uint32_t dig;
-            asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(dig) : "v"((uint32_t)(ub >> 32)), "v"((uint32_t)ub), "v"(osel));
-            hi[uu] = (hi[uu] & 0x00ffffffu) | (dig ^ oxor);
+            asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(dig) : "v"((uint32_t)(ub >> 32)), "v"((uint32_t)ub), "v"(osel_l));
+            hi[uu] = (hi[uu] & 0x00ffffffu) | (dig ^ oxor_l);
           }
         }
 #endif
@@ -656,8 +679,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         ahead();
 #endif
         G_PIN();
-        mfma_q(std::integral_constant<int, 2 * G2>{});
-        if constexpr (G2 == 2) mfma_q(std::integral_constant<int, 2 * G2 + 1>{});
+        t_static_for<(2 + 1) * NQ / 4 - 2 * NQ / 4>([&](auto jc) { mfma_q(std::integral_constant<int, 2 * NQ / 4 + decltype(jc)::value>{}); });
         G_PIN();
         // (c) the stores
 #ifndef TXM_G_NO_PRODUCE  // (ablation build: no stores)
@@ -666,8 +688,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         asm volatile("" ::"v"(lo[0]), "v"(hi[0]), "v"(lo[1]), "v"(hi[1]));
 #endif
         G_PIN();
-        mfma_q(std::integral_constant<int, 3 * G2>{});
-        if constexpr (G2 == 2) mfma_q(std::integral_constant<int, 3 * G2 + 1>{});
+        t_static_for<(3 + 1) * NQ / 4 - 3 * NQ / 4>([&](auto jc) { mfma_q(std::integral_constant<int, 3 * NQ / 4 + decltype(jc)::value>{}); });
         G_PIN();
         // (d) behind the stores, behind the MFMAs that read the old ones: the next step's B operand of the row set
 #ifndef TXM_G_NO_TRREAD  // (ablation build)
@@ -757,10 +778,10 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 template <int J0, int JN, bool WEIGHTED, bool YS>
 static int launch_pass_g(const I8Args &a, int K, const unsigned char *table, int64_t rep_begin, int n_grp, hipStream_t st) {
   constexpr int NS = JN + (YS ? 1 : 0);
-  constexpr int G2 = G_GROUPS_PER_WG<JN, YS>;
-  const size_t lds = (size_t)T_WAVES * NS * T_PB + 2 * G_BS * G_KSTEP_BYTES * G2 + (size_t)(YS ? 2 * G_XR : G_XRB) * T_WAVES * 1024 + 3 * G_RAW +
-                     3 * 2 * G_FU + G_REPS * G2 * sizeof(uint32_t);
-  const dim3 grid((unsigned)(cdiv(a.nwin, 8) * 8 * cdiv(n_grp, G2)));
+  constexpr int NQ = G_NQ<J0, JN, WEIGHTED, YS>;
+  const size_t lds = (size_t)T_WAVES * NS * T_PB + 2 * G_BS * NQ * 1024 + (size_t)(YS ? 2 * G_XR : G_XRB) * T_WAVES * 1024 + 3 * G_RAW +
+                     3 * 2 * G_FU + 32 * NQ * sizeof(uint32_t);
+  const dim3 grid((unsigned)(cdiv(a.nwin, 8) * 8 * cdiv(4 * (int64_t)n_grp, NQ)));
   if (a.progress != nullptr) TXM_HIP(hipMemsetAsync(a.progress, 0, (size_t)cdiv(a.nwin, 8) * 8 * 16 * sizeof(uint32_t), st));
   TXM_SET_MAX_LDS((&resample_i8g_kernel<J0, JN, WEIGHTED, YS>), lds);
   hipLaunchKernelGGL((resample_i8g_kernel<J0, JN, WEIGHTED, YS>), grid, dim3(T_BLOCK), lds, st, a, K, table, rep_begin, n_grp);
@@ -802,6 +823,10 @@ int launch_resample_i8g(const I8Args &a, int K, bool weighted, const unsigned ch
   }
 #ifdef TXM_G_ONLY03  // (ablation builds: one instance, seconds to compile)
     if (j0 == 0 && jn == 3 && !y_here && !weighted) rc = launch_pass_g<0, 3, false, false>(a, K, table, rep_begin, n_grp, st);
+#elif defined(TXM_G_ONLY32)
+    if (j0 == 3 && jn == 2 && !y_here && !weighted) rc = launch_pass_g<3, 2, false, false>(a, K, table, rep_begin, n_grp, st);
+#elif defined(TXM_G_ONLY02)
+    if (j0 == 0 && jn == 2 && !y_here && !weighted) rc = launch_pass_g<0, 2, false, false>(a, K, table, rep_begin, n_grp, st);
 #elif defined(TXM_G_ONLY01)
     if (j0 == 0 && jn == 1 && !y_here && !weighted) rc = launch_pass_g<0, 1, false, false>(a, K, table, rep_begin, n_grp, st);
 #else
