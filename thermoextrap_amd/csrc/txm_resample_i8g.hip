@@ -212,6 +212,10 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // stage the factors; landing is published by the block's barrier, behind every issuer's vmcnt(0).
   const bool loader = !XBLK || wave < 4;  // uniform
   const int qsrc2 = 4 * (wave + 4) < a.C ? wave + 4 : 0;
+  const int64_t xcol1 = (a.col0 + 4 * qsrc) * 8, xcol2 = (a.col0 + 4 * qsrc2) * 8;  // byte offsets of the two column quads in a row
+  size_t qoff[NQ];  // (uniform: scalar registers)
+#pragma unroll
+  for (int Q = 0; Q < NQ; ++Q) qoff[Q] = q_off(Q);
   auto x_request = [&](int slot) {  // chunk cq -> ring slot; chunks past the window re-read its last one
 #ifdef TXM_G_NO_XDMA  // ablation build
     if (slot >= 0) { ++cq; return; }
@@ -499,16 +503,53 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     stage_factors(B + 1);
     G_TICK(7);
     raw_request(B + 2);
+    // the loader waves' requests for the next block, lean: what does not change inside a block -- the count pieces' source and
+    // destination, the lanes' offsets -- is formed here once (the general a_request / x_request did it per piece: 57
+    // instructions an item, a third of a loader wave's instruction stream -- this kernel is paced by what a wave has to issue)
+    const unsigned char *blk_asrc = nullptr;
+    uint32_t blk_adst = 0, blk_l16 = 0, blk_xrow = 0;
+    if constexpr (XBLK) {
+      if (loader) {
+        const int Bn = B + 1 < nblk ? B + 1 : nblk - 1;
+        blk_asrc = tab + (size_t)(Bn * G_BS + wave) * G_KSTEP_BYTES;
+        blk_adst = (uint32_t)(OFF_A + ((B + 1) & 1) * (G_BS * A_STEP) + wave * A_STEP);
+        const uint32_t ln = g_lane_now();
+        blk_l16 = ln * 16u;
+        blk_xrow = (ln >> 1) * (uint32_t)(a.ldx_s * 8) + (ln & 1) * 16u;
+      }
+    }
+    auto a_piece = [&](int Q) {
+#ifndef TXM_G_NO_ADMA
+      if (loader) g_dma16(blk_asrc + qoff[Q], blk_l16, blk_adst + (uint32_t)(Q * 1024));
+#endif
+    };
+    auto x_chunk = [&](int i) {  // chunk cq -> slot i of the ring half the next block reads: the wave's own columns and its partner's
+#ifndef TXM_G_NO_XDMA
+      if (loader) {
+        const uint32_t dst = xring + (uint32_t)((4 * ((B + 1) & 1) + i) * 1024);
+        g_dma16(xq + xcol1, blk_xrow, dst);
+        g_dma16(xq + xcol2, blk_xrow, dst + (uint32_t)(4 * XRN * 1024));
+      }
+#endif
+      ++cq;
+      if (cq < nsteps) {
+        if ((cq & 31) == 0) xq = reinterpret_cast<const char *>(a.x + chunk_sample(cq) * a.ldx_s);  // a new tile
+        else xq += xstep;
+      }
+    };
 #ifdef TXM_G_BURST  // (experiment build: the next block's count words and x requested here, 14 pieces per loader wave at once)
     constexpr bool SPREAD = false;
 #else
     constexpr bool SPREAD = XBLK && NS >= 2;  // (one row set: a step is short, two bursts of 6 cost more than one of 12: 77.7 -> 75.6 ms at order 0)
 #endif
     if constexpr (!SPREAD) {
-      a_request(B + 1);
-      if constexpr (XBLK) {  // the next block's x: chunks 4 (B + 1) + 1 .. + 4 into the ring half this block does not read
+      if constexpr (XBLK) {  // the next block's count words and x (chunks 4 (B + 1) + 1 .. + 4 into the ring half this block does not read)
 #pragma unroll
-        for (int i = 0; i < G_BS; ++i) x_request(4 * ((B + 1) & 1) + i);
+        for (int Q = 0; Q < NQ; ++Q) a_piece(Q);
+#pragma unroll
+        for (int i = 0; i < G_BS; ++i) x_chunk(i);
+      } else {
+        a_request(B + 1);
       }
     }
     // SPREAD: the eight requests of the next block (four count pieces, four x chunks = 12 pieces per loader wave) go out one or
@@ -521,9 +562,9 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int j = 0; j < NQ + 4; ++j)
           if (j * ISSUE_SLOTS / (NQ + 4) == k) {  // interleaved: count piece, x chunk, count piece, ... then the remaining count pieces
-            if (j < 8 && (j & 1) == 0) a_request(B + 1, j >> 1);
-            else if (j < 8) x_request(4 * ((B + 1) & 1) + (j >> 1));
-            else a_request(B + 1, j - 4);
+            if (j < 8 && (j & 1) == 0) a_piece(j >> 1);
+            else if (j < 8) x_chunk(j >> 1);
+            else a_piece(j - 4);
           }
       }
     };
@@ -661,10 +702,14 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // (b) the u-row overlay (wave-uniform branch, kept by the volatile permute), then the reads of the NEXT slot
 #if !defined(TXM_G_NO_OVERLAY) && !defined(TXM_G_NO_SLICE)
         if (fi < JN && ofi == fi) {
-          // (selector and bias from the lane id, here: two registers fewer held across the k-steps)
+#ifdef TXM_G_OVERLAY_RECOMPUTE  // (selector and bias from the lane id, here: two registers fewer held across the k-steps, nine vector
+          // instructions more per overlay -- what the six-quarter A/B build needs to fit)
           const uint32_t od_l = 4u * (uint32_t)(wave & 1) + (g_lane_now() & 3u);
           const uint32_t osel_l = od_l < 7u ? ((od_l << 24) | 0x000c0c0cu) : 0x0c0c0c0cu;
           const uint32_t oxor_l = od_l < 6u ? 0x80000000u : 0u;
+#else
+          const uint32_t osel_l = osel, oxor_l = oxor;
+#endif
 #pragma unroll
           for (int uu = 0; uu < 2; ++uu) {
             const uint64_t ub = (uint64_t)__double_as_longlong(__builtin_ldexp(f[uu], 50) + T_MAGIC);
