@@ -319,6 +319,16 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
   // ---- store the fixed-point words of the wave's two units of one row set (as resample_i8t_kernel: four 256-byte runs)
   auto store_x2 = [&](uint32_t lo0, uint32_t hi0, uint32_t lo1, uint32_t hi1, int off) {
+#ifdef TXM_G_PLAIN_STORES  // (experiment: stores the compiler can see and count in its s_waitcnt lgkmcnt values -- the four
+    // ds_write_addtid_b32 of the asm below are invisible to it, so every wait it derives is up to four operations too strict)
+    typedef __attribute__((address_space(3))) uint32_t *lds_u32;
+    const uint32_t base = wreg + g_lane_now() * 4u;
+    *(lds_u32)(lds + base + off) = lo0;
+    *(lds_u32)(lds + base + off + T_PLANE + 128) = hi0;
+    *(lds_u32)(lds + base + off + 256) = lo1;
+    *(lds_u32)(lds + base + off + 256 + T_PLANE + 128) = hi1;
+    return;
+#endif
     asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\t"
                  "ds_write_addtid_b32 %0 offset:%5\n\t"
                  "ds_write_addtid_b32 %1 offset:%6\n\t"
