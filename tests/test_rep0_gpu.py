@@ -286,7 +286,8 @@ def test_workspace_budget_slabs_equal_the_unslabbed_rows_bit_for_bit(txm):
     y = 0.5 * x + 1.0
     L = eng._L()
     for nrep, order, path, withy in ((1000, 2, None, False), (1000, 4, None, False), (700, 6, "int8_table", True), (600, 4, "int8_fused", False),
-                                    (520, 3, "fp64", False), (900, 1, None, True)):
+                                    (520, 3, "fp64", False), (900, 1, None, True),
+                                    (1000, 0, None, False)):  # order 0: two 128-replicate groups per workgroup, slabs of odd group counts
         s = eng.DeviceSampler(77, nrep, N, rep0=3)
         kw = dict(sampler=s, path=path, y=y if withy else None)
         old = eng.WORKSPACE_BUDGET_BYTES
