@@ -518,6 +518,26 @@ def main():
             ksteps = -(-nrep_rank // 128) * (-(-N // 1024) * 32) * -(-C // 32)
         i8_ops = 2.0 * 32 * 32 * 32 * n_mfma * ksteps
         tops = i8_ops / (t_boot * 1e-3) / 1e12
+        table_split = None
+        if info.get("kernel") == "int8_table":
+            # the call = count-table generator (HBM-write bound) + contraction passes (int8 pipe) + finalize: the generator alone,
+            # timed live on the same stream outside the timed region (txm_sampler_count_table: the launch the call makes)
+            import ctypes as _ct
+            from thermoextrap_amd import _lib as _tl
+            _L = _tl.load()
+            _tb = torch.empty(_L.txm_sampler_count_table_bytes(N, nrep_rank), dtype=torch.uint8, device="cuda")
+            def _gen():
+                _tl.check(_L.txm_sampler_count_table(_ct.byref(sampler.spec), engine._ptr(sampler.counts), 0, nrep_rank,
+                                                     engine._ptr(_tb), engine._stream()), "count_table")
+            _gen()
+            t_gen = timed(_gen, 3)
+            del _tb
+            t_con = max(t_boot - t_gen, 1e-6)
+            table_split = {"count_table_kernel_ms": t_gen, "count_table_written_GBs": N * (-(-nrep_rank // 128) * 128) / (t_gen * 1e-3) / 1e9,
+                           "contraction_and_finalize_ms": t_con,
+                           "contraction_frac_of_int8_peak": i8_ops / (t_con * 1e-3) / 1e12 / INT8_PEAK_TOPS,
+                           "how": "generator timed alone with HIP events after the timed region; contraction = the call minus it "
+                                  "(finalize and memsets included); profiles/*_kernel_stats.csv has the rocprofv3 per-kernel durations"}
         tr, src = pmc_traffic(kname, shape)
         roofline = {
             "kernel": f"{kname} ({kdesc}) + pre-pass (unless reused) and finalize kernels",
@@ -531,6 +551,7 @@ def main():
             "hbm_achieved_GBs": alg_bytes / (t_boot * 1e-3) / 1e9,
             "hbm_frac": alg_bytes / (t_boot * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "guard_windows": info["windows"], "guard_windows_fp64": info["windows_fp64"],
+            "table_call_split": table_split,
             "note": "achieved = EXECUTED v_mfma_i32_32x32x32_i8 operations per second against the dense int8 peak "
                     "(2x bf16 = 5 POP/s); fp64_equiv_tflops = the algorithmic FP64 flops 2*N*nrep*K*(N_obs+1) per "
                     "second -- a speed, not a fraction of any roof.  12.5 % of the executed MFMA columns are the dead "
