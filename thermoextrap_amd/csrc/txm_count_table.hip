@@ -45,7 +45,11 @@ __global__ __launch_bounds__(T_BLOCK) void count_table_kernel(const uint32_t *__
     __syncthreads();  // the previous tile's write-out has read the count tile
     for (int e = threadIdx.x; e < T_CNT_BYTES / 16; e += T_BLOCK) reinterpret_cast<uint4 *>(cntw)[e] = make_uint4(0, 0, 0, 0);
     __syncthreads();
+#ifdef TXM_CT_NO_FILL  // (timing build: zeroed tiles written out -- what the write-out path alone costs)
+    if (false) {
+#else
     if (any_live) {
+#endif
       if (tsize == (uint32_t)SM_T) {
         // dead lanes (replicates past nrep) draw like the smallest live lane; their rows are written as zeros below
         uint32_t nmin = rep_live ? n : 0xffffffffu, nmax = rep_live ? n : 0u;
@@ -93,7 +97,9 @@ __global__ __launch_bounds__(T_BLOCK) void count_table_kernel(const uint32_t *__
       const uint32_t *src = cntw + (8 * s + 4 * (L >> 5)) * I8_REPS + rl;
       uint4 v = make_uint4(src[0], src[I8_REPS], src[2 * I8_REPS], src[3 * I8_REPS]);
       if (rep0 + rl >= nrep) v = make_uint4(0, 0, 0, 0);
-#ifdef TXM_CT_PLAIN_STORE
+#ifdef TXM_CT_NO_STORE  // (timing build: the fill alone)
+      if (v.x == 0xdeadbeefu) *reinterpret_cast<uint4 *>(out_t + (size_t)L * 16) = v;
+#elif defined(TXM_CT_PLAIN_STORE)
       *reinterpret_cast<uint4 *>(out_t + (size_t)s * G_KSTEP_BYTES + (size_t)ql * 1024 + (size_t)L * 16) = v;
 #else
       typedef uint32_t ct_v4u __attribute__((ext_vector_type(4)));

@@ -91,7 +91,12 @@ __device__ __forceinline__ void t_fill_call(uint32_t *cntw, uint32_t k0, uint32_
       asm volatile("" : "+v"(q));
       uint32_t inc = 1u << (((k == 0) ? (lo2 << 3) : (lo2 >> (10 * k - 3))) & 31u);
       if (!ALL_VALID) inc = (first + (uint32_t)(wi * 3 + k) < n) ? inc : 0u;
+#ifdef TXM_FILL_NO_ATOMIC  // (timing build: the fill's vector work without its LDS atomics)
+      uint32_t ad_ = (q << 8) + lane4;
+      asm volatile("" ::"v"(ad_), "v"(inc));
+#else
       atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(cntw) + (q << 8) + lane4), inc);
+#endif
     }
   }
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Count-table generator (txm_sampler_count_table): bit-for-bit against txm_sampler_freq on small shapes, then its time at
-bench sizes.   python tools/count_table_check.py [time]"""
+bench sizes.   python tools/count_table_check.py [time [nocheck]]"""
 import ctypes as ct, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -40,7 +40,7 @@ for (N, nrep, rep0, rb, nr) in [(4096, 130, 0, 0, 130), (5000, 200, 7, 0, 200), 
     live = min(nrep - rb, e.shape[0])
     ok = np.array_equal(e[:live], f[rb:rb + live]) and not e[live:].any()
     print(f"N={N} nrep={nrep} rep0={rep0} slab=[{rb},{rb+nr}): {'OK' if ok else 'MISMATCH'}", flush=True)
-    assert ok
+    assert ok or len(sys.argv) > 2  # (a third argument: timing builds whose tables are wrong by construction)
 
 if len(sys.argv) > 1:
     for (N, nrep) in [(20_000_000, 1000), (100_000_000, 256), (100_000_000, 1000)]:
