@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""Random shapes: the count-table kernel against the fused kernel, bit for bit (and both against the FP64 kernel to 1e-12 of scale).
+   python tools/i8g_fuzz.py [cases] [seed]"""
+import sys, random
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+import thermoextrap_amd as txa
+from thermoextrap_amd import engine
+txa.require_gpu(0)
+ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+for it in range(ncase):
+    N = rng.choice([262144, 300_000, 555_555, 786432, 1_000_003, 1_500_000, 2_097_152 + rng.randrange(1, 1024)])
+    C = rng.choice([20, 24, 28, 32, 36, 40, 48, 64])
+    pad = rng.choice([0, 0, 4, 8])              # row pitch > C
+    nrep = rng.choice([1, 33, 64, 100, 127, 128, 129, 200, 256, 257, 300, 384, 385, 512, 640, 700])
+    order = rng.randrange(0, 8)
+    weighted = rng.random() < 0.4
+    withy = rng.random() < 0.3
+    g = torch.Generator(device="cuda").manual_seed(1000 + it)
+    u = 3.0 + 2.0 * torch.randn(N, generator=g, dtype=torch.float64, device="cuda")
+    xf = torch.randn(N, C + pad, generator=g, dtype=torch.float64, device="cuda") * 0.7 + 0.05 * u[:, None] + 1.5
+    x = xf[:, :C]
+    w = (torch.rand(N, generator=g, dtype=torch.float64, device="cuda") + 0.5) if weighted else None
+    y = None
+    if withy:
+        yf = torch.randn(N, C + pad, generator=g, dtype=torch.float64, device="cuda") + 0.3 * xf
+        y = yf[:, :C]
+    s = engine.DeviceSampler(500 + it, nrep, N, rep0=rng.choice([0, 5, 128, 1000]))
+    r = {}
+    ker = {}
+    for path in ("int8_fused", "int8_table"):
+        out = engine.resample_vals(x, u, order, sampler=s, w=w, y=y, path=path)
+        r[path] = out if withy else (out, None)
+        ker[path] = engine.resample_info()["kernel"]
+    same = torch.equal(r["int8_table"][0], r["int8_fused"][0])
+    if withy:
+        a, b = r["int8_table"][1], r["int8_fused"][1]
+        same = same and (torch.equal(a, b) or (a - b).abs().max().item() <= 1e-14 * b.abs().max().item())
+    f = engine.resample_vals(x, u, order, sampler=s, w=w, path="fp64")
+    sc = f.abs().mean(dim=0, keepdim=True)
+    rel = ((r["int8_table"][0] - f).abs() / (f.abs() + sc + 1e-300)).max().item()
+    ok = same and rel < 1e-11
+    bad += not ok
+    print(f"{it:3d} N={N} C={C}+{pad} nrep={nrep} order={order} w={weighted} y={withy} kernels={ker['int8_fused']}/{ker['int8_table']}: "
+          f"{'SAME' if same else 'DIFFER'}  vs fp64 {rel:.1e} {'' if ok else '  <-- FAIL'}", flush=True)
+print("ALL OK" if bad == 0 else f"{bad} FAILED")
+sys.exit(1 if bad else 0)
