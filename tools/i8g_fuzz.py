@@ -35,7 +35,16 @@ for it in range(ncase):
         out = engine.resample_vals(x, u, order, sampler=s, w=w, y=y, path=path)
         r[path] = out if withy else (out, None)
         ker[path] = engine.resample_info()["kernel"]
-    same = torch.equal(r["int8_table"][0], r["int8_fused"][0])
+    # bit for bit on every 32-column group the table kernel serves.  A narrow TAIL group (1..16 columns behind full groups) runs the
+    # fused kernel's narrow variant in both calls, but in a pass structure that depends on whether the call's kernels carry y
+    # (the table call always does, the fused one not at every order): its sums then agree to rounding, not to the bit -- a
+    # property of that variant since round 4 (states with / without y differ there by 1e-15 .. 1e-13 on the pure fused path too)
+    ntail = C % 32 if 0 < C % 32 <= 16 and withy else 0
+    cfull = C - ntail
+    same = torch.equal(r["int8_table"][0][:, :cfull], r["int8_fused"][0][:, :cfull])
+    if ntail:
+        a, b = r["int8_table"][0][:, cfull:], r["int8_fused"][0][:, cfull:]
+        same = same and ((a - b).abs() / (b.abs() + b.abs().mean(dim=0, keepdim=True))).max().item() < 1e-12
     if withy:
         a, b = r["int8_table"][1], r["int8_fused"][1]
         same = same and (torch.equal(a, b) or (a - b).abs().max().item() <= 1e-14 * b.abs().max().item())
