@@ -214,7 +214,7 @@ int txm_sampler_count_table(const txm_sampler_spec *spec_host, const uint32_t *c
  *       shorter series from nrep >= 64 at order >= 3, 128 at orders 1-2, 384 at order 0.
  *   Inside the int8 path two contraction kernels serve wide states and agree BIT FOR BIT (same int32 sums, same flush):
  *     - the kernel that draws the per-sample counts in place (64 replicates per workgroup; orders 0-4 one pass over the
- *       sampler stream, 5-7 two): order 3 without a second matrix (a tie, and no table), order 4 at nrep <= 128, replicate counts that pad badly to 128
+ *       sampler stream, 5-7 two): orders 3 and 4 without a second matrix at nrep <= 128, replicate counts that pad badly to 128
  *       (4 * ceil128(nrep) > 5 * ceil64(nrep)), misaligned operands (x not 16-byte aligned or an odd row pitch), and
  *       every narrow state;
  *     - the count-table kernel (128 replicates per workgroup, at most three row sets per pass over ONE table of per-sample

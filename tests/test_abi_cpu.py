@@ -205,7 +205,7 @@ def test_dispatch_rule_matches_the_header_thresholds(lib):
         assert B(S, LONG - 1, 4, 127, 3) == 0 and B(S, LONG - 1, 4, 128, 3) == 1
         assert B(S, LONG, 32, 100, 3) == 0                    # wide states: the batched int8 launch does not serve them
     # which int8 kernel serves a wide call, seen through the workspace it asks for: the count table (one byte per sample and
-    # replicate padded to 128) is part of it for every order but 3, for every call with a second matrix, and never
+    # replicate padded to 128) is part of it for every order (orders 3 and 4: from two replicate groups on), for every call with a second matrix, and never
     # when the padding to 128 replicates wastes more than 5/4 of the padding to 64
     W = lib.txm_resample_vals_ws_bytes_opts
     N = 10_000_000
@@ -217,10 +217,11 @@ def test_dispatch_rule_matches_the_header_thresholds(lib):
         with_table = W(N, 32, 1000, order, TABLE, 0)
         assert table(1000) <= with_table - base < table(1000) + 4096
         auto = W(N, 32, 1000, order, AUTO, 0)
-        assert auto == (base if order == 3 else with_table), order
+        assert auto == with_table, order
         assert W(N, 32, 1000, order, AUTO, 1) == with_table            # a second matrix always rides the table kernel
         assert W(N, 32, 1000, order, INT8, 0) == auto and lib.txm_resample_vals_ws_bytes(N, 32, 1000, order) == auto
-    assert W(N, 32, 128, 4, AUTO, 0) == W(N, 32, 128, 4, FUSED, 0)      # order 4: only from two replicate groups on
+    assert W(N, 32, 128, 4, AUTO, 0) == W(N, 32, 128, 4, FUSED, 0)      # orders 3 and 4: only from two replicate groups on
+    assert W(N, 32, 128, 3, AUTO, 0) == W(N, 32, 128, 3, FUSED, 0) and W(N, 32, 200, 3, AUTO, 0) == W(N, 32, 200, 3, TABLE, 0)
     assert W(N, 32, 129, 4, AUTO, 0) == W(N, 32, 129, 4, FUSED, 0)      # (129 -> 256 against 192: pads badly)
     assert W(N, 32, 200, 4, AUTO, 0) == W(N, 32, 200, 4, TABLE, 0)
     assert W(N, 32, 128, 4, AUTO, 1) == W(N, 32, 128, 4, TABLE, 1)

@@ -88,7 +88,7 @@ def test_table_kernel_vs_oracle(eng, orc, N, C, nrep, order, weighted):
 def test_default_dispatch_picks_the_documented_kernel(eng):
     """include/txmom.h's paragraph on the two int8 kernels, seen through resample_info() on real calls."""
     x, u = data(800_000, 32, 5)
-    for order, nrep, want in ((0, 256, "int8_table"), (2, 200, "int8_table"), (3, 200, "int8_fused"), (4, 128, "int8_fused"),
+    for order, nrep, want in ((0, 256, "int8_table"), (2, 200, "int8_table"), (3, 200, "int8_table"), (3, 128, "int8_fused"), (4, 128, "int8_fused"),
                               (4, 200, "int8_table"), (2, 64, "int8_fused"), (6, 130, "int8_fused"), (6, 256, "int8_table")):
         s = eng.DeviceSampler(1, nrep, x.shape[0])
         eng.resample_vals(x, u, order, sampler=s)

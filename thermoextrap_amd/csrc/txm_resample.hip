@@ -847,7 +847,7 @@ static constexpr bool throttle_on() {
 // passes against the fused kernel's one -- were ties on the kernel's first cut; after its re-cut (reads a slot ahead, no
 // spills; same box, fused / table, profiles/r05_orders34_ab.txt): order 4 168.3 / 163.2 (N = 1e8, nrep = 1000), 37.0 / 35.5
 // (2e7), 6.2 / 5.95 (1e7, nrep = 200), 1.55 / 1.42 (1e6, 384), 1.72 / 1.76 (3e6, 128); order 3 145.6 / 145.1, 31.8 / 31.9,
-// 5.47 / 5.55, 1.47 / 1.56 -- order 4 moves to the table kernel, order 3 stays fused (a tie, and no table in the workspace).
+// 5.47 / 5.55, 1.47 / 1.56 -- order 4 moved to the table kernel; order 3 followed once its passes were split 3 + 1 (below).
 // Replicates come in groups of 128 there, 64 on the fused kernel: a call whose padding to 128 wastes much more than its
 // padding to 64 stays fused (nrep = 64: 1.80 / 2.66 ms; 130: 3.45 / 3.92; 100: 2.87 / 2.93; 200, 256, 1000: the table above).
 static bool table_kernel_pays(int64_t nrep, int K, bool has_y) {
@@ -857,8 +857,11 @@ static bool table_kernel_pays(int64_t nrep, int K, bool has_y) {
   // order 4 is only ~3 % ahead on the table kernel, and one 128-replicate group is 382 workgroups per 1e8 samples -- 1.5 rounds of
   // the 256 CUs -- where two 64-replicate groups of the fused kernel are 3.0 (a 125-replicate slab, what one of 8 ranks runs in
   // bench.py --mode replicas: 22.6 ms fused, 24.4 table)
-  if (K == 5) return pad128 >= 2 * G_REPS;
-  return K != 4;
+  // order 3 likewise since its four row sets go as 3 + 1 (the single-row-set pass takes 256 replicates per workgroup: 101 ms for
+  // the two passes against 109 for 2 + 2): 142.2 / 150.1 ms table / fused at N = 1e8, 31.1 / 32.7 at 2e7, 5.4 / 5.5 at 1e7 x 200,
+  // 1.27 / 1.32 at 1e6 x 384, 1.59 / 1.50 at 3e6 x 128 (profiles/r05_pass_split_ab.txt)
+  if (K == 4 || K == 5) return pad128 >= 2 * G_REPS;
+  return true;
 }
 
 static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K, int call_path = TXM_PATH_AUTO) {

@@ -855,15 +855,22 @@ bool i8g_applicable(const double *x, int64_t ldx_s, int64_t C, const double *y, 
 }
 
 // the passes of one 32-column group over the count table of replicate groups [rep_begin, rep_begin + 128 n_grp):
-// K power row sets (+ the second matrix's) dealt out over the fewest passes of at most three, sizes within one of each
-// other (a pass costs at least a read of the table, so two passes of 2 beat 3 + 1); the second matrix rides on the last
+// K power row sets (+ the second matrix's) over the fewest passes of at most three.  Measured pass times at the north-star size:
+// 70.5 / 54.5 / 30.8 ms for 3 / 2 / 1 row sets (the single-row-set pass takes 256 replicates per workgroup), so without a second
+// matrix a remainder of one goes into a pass of its own -- 3 + 1 (101 ms) beats 2 + 2 (109), 3 + 3 + 1 beats 3 + 2 + 2 -- and
+// every other count is dealt out evenly; with a second matrix (it rides on the last pass, which needs a power beside it) evenly.
 int launch_resample_i8g(const I8Args &a, int K, bool weighted, const unsigned char *table, int64_t rep_begin, int n_grp,
                         hipStream_t st) {
   const bool ys = a.y != nullptr;
   const int rows = K + (ys ? 1 : 0), np = (rows + 2) / 3;
+#ifdef TXM_G_EVEN_SPLIT  // (A/B build: sizes within one of each other, always)
+  const bool greedy = false;
+#else
+  const bool greedy = !ys && rows > 3 && rows % 3 == 1;
+#endif
   int j0 = 0;
   for (int i = 0; i < np; ++i) {
-    const int n = rows / np + (i < rows % np ? 1 : 0);
+    const int n = greedy ? (i < np - 1 ? 3 : 1) : rows / np + (i < rows % np ? 1 : 0);
     const bool last = i == np - 1;
     const int jn = n - ((last && ys) ? 1 : 0);
     const bool y_here = last && ys;
