@@ -28,8 +28,8 @@ python3 bench.py --steps 10 --warmup 2 > gpurun_out/${TAG}_bench.json 2> gpurun_
 for c in c2 c4 c3 c5; do
   python3 bench.py --config $c --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_$c.json 2>> gpurun_out/${TAG}_bench.err || echo "bench $c failed"
 done
-# (the north star runs the table kernel since the rule moved order 4 over: the fused kernel's counters at order 3, which it keeps)
-PMC_ORDER=${PMC_ORDER_FUSED:-3} PMC_TAG=${TAG}_pmc_i8t PMC_N=1e8 PMC_NREP=1000 bash tools/i8_pmc.sh 1e8 1000 > gpurun_out/${TAG}_pmc.log 2>&1 || echo "pmc failed"
+# (every wide order runs the table kernel by rule now; the fused kernel's counters: a 125-replicate slab of the north star, which it keeps)
+PMC_ORDER=${PMC_ORDER_FUSED:-4} PMC_TAG=${TAG}_pmc_i8t PMC_N=1e8 PMC_NREP=125 bash tools/i8_pmc.sh 1e8 125 > gpurun_out/${TAG}_pmc.log 2>&1 || echo "pmc failed"
 KREGEX=resample_i8g_kernel PMC_ORDER=${PMC_ORDER_TABLE:-4} PMC_TAG=${TAG}_pmc_i8g PMC_N=1e8 PMC_NREP=1000 bash tools/i8_pmc.sh 1e8 1000 > gpurun_out/${TAG}_pmc_g.log 2>&1 || echo "pmc g failed"
 timeout -k 10 900 python3 tools/profile_shapes.py 1e8 > gpurun_out/${TAG}_shapes.jsonl 2> gpurun_out/${TAG}_shapes.err || echo "shapes failed"
 cp gpurun_out/${TAG}_bench*.json gpurun_out/${TAG}_shapes.jsonl profiles/ 2>/dev/null
