@@ -101,9 +101,68 @@ class _DeviceTable:
         return out
 
 
+_STATE_KINDS = frozenset({"du", "u", "dxdu", "xu", "x1", "umean"})
+
+
 @lru_cache(16)
 def _minus_log_series():
     return S.DerivSeries(S.Poly.atom(("X", 0)), rule=S.chain_rule, post_func="minus_log")
+
+
+class _HostSource:
+    """What ``predict`` / the GP input need to know about a derivative array that was evaluated on the host (the layout
+    words of data.DerivSource, without a device state behind them)."""
+
+    def __init__(self, out_dims, out_shape, coords, lead_dim):
+        self.out_dims, self.out_shape, self.coords = list(out_dims), list(out_shape), coords
+        has_lead = lead_dim is not None and bool(out_dims) and out_dims[0] == lead_dim
+        self.nrep = int(out_shape[0]) if has_lead else 1
+        rest = out_shape[1:] if has_lead else out_shape
+        self.nval = int(np.prod(rest)) if len(rest) else 1
+
+
+class _SympyFuncs:
+    """``Derivatives.from_sympy(exprs, args)``: ``self[i]`` is the lambdified ``exprs[i]`` exactly as the reference's
+    ``Lambdify`` builds it (models.py:241-243), ``self.series[i]`` its translation into a polynomial table for the device
+    evaluator -- raising NotImplementedError for an expression that is not a Laurent polynomial (+ one ``-log``) in the
+    indexed symbols, in which case ``Derivatives.derivs`` evaluates the lambdified functions on the host."""
+
+    def __init__(self, exprs, args):
+        self.exprs, self.args = exprs, tuple(args)
+        self._funcs: dict = {}
+        self.series = _SympySeries(exprs)
+
+    def __getitem__(self, order):
+        if order not in self._funcs:
+            import sympy as sp
+
+            self._funcs[order] = sp.lambdify(self.args, self.exprs[order])
+        return self._funcs[order]
+
+
+class _SympySeries:
+    def __init__(self, exprs):
+        self._exprs = exprs
+        self._items: dict = {}
+
+    def __getitem__(self, order):
+        if order not in self._items:
+            self._items[order] = S.poly_from_expr(self._exprs[order])
+        return self._items[order]
+
+
+def _arg_names(args):
+    """names of the symbol families of ``args``: strings as they are, sympy ``Symbol`` / ``IndexedBase`` by name."""
+    if args is None:
+        return None
+    return tuple(a if isinstance(a, str) else str(getattr(a, "name", getattr(a, "label", a))) for a in args)
+
+
+def _defining_class(obj, name):
+    for klass in type(obj).__mro__:
+        if name in vars(klass):
+            return klass
+    return None
 
 
 class Derivatives(_Params):
@@ -111,20 +170,67 @@ class Derivatives(_Params):
 
     Parameters
     ----------
-    series : SymDerivBase
-        ``series[i]`` is the i-th derivative polynomial.
-    args : sequence of str
-        names of the symbol families, in the order the reference passes them to
-        its lambdified functions (central: x1, du, dxdu; raw: u, xu).
+    funcs : sequence of callable -- or of polynomials
+        ``funcs[i](*args)`` gives the i-th derivative (the reference's contract, models.py:296-300: any object with
+        ``__getitem__``, e.g. the ``VolumeDerivFuncs`` class of examples/usage/basic/Customized_Derivatives.ipynb).
+        The built-in factories pass a series of :class:`thermoextrap_amd.symbolic.Poly` instead, which is evaluated by
+        ONE table kernel from the moment states in HBM (txm_eval_poly).
+    exprs : sequence of sympy expressions, optional
+    args : sequence of str or sympy symbols, optional
+        the symbol families, in the order the functions take them (central: x1, du, dxdu; raw: u, xu; callbacks
+        append their own).
+
+    Which route ``derivs(data)`` takes:
+
+    * polynomial series + a data object whose callback is the default one or supplies ``device_sources`` (the two
+      built-in callbacks): the device table;
+    * plain callables, or a callback that (re)defines ``derivs_args`` without a matching ``device_sources``, or an
+      expression the table cannot hold: ``funcs[i](*data.derivs_args)`` on the host selectors, as the reference does
+      (models.py:357-383).  A callback's ``derivs_args`` is never ignored.
     """
 
-    _fields = ("series", "args")
+    _fields = ("funcs", "exprs", "args")
 
-    def __init__(self, series, args=None):
-        self.series = series
+    def __init__(self, funcs=None, *, exprs=None, args=None, series=None):
+        if funcs is None:
+            funcs = series
+        if funcs is None:
+            raise TypeError("Derivatives needs funcs (callables, or a polynomial series)")
+        self.funcs = funcs
         self.args = args
-        self.exprs = _ExprView(series)
+        self.series = getattr(funcs, "series", None)
+        if self.series is None and self._looks_like_poly_series(funcs):
+            self.series = funcs
+        self.exprs = exprs if exprs is not None else (_ExprView(self.series) if self.series is not None else None)
         self._tables: dict = {}
+
+    @staticmethod
+    def _looks_like_poly_series(funcs) -> bool:
+        try:
+            return isinstance(funcs[0], S.Poly)
+        except Exception:  # noqa: BLE001 -- a user's funcs object may refuse order 0 however it likes
+            return False
+
+    # ---- routes ---------------------------------------------------------------------------------------------------
+    def _device_route(self, data) -> bool:
+        """True when the device table can serve ``data`` (see the class docstring)."""
+        if self.series is None:
+            return False
+        meta = getattr(data, "meta", None)
+        if meta is None:
+            return True
+        from .data import DataCallback, DataCallbackABC
+
+        args_cls = _defining_class(meta, "derivs_args")
+        if args_cls in (DataCallback, DataCallbackABC, None):
+            return True          # nothing appended to the data object's own selectors
+        hook_cls = _defining_class(meta, "device_sources")
+        if hook_cls is None:
+            return False         # a callback with its own derivs_args and no device view of them
+        # a subclass that overrides derivs_args BELOW the class that supplies device_sources changed the arguments
+        # without telling the device hook: honour the arguments
+        mro = type(meta).__mro__
+        return mro.index(args_cls) >= mro.index(hook_cls)
 
     def _table_for(self, src, order, extra_resolve=None) -> _DeviceTable:
         key = (order, src.central, src.x_is_u, src.nrep, src.ndrv, src.nval, src.K)
@@ -141,6 +247,10 @@ class Derivatives(_Params):
                 d = a[2] if len(a) > 2 and a[2] is not None else 0
                 if kind == "x1":
                     d, n = (a[1] or 0), 0
+                if kind not in _STATE_KINDS:
+                    # a symbol the moment state does not hold and no device hook supplied: the host route decides
+                    # (the callback's derivs_args may carry it)
+                    raise S.NotRepresentable(f"symbol family {kind!r} has no device source")
                 off, s_rep, s_val = src.resolve(kind, n, d)
                 specs.append((0, off, s_rep, s_val))
             built = _DeviceTable(table, specs)
@@ -162,14 +272,14 @@ class Derivatives(_Params):
         if order is None:
             raise ValueError("must specify order or data")
 
-        src = data._derivs_source()
-        srcs = [src.tensor]
-        extra = None
-        hook = getattr(data.meta, "device_sources", None)
-        if hook is not None:
-            extra = hook(data=data, src=src, srcs=srcs)
-        table = self._table_for(src, order, extra)
-        vals = table.run(srcs, src.nrep, src.nval)  # (order+1, nrep, nval)
+        vals = src = None
+        if self._device_route(data):
+            try:
+                vals, src = self._derivs_device(data, order)
+            except S.NotRepresentable:
+                vals = None      # from_sympy expression outside the table's algebra: the lambdified functions serve
+        if vals is None:
+            return self._derivs_host(data, order, minus_log, order_dim, norm, _device)
         if minus_log:
             ml = _minus_log_series()
             key = ("mlog", order, src.nrep, src.nval)
@@ -197,16 +307,67 @@ class Derivatives(_Params):
         out._inherit(src.coords)
         return out
 
+    def _derivs_device(self, data, order):
+        src = data._derivs_source()
+        srcs = [src.tensor]
+        extra = None
+        hook = getattr(data.meta, "device_sources", None)
+        if hook is not None:
+            extra = hook(data=data, src=src, srcs=srcs)
+        table = self._table_for(src, order, extra)
+        return table.run(srcs, src.nrep, src.nval), src  # (order+1, nrep, nval)
+
+    def _derivs_host(self, data, order, minus_log, order_dim, norm, _device):
+        """``funcs[i](*data.derivs_args)`` (reference models.py:357-383).  The arguments are the data object's host
+        selectors -- slices of the moment states the reduction kernels produced -- plus whatever the callback appends."""
+        dargs = tuple(data.derivs_args)
+        if self.series is not None and not callable(self._first_func()):
+            out = self._derivs_from_args(dargs, order, minus_log, None, norm)
+        else:
+            out = [self.funcs[i](*dargs) for i in range(order + 1)]
+            if minus_log:
+                ml = _minus_log_series()
+                X = list(out)
+                out = [S.eval_host(ml[i], lambda a: X[a[1]]) for i in range(order + 1)]
+            if norm:
+                out = [x / math.factorial(i) for i, x in enumerate(out)]
+        if _device or order_dim is not None:
+            lab = [o if is_labelled(o) else DataArray(np.asarray(o, dtype=float), ()) for o in out]
+            ref = max(lab, key=lambda o: len(o.dims))
+            lab = [o if o.dims == ref.dims else (o + 0.0 * ref).transpose(*ref.dims) for o in lab]
+        if _device:
+            lead = getattr(data, "_lead_dim", lambda: None)()
+            if lead is None and getattr(data, "rec_dim", None) in ref.dims:
+                lead = data.rec_dim
+            if lead in ref.dims and ref.dims[0] != lead:
+                lab = [o.transpose(lead, *[d for d in ref.dims if d != lead]) for o in lab]
+                ref = lab[0]
+            host = np.stack([np.asarray(o.values, dtype=np.float64) for o in lab])
+            src = _HostSource(ref.dims, list(ref.shape), dict(ref._coords), lead if lead in ref.dims else None)
+            return engine.to_device(host.reshape(order + 1, src.nrep, src.nval)), src
+        if order_dim is None:
+            return out
+        return concat(lab, order_dim)
+
+    def _first_func(self):
+        try:
+            return self.funcs[0]
+        except Exception:  # noqa: BLE001
+            return None
+
     def _derivs_from_args(self, args, order, minus_log, order_dim, norm):
         """``derivs(args=...)`` without a data object (reference models.py:357-383: ``funcs[i](*args)``): the caller's
         arrays are not moment states in HBM, so the polynomials are evaluated where the arguments live -- on the host,
         with the arguments' own arithmetic (numpy / labelled arrays).  Same tables as the device path."""
         if order is None:
             raise ValueError("must specify order or data")
-        if self.args is None:
-            raise ValueError("this Derivatives object does not name its arguments (args=None)")
-        resolve = S.resolve_from_args(self.args, tuple(args))
-        out = [S.eval_host(self.series[i], resolve) for i in range(order + 1)]
+        if self.series is None or callable(self._first_func()):
+            out = [self.funcs[i](*args) for i in range(order + 1)]
+        else:
+            if self.args is None:
+                raise ValueError("this Derivatives object does not name its arguments (args=None)")
+            resolve = S.resolve_from_args(_arg_names(self.args), tuple(args))
+            out = [S.eval_host(self.series[i], resolve) for i in range(order + 1)]
         if minus_log:
             ml = _minus_log_series()
             X = list(out)
@@ -225,7 +386,17 @@ class Derivatives(_Params):
 
     @classmethod
     def from_series(cls, series, args):
-        return cls(series=series, args=args)
+        return cls(series, args=args)
+
+    @classmethod
+    def from_sympy(cls, exprs, args):
+        """From sympy expressions over the reference's symbols -- ``IndexedBase`` families ``du[n]``, ``dxdu[n]`` /
+        ``dxdu[n, d]``, ``u[n]``, ``xu[n]`` / ``xu[n, d]``, ``x1[d]`` and the plain symbols ``x1``, ``u`` (reference
+        models.py:404-421, beta.py:46-240).  ``exprs[i]`` is the i-th derivative, ``args`` the symbols in the order the
+        data object's ``derivs_args`` supplies them.  Expressions that are Laurent polynomials in those symbols (plus at
+        most one ``-log(symbol)``) are compiled into the device table; anything else is lambdified and evaluated on the
+        host selectors exactly as the reference does."""
+        return cls(_SympyFuncs(exprs, args), exprs=exprs, args=args)
 
 
 @lru_cache(10)

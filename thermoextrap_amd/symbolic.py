@@ -348,6 +348,93 @@ def poly_from_sympy(expr, fs, func: Poly) -> Poly:
     return out if poly is None else out + poly
 
 
+class NotRepresentable(NotImplementedError):
+    """An expression outside the table evaluator's algebra (Laurent polynomials in atoms + one ``-log(atom)``), or a
+    symbol with no device source: ``Derivatives`` then evaluates on the host."""
+
+
+def _atom_from_sympy(obj) -> Atom | None:
+    """A sympy ``Indexed`` / ``Symbol`` of the reference's naming (beta.py:46-240, volume.py:63-78) -> atom, None for a
+    symbol occurrence that is identically 1 (``du[0]``, ``u[0]``); raises for ``du[1]`` / ``dxdu[0]`` = 0 via ZeroAtom."""
+    import sympy as sp
+
+    if isinstance(obj, sp.Indexed):
+        name = _ROLE.get(str(obj.base.label), str(obj.base.label))
+        try:
+            idx = tuple(int(i) for i in obj.indices)
+        except TypeError as e:
+            raise NotRepresentable(f"symbolic index in {obj}") from e
+        if name in ("du", "u"):
+            if len(idx) != 1:
+                raise NotRepresentable(f"{obj}: one index expected")
+            return (name, idx[0])
+        if name in ("dxdu", "xu"):
+            if len(idx) not in (1, 2):
+                raise NotRepresentable(f"{obj}: one or two indices expected")
+            return (name, idx[0], idx[1] if len(idx) == 2 else None)
+        if name == "x1":
+            return ("x1", idx[0])
+        return (name, *idx)
+    if isinstance(obj, sp.Symbol):
+        name = str(obj.name)
+        if name == "u":
+            return ("umean",)
+        if name == "x1":
+            return ("x1", None)
+        return (name,)
+    raise NotRepresentable(f"{obj} is not a symbol of the moment families")
+
+
+def _atom_value(a: Atom):
+    """identities of the families: du[0] = 1, du[1] = 0, dxdu[0] = 0, u[0] = 1 (reference beta.py:57-66, 119-126)."""
+    if a[0] == "du" and a[1] in (0, 1):
+        return 1 - a[1]
+    if a[0] == "u" and a[1] == 0:
+        return 1
+    if a[0] == "dxdu" and a[1] == 0:
+        return 0
+    return None
+
+
+def poly_from_expr(expr) -> Poly:
+    """A sympy expression over the reference's symbols as a Poly; NotRepresentable when it is not a Laurent polynomial
+    with rational coefficients plus at most one bare ``-log(symbol)``."""
+    import sympy as sp
+
+    expr = sp.expand(sp.sympify(expr))
+    out = Poly()
+    for term in sp.Add.make_args(expr):
+        c, rest = term.as_coeff_Mul()
+        if not c.is_Rational:
+            raise NotRepresentable(f"coefficient {c} is not rational")
+        if isinstance(rest, sp.log):
+            if c != -1:
+                raise NotRepresentable(f"only a bare -log(symbol) term is supported, got {term}")
+            a = _atom_from_sympy(rest.args[0])
+            if _atom_value(a) is not None:
+                raise NotRepresentable(f"log of the constant {rest.args[0]}")
+            out = out + Poly.minus_log(a)
+            continue
+        p = Poly.const(Fraction(int(c.p), int(c.q)))
+        for base, e in rest.as_powers_dict().items():
+            if base.is_Number:
+                if base != 1:
+                    raise NotRepresentable(f"{term}")
+                continue
+            if not e.is_Integer:
+                raise NotRepresentable(f"non-integer power in {term}")
+            a = _atom_from_sympy(base)
+            v = _atom_value(a)
+            if v is not None:
+                if v == 0 and int(e) < 0:
+                    raise ZeroDivisionError(f"{base} is identically 0")
+                p = p * (v ** int(e) if int(e) >= 0 else 1)
+            else:
+                p = p * Poly.atom(a, int(e))
+        out = out + p
+    return out
+
+
 # ---------------------------------------------------------------------------
 # compilation to the device table (include/txmom.h: txm_poly_table)
 # ---------------------------------------------------------------------------
