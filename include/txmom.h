@@ -268,6 +268,17 @@ typedef struct txm_resample_opts {
   double *out_y;
 } txm_resample_opts;
 int txm_resample_path(int64_t N, int64_t C, int64_t nrep, int order);
+/* The contraction kernel ONE scale-mode call with these options runs when it is handed txm_resample_vals_ws_bytes_opts(N, C,
+ * nrep, order, path, has_y) bytes: TXM_PATH_FP64, TXM_PATH_INT8_FUSED or TXM_PATH_INT8_TABLE, OR-ed with TXM_KERNEL_WITH_Y
+ * when that kernel carries opts.y as a row set of its own (otherwise y is bootstrapped by a separate order-0 pass behind the
+ * call).  `aligned` != 0: x (and y) are 16-byte aligned with an even row pitch >= C rounded up to 4 (the count-table kernel's
+ * operand requirement; anything else runs the fused kernel).  What a caller-held pre-pass block (opts.prep) contains depends
+ * on exactly this word: WITH_Y blocks hold y's pivot, scales and guard flags, the others do not -- reuse a block
+ * (prep_valid = 1) only for calls on the same tensors and (N, C, order) that return the same word here.  Replicate slabs of
+ * one bootstrap (spec.rep0) should pass the whole call's kernel as their opts.path, so that a short last slab does not fall on
+ * the other side of a replicate-count threshold of the rule. */
+#define TXM_KERNEL_WITH_Y 0x100
+int txm_resample_kernel(int64_t N, int64_t C, int64_t nrep, int order, int path, int has_y, int aligned);
 int txm_set_resample_path(int path);
 int txm_resample_vals_info(const void *ws, int64_t N, int64_t C, int64_t nrep, int order,
                            int64_t *info_host, txm_stream stream);

@@ -234,6 +234,179 @@ def test_dispatch_rule_matches_the_header_thresholds(lib):
     assert lib.txm_sampler_count_table_bytes(N, 1000) == table(1000)
 
 
+def test_kernel_word_is_what_a_prep_block_is_keyed_on(lib):
+    """txm_resample_kernel: the concrete kernel of one call and whether it carries a second matrix -- what decides the content
+    of a kept pre-pass block (round-5 advice: with y at order 4 the fused kernel below two replicate groups leaves no y tables,
+    the table kernel above reads them)."""
+    assert lib.txm_set_resample_path(-1) == 0
+    Kn = lib.txm_resample_kernel
+    N, FP64, FUSED, TABLE, WY = 10_000_000, 0, 2, 3, 0x100
+    # order 4 + y: the rule's replicate thresholds flip both the kernel and who carries y
+    assert Kn(N, 32, 64, 4, -1, 1, 1) == FUSED and Kn(N, 32, 129, 4, -1, 1, 1) == FUSED and Kn(N, 32, 192, 4, -1, 1, 1) == FUSED
+    assert Kn(N, 32, 128, 4, -1, 1, 1) == TABLE | WY and Kn(N, 32, 1000, 4, -1, 1, 1) == TABLE | WY
+    # other orders: the fused kernel carries y itself (a row set of its last pass)
+    assert Kn(N, 32, 64, 6, -1, 1, 1) == FUSED | WY and Kn(N, 32, 1000, 6, -1, 1, 1) == TABLE | WY
+    # without y: orders 3 and 4 from two replicate groups on
+    assert Kn(N, 32, 128, 4, -1, 0, 1) == FUSED and Kn(N, 32, 256, 4, -1, 0, 1) == TABLE and Kn(N, 32, 1000, 2, -1, 0, 1) == TABLE
+    # a forced path is honoured (a slab of 40 replicates of a table call), misaligned operands and narrow states never ride the table
+    assert Kn(N, 32, 40, 4, TABLE, 1, 1) == TABLE | WY and Kn(N, 32, 1000, 4, FUSED, 1, 1) == FUSED
+    assert Kn(N, 32, 1000, 4, -1, 1, 0) == FUSED and Kn(N, 32, 1000, 4, TABLE, 0, 0) == FUSED
+    assert Kn(N, 8, 1000, 3, -1, 1, 1) == FUSED and Kn(N, 8, 1000, 3, TABLE, 0, 1) == FUSED
+    assert Kn(N, 32, 16, 4, -1, 0, 1) == FP64 and Kn(N, 32, 1000, 4, FP64, 1, 1) == FP64 and Kn(N, 32, 1000, 8, -1, 0, 1) == FP64
+    assert Kn(0, 32, 1000, 4, -1, 0, 1) == FP64
+    # consistent with the workspace query: a call whose kernel word says TABLE is sized with the table
+    W = lib.txm_resample_vals_ws_bytes_opts
+    for nrep in (64, 128, 129, 200, 1000):
+        for order in (2, 3, 4, 6):
+            for has_y in (0, 1):
+                table = (Kn(N, 32, nrep, order, -1, has_y, 1) & 0xFF) == TABLE
+                assert (W(N, 32, nrep, order, -1, has_y) == W(N, 32, nrep, order, TABLE, has_y)) == table or \
+                    W(N, 32, nrep, order, TABLE, has_y) == W(N, 32, nrep, order, FUSED, has_y), (nrep, order, has_y)
+
+
+# ---------------------------------------------------------------------------
+# static guard for inline assembly (round-5 verdict item 5): a GPU memory-access fault of that round came from an asm
+# statement that wrote SCC without naming it as clobbered -- the compiler kept a live condition in SCC across it.  Source
+# level, no disassembly: every `asm volatile` of the kernels is parsed and every instruction in it that writes M0, SCC, VCC
+# or EXEC must be covered by the statement's clobber list (or by an output operand for the SGPR / VGPR it names).
+# ---------------------------------------------------------------------------
+_SCC_WRITERS = re.compile(
+    r"^s_(cmp|cmpk|add|addc|sub|subb|and|andn\d|or|orn\d|xor|xnor|nand|nor|not|lshl|lshr|ashr|bfe|bfm_never|min|max|abs|absdiff|"
+    r"bitcmp|wqm|quadmask|bcnt\d|ff\d|flbit|sext_never|lshl\d_add|mul_hi_never|addk|cselect_never|"
+    r"and_saveexec|or_saveexec|xor_saveexec|andn\d_saveexec|orn\d_saveexec|nand_saveexec|nor_saveexec|xnor_saveexec)")
+_SCC_SAFE = re.compile(r"^s_(mov|cmov|movk|mul_i32|mul_hi|nop|waitcnt|barrier|sleep|setprio|load|buffer_load|memtime|memrealtime|"
+                       r"sendmsg|getreg|setreg|bfm|sext|brev|pack|getpc|branch|cbranch|endpgm|cselect|dcache|icache|trap|sethalt|"
+                       r"ttrace|inst_prefetch|clause|code_end|version|round_mode|denorm_mode|wait_idle|wakeup|store|scratch|atomic)")
+
+
+def _asm_statements(text):
+    """(line number, template string, clobber list) of every asm statement of a source text."""
+    out = []
+    for m in re.finditer(r"\basm\s+volatile\s*\(", text):
+        i, depth, in_str = m.end(), 1, False
+        while depth and i < len(text):
+            ch = text[i]
+            if in_str:
+                if ch == "\\":
+                    i += 1
+                elif ch == '"':
+                    in_str = False
+            elif ch == '"':
+                in_str = True
+            elif ch == "(":
+                depth += 1
+            elif ch == ")":
+                depth -= 1
+            i += 1
+        body = text[m.end():i - 1]
+        # split the top level at ':' outside strings and parentheses ("::" = an empty section)
+        secs, cur, depth, in_str, k = [], "", 0, False, 0
+        while k < len(body):
+            ch = body[k]
+            if in_str:
+                cur += ch
+                if ch == "\\":
+                    cur += body[k + 1]
+                    k += 1
+                elif ch == '"':
+                    in_str = False
+            elif ch == '"':
+                in_str = True
+                cur += ch
+            elif ch in "([":
+                depth += 1
+                cur += ch
+            elif ch in ")]":
+                depth -= 1
+                cur += ch
+            elif ch == ":" and depth == 0:
+                secs.append(cur)
+                cur = ""
+            else:
+                cur += ch
+            k += 1
+        secs.append(cur)
+        template = "".join(re.findall(r'"((?:[^"\\]|\\.)*)"', secs[0])).replace("\\n", "\n").replace("\\t", " ")
+        clob = set(re.findall(r'"([^"]*)"', secs[3])) if len(secs) > 3 else set()
+        outputs = secs[1] if len(secs) > 1 else ""
+        out.append((text.count("\n", 0, m.start()) + 1, template, clob, outputs))
+    return out
+
+
+def _asm_violations(text):
+    bad = []
+    for line, template, clob, outputs in _asm_statements(text):
+        for ins in re.split(r"[\n;]", template):
+            ins = ins.strip()
+            if not ins:
+                continue
+            mnem, _, ops = ins.partition(" ")
+            dst = ops.split(",")[0].strip() if ops else ""
+            need = set()
+            if dst == "m0" or re.match(r"^s_(mov|movk).*\bm0\b", ins) and dst == "m0":
+                need.add("m0")
+            if mnem.startswith("s_") and not _SCC_SAFE.match(mnem):
+                if _SCC_WRITERS.match(mnem):
+                    need.add("scc")
+                else:
+                    bad.append((line, ins, "scalar instruction the guard does not know: classify it (SCC writer or not)"))
+            if dst in ("vcc", "vcc_lo", "vcc_hi") or (re.match(r"^v_cmp_", mnem) and not mnem.endswith("_e64")):
+                need.add("vcc")
+            if re.match(r"^v_(add|sub|subrev)_co_u32$", mnem) and len(ops.split(",")) >= 2 and ops.split(",")[1].strip().startswith("vcc"):
+                need.add("vcc")
+            if dst in ("exec", "exec_lo", "exec_hi") or mnem.startswith("v_cmpx") or "saveexec" in mnem:
+                need.add("exec")
+            for r in need:
+                if r not in clob:
+                    bad.append((line, ins, f"writes {r.upper()} but the statement's clobber list {sorted(clob)} does not name it"))
+    return bad
+
+
+def test_inline_asm_clobbers_are_complete():
+    """Every asm statement of the kernels names what it writes behind the compiler's back.  The snippet of round 5's reverted
+    scalar-condition experiment (gpurun_out/r5_chk12.log: a memory access fault on the first case) must FAIL the guard."""
+    n = 0
+    for f in sorted((ROOT / "thermoextrap_amd" / "csrc").glob("*.h*")):
+        text = f.read_text()
+        n += len(_asm_statements(text))
+        assert not _asm_violations(text), (f.name, _asm_violations(text))
+    assert n >= 25, n                                     # the scanner sees the statements (i8g: 21, i8t: 5, common: 4)
+    # the statements that write M0 today are found and are covered
+    i8g = (ROOT / "thermoextrap_amd" / "csrc" / "txm_resample_i8g.hip").read_text()
+    m0 = [st for st in _asm_statements(i8g) if "s_mov_b32 m0" in st[1]]
+    assert len(m0) >= 3 and all("m0" in st[2] for st in m0)
+    # negative controls: round 5's faulting statement (SCC written, not clobbered), and the same mistakes for M0 / VCC / EXEC
+    reverted = 'uint32_t c; asm volatile("s_lshr_b32 %0, %1, 1" : "=s"(c) : "s"(wave));'
+    v = _asm_violations(reverted)
+    assert len(v) == 1 and "SCC" in v[0][2]
+    assert not _asm_violations('asm volatile("s_lshr_b32 %0, %1, 1" : "=s"(c) : "s"(wave) : "scc");')
+    assert _asm_violations('asm volatile("s_mov_b32 m0, %0\\n\\tds_write_addtid_b32 %1" :: "s"(b), "v"(x) : "memory");')
+    assert not _asm_violations('asm volatile("s_mov_b32 m0, %0\\n\\tds_write_addtid_b32 %1" :: "s"(b), "v"(x) : "memory", "m0");')
+    assert _asm_violations('asm volatile("v_cmp_lt_u32 vcc, %0, %1" :: "v"(a), "v"(b));')
+    assert _asm_violations('asm volatile("s_and_saveexec_b64 %0, vcc" : "=s"(m) :: "scc");')
+    assert _asm_violations('asm volatile("s_cmp_eq_u32 %0, 0\\n\\ts_cselect_b32 %1, 1, 0" : "=s"(r) : "s"(a));')
+    assert _asm_violations('asm volatile("s_frobnicate_b32 %0" : "=s"(r));')          # unknown scalar mnemonic: classify first
+
+
+def test_csrc_sha_covers_the_public_header_and_the_build_flags(monkeypatch, tmp_path):
+    """A library is current only if it was built from these sources WITH these flags against this header (round-5 advice:
+    an edit of include/txmom.h or of _build.FLAGS did not trigger a rebuild)."""
+    from thermoextrap_amd import _build
+
+    base = _build.csrc_sha()
+    monkeypatch.setattr(_build, "FLAGS", [*_build.FLAGS, "-DX=1"])
+    assert _build.csrc_sha() != base
+    monkeypatch.undo()
+    monkeypatch.setattr(_build, "EXTRA_FLAGS", {**_build.EXTRA_FLAGS, "txm_api.hip": ["-DY"]})
+    assert _build.csrc_sha() != base
+    monkeypatch.undo()
+    assert _build.csrc_sha() == base
+    edited = tmp_path / "txmom.h"
+    edited.write_bytes(_build.HEADER.read_bytes() + b"/* an edit */")
+    monkeypatch.setattr(_build, "HEADER", edited)
+    assert _build.csrc_sha() != base
+
+
 def test_graft_entry_build_runs(lib):
     """The driver's build check: __graft_entry__.build() compiles (a no-op when the library is current), loads and checks
     the ABI version the binding expects -- it carried a literal 1 into the round that made the ABI 2."""

@@ -309,3 +309,73 @@ def test_workspace_budget_slabs_equal_the_unslabbed_rows_bit_for_bit(txm):
             assert torch.equal(whole[1], parts[1]), (nrep, order, path)
         if path != "fp64":
             assert prep.misses == 1 and prep.hits >= 3, (prep.misses, prep.hits)
+
+
+def test_prep_block_is_keyed_on_the_kernel_that_fills_it_second_matrix_order4(txm):
+    """Round-5 advice (medium): with y= at order 4 a call of 64 replicates runs the fused kernel, which does NOT carry y (its
+    block holds no y tables), a call of 1000 the table kernel, which does.  One ResamplePrep shared by both must not hand the
+    second call a block without y's pivot / scales / flags: the key is the kernel word of txm_resample_kernel, so the second
+    call recomputes -- and equals a cold call bit for bit, states and y means; coming back to 64 recomputes again."""
+    import torch
+
+    from thermoextrap_amd import engine as eng
+
+    N, C, order = 1_000_000, 32, 4
+    g = torch.Generator(device="cuda").manual_seed(11)
+    u = 174.85 + 5.31 * torch.randn(N, generator=g, dtype=torch.float64, device="cuda")
+    x = 0.2 + 1e-3 * u[:, None] + 0.05 * torch.randn(N, C, generator=g, dtype=torch.float64, device="cuda")
+    y = 3.0 - 0.25 * x + 0.01 * torch.randn(N, C, generator=g, dtype=torch.float64, device="cuda")
+    L = eng._L()
+    k64, k1000 = L.txm_resample_kernel(N, C, 64, order, -1, 1, 1), L.txm_resample_kernel(N, C, 1000, order, -1, 1, 1)
+    assert k64 == 2 and k1000 == (3 | 0x100)
+    prep = eng.ResamplePrep()
+    s64, s1000 = eng.DeviceSampler(5, 64, N), eng.DeviceSampler(5, 1000, N)
+    a64 = eng.resample_vals(x, u, order, sampler=s64, y=y, prep=prep)
+    assert (prep.hits, prep.misses) == (0, 1)
+    a1000 = eng.resample_vals(x, u, order, sampler=s1000, y=y, prep=prep)
+    assert (prep.hits, prep.misses) == (0, 2) and not eng.resample_info()["prep_reused"]
+    b1000 = eng.resample_vals(x, u, order, sampler=s1000, y=y, prep=prep)
+    assert (prep.hits, prep.misses) == (1, 2) and eng.resample_info()["prep_reused"]
+    c1000 = eng.resample_vals(x, u, order, sampler=s1000, y=y)           # cold: no block at all
+    for got in (a1000, b1000):
+        assert torch.equal(got[0], c1000[0]) and torch.equal(got[1], c1000[1])
+    c64 = eng.resample_vals(x, u, order, sampler=s64, y=y)
+    b64 = eng.resample_vals(x, u, order, sampler=s64, y=y, prep=prep)
+    assert prep.misses == 3
+    assert torch.equal(a64[0], c64[0]) and torch.equal(a64[1], c64[1]) and torch.equal(b64[0], c64[0]) and torch.equal(b64[1], c64[1])
+    # the y means are the weighted means of y on the draw, whatever kernel carried them
+    f = s1000.freq()[:4].to(torch.float64)
+    np.testing.assert_allclose((f @ y / f.sum(1, keepdim=True)).cpu().numpy(), c1000[1][:4].cpu().numpy(), rtol=1e-12)
+
+
+def test_short_last_slab_takes_the_whole_calls_kernel(txm):
+    """Round-5 advice (low): replicate slabs used to pin only int8 vs FP64; a last slab of <= 64 replicates then ran the fused
+    kernel while the others ran the table kernel -- with y= at order 4 its y means came from the separate order-0 bootstrap and
+    agreed with the unslabbed rows only to rounding.  Slabs now carry the whole call's kernel: 128 + 128 + 128 + 40 replicates,
+    y at order 4, bit for bit the unslabbed call, ONE pre-pass block for all of them and for the unslabbed call."""
+    import torch
+
+    from thermoextrap_amd import engine as eng
+
+    N, C, order, nrep = 1_000_000, 32, 4, 424
+    g = torch.Generator(device="cuda").manual_seed(12)
+    u = 174.85 + 5.31 * torch.randn(N, generator=g, dtype=torch.float64, device="cuda")
+    x = 0.2 + 1e-3 * u[:, None] + 0.05 * torch.randn(N, C, generator=g, dtype=torch.float64, device="cuda")
+    y = 0.5 * x + 1.0
+    L = eng._L()
+    assert L.txm_resample_kernel(N, C, nrep, order, -1, 1, 1) == (3 | 0x100)
+    assert L.txm_resample_kernel(N, C, 40, order, -1, 1, 1) == 2          # what the 40-replicate slab would pick on its own
+    s = eng.DeviceSampler(21, nrep, N, rep0=7)
+    old = eng.WORKSPACE_BUDGET_BYTES
+    prep = eng.ResamplePrep()
+    try:
+        eng.WORKSPACE_BUDGET_BYTES = 1 << 50
+        whole = eng.resample_vals(x, u, order, sampler=s, y=y, prep=prep)
+        assert (prep.hits, prep.misses) == (0, 1)
+        eng.WORKSPACE_BUDGET_BYTES = L.txm_resample_vals_ws_bytes_opts(N, C, 128, order, 3, 1) + L.txm_resample_y_ws_bytes(N, C, 128) + 4096
+        assert eng._slab_size(L, N, C, nrep, order, 3, True) == 128
+        parts = eng.resample_vals(x, u, order, sampler=s, y=y, prep=prep)
+        assert (prep.hits, prep.misses) == (4, 1)                           # the unslabbed call's block served the four slabs
+    finally:
+        eng.WORKSPACE_BUDGET_BYTES = old
+    assert torch.equal(whole[0], parts[0]) and torch.equal(whole[1], parts[1])

@@ -39,15 +39,20 @@ def _hipcc() -> str:
     return "hipcc"
 
 
+HEADER = CSRC.parent.parent / "include" / "txmom.h"   # the public C ABI (txm_common.h includes it)
+
+
 def csrc_sha() -> str:
-    """sha256 (16 hex digits) over the kernel sources: what a built library carries (txm_csrc_sha) and what ties a
-    committed profile to the code it was measured on (bench.py)."""
+    """sha256 (16 hex digits) over what decides the built library: the kernel sources, the public header they include and
+    the compiler flags -- what a built library carries (txm_csrc_sha) and what ties a committed profile to the code it was
+    measured on (bench.py)."""
     import hashlib
 
     h = hashlib.sha256()
-    for f in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h"))):
+    for f in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h"))) + [HEADER]:
         h.update(f.name.encode())
         h.update(f.read_bytes())
+    h.update(repr((FLAGS, sorted(EXTRA_FLAGS.items()), SOURCES)).encode())
     return h.hexdigest()[:16]
 
 

@@ -864,6 +864,14 @@ static bool table_kernel_pays(int64_t nrep, int K, bool has_y) {
   return true;
 }
 
+// ONE statement of "does this call run the count-table kernel" for the call itself, the workspace query and
+// txm_resample_kernel (what the host keys a kept pre-pass block on): `eff` is the call's path after the process-wide
+// override, `applicable` = i8g_applicable() of the operands.  The call additionally needs the table's bytes in its workspace.
+static bool table_call_rule(size_t table_bytes, int eff, int64_t nrep, int K, bool has_y, bool applicable) {
+  return eff != TXM_PATH_FP64 && eff != TXM_PATH_INT8_FUSED && table_bytes != 0 && applicable &&
+         (eff == TXM_PATH_INT8_TABLE || table_kernel_pays(nrep, K, has_y));
+}
+
 static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K, int call_path = TXM_PATH_AUTO) {
   if (!i8_supported(N, C, nrep, K)) return false;
   const int ov = call_path != TXM_PATH_AUTO ? call_path : path_override();
@@ -954,6 +962,22 @@ extern "C" int txm_resample_path(int64_t N, int64_t C, int64_t nrep, int order) 
   return use_i8(N, C, nrep, order + 1) ? TXM_PATH_INT8 : TXM_PATH_FP64;
 }
 
+// The contraction kernel ONE device-sampler call with these options runs -- TXM_PATH_FP64, TXM_PATH_INT8_FUSED or
+// TXM_PATH_INT8_TABLE -- given a workspace of txm_resample_vals_ws_bytes_opts(same arguments) bytes, | TXM_KERNEL_WITH_Y when
+// that kernel carries the second matrix (so that the call's pre-pass block holds y's pivot, scales and guard flags).
+// `aligned`: x (and y) 16-byte aligned with an even row pitch >= C rounded up to 4 -- what the table kernel's DMA needs.
+// A kept pre-pass block serves exactly the calls that return the same word here (and the same N, C, order, tensors).
+extern "C" int txm_resample_kernel(int64_t N, int64_t C, int64_t nrep, int order, int path, int has_y, int aligned) {
+  if (N < 1 || C < 1 || nrep < 1 || order < 0 || order > TXM_MAX_ORDER) return TXM_PATH_FP64;
+  const int K = order + 1;
+  if (!use_i8(N, C, nrep, K, path)) return TXM_PATH_FP64;
+  const I8Plan q = plan_i8(N, C, nrep, K);
+  const int eff = path != TXM_PATH_AUTO ? path : path_override();
+  const bool table = table_call_rule(q.table_bytes, eff, nrep, K, has_y != 0, aligned != 0 && C > 16);
+  const bool with_y = has_y != 0 && (table || i8t_carries_y(C, K));
+  return (table ? TXM_PATH_INT8_TABLE : TXM_PATH_INT8_FUSED) | (with_y ? TXM_KERNEL_WITH_Y : 0);
+}
+
 extern "C" size_t txm_resample_prep_bytes(int64_t N, int64_t C, int64_t nrep, int order) {
   if (N < 1 || C < 1 || nrep < 1 || order < 0 || order > TXM_MAX_ORDER) return 0;
   if (!i8_supported(N, C, nrep, order + 1)) return 256;
@@ -985,8 +1009,7 @@ extern "C" size_t txm_resample_vals_ws_bytes_opts(int64_t N, int64_t C, int64_t 
   if (i8_supported(N, C, nrep, order + 1)) {
     const I8Plan q = plan_i8(N, C, nrep, order + 1);
     const int eff = path != TXM_PATH_AUTO ? path : path_override();
-    const bool table = q.table_bytes != 0 && eff != TXM_PATH_FP64 && eff != TXM_PATH_INT8_FUSED &&
-                       (eff == TXM_PATH_INT8_TABLE || table_kernel_pays(nrep, order + 1, has_y != 0));
+    const bool table = table_call_rule(q.table_bytes, eff, nrep, order + 1, has_y != 0, true);
     const size_t m = table ? q.total_table : q.total;
     if (m > n) n = m;
   }
@@ -1139,9 +1162,8 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
     // and the passes) and the contraction kernel without a sampler inside (txm_resample_i8g.hip).  Misaligned operands and
     // TXM_PATH_INT8_FUSED keep the kernel that draws in place; narrow states and narrow tail groups always run it.
     const int eff_path = path != TXM_PATH_AUTO ? path : path_override();
-    const bool fused_only = eff_path == TXM_PATH_INT8_FUSED;
-    const bool table_call = !fused_only && q.table_bytes != 0 && ws_bytes >= q.total_table && i8g_applicable(x, ldx_s, C, y, ldy_s) &&
-                            (eff_path == TXM_PATH_INT8_TABLE || table_kernel_pays(nrep, K, y != nullptr));
+    const bool table_call = ws_bytes >= q.total_table &&
+                            table_call_rule(q.table_bytes, eff_path, nrep, K, y != nullptr, i8g_applicable(x, ldx_s, C, y, ldy_s));
     const bool with_y = y != nullptr && (table_call || i8t_carries_y(C, K));
     if (ws_bytes < q.total) {
       set_error("resample_vals: workspace too small (%zu < %zu)", ws_bytes, q.total);

@@ -295,10 +295,13 @@ class ResamplePrep:
     reference caches per data object the same way (data.py:285, 844-942).
 
     The key is built from the CALLER's tensors (storage pointer, torch version counter, shape, strides) -- not from the
-    contiguous temporaries a call may have to make -- and the block keeps strong references to them, so their storage
-    cannot be recycled under the key; the temporaries themselves are kept here and reused with the tables.  An in-place
-    edit of a sample array through torch, another shape or another replicate count therefore invalidates the block; so
-    does ``new_like`` on the owning data object (a fresh cache).  What torch cannot see -- another library writing the
+    contiguous temporaries a call may have to make -- plus (N, C, order) and the KERNEL WORD of the call
+    (txm_resample_kernel: fused / count-table kernel, and whether it carries a second matrix -- a block holds y's tables only
+    then); the block keeps strong references to the tensors, so their storage cannot be recycled under the key; the
+    temporaries themselves are kept here and reused with the tables.  An in-place edit of a sample array through torch,
+    another shape, or a replicate count that the dispatch rule sends to another kernel therefore invalidates the block (the
+    replicate slabs of one call and calls with other counts on the same kernel share it); so does ``new_like`` on the
+    owning data object (a fresh cache).  What torch cannot see -- another library writing the
     samples through a raw pointer -- does not bump a version counter: call ``invalidate()`` after such a write (the C
     ABI has no such state: ``prep_valid`` there is the caller's own statement)."""
 
@@ -386,6 +389,24 @@ def _call_path(path) -> int:
     return -1
 
 
+def _table_operands_ok(x2: torch.Tensor, ls: int, C: int, y: torch.Tensor | None) -> bool:
+    """The count-table kernel's operand requirement (txm_resample_kernel's `aligned`): 16-byte aligned, even row pitch
+    that holds C rounded up to 4 columns -- for x and for a second matrix."""
+    cq = (C + 3) // 4 * 4
+
+    def ok(t, pitch):
+        return t.data_ptr() % 16 == 0 and pitch % 2 == 0 and cq <= pitch
+
+    if not ok(x2, ls):
+        return False
+    if y is not None:
+        y2 = y.unsqueeze(1) if y.dim() == 1 else y
+        if y2.dim() != 2 or y2.stride(1) != 1 or (y2.shape[0] > 1 and y2.stride(0) < C):
+            return C % 2 == 0 and cq <= C      # copied contiguous below: pitch C, torch allocations are 256-byte aligned
+        return ok(y2, max(y2.stride(0) if y2.shape[0] > 1 else C, C))
+    return True
+
+
 def resample_vals(
     x: torch.Tensor,
     u: torch.Tensor,
@@ -464,26 +485,27 @@ def resample_vals(
         if tuple(out.shape) != (nrep, C, 2, order + 1) or not out.is_contiguous():
             raise ValueError(f"out must be a contiguous ({nrep}, {C}, 2, {order + 1}) tensor, got {tuple(out.shape)}")
     opts = ResampleOpts()
-    opts.path = _call_path(path)
+    opts.path = _slab if _slab is not None else _call_path(path)
+    kern = -1
+    if sampler is not None:
+        # the contraction kernel this call runs (FP64 / int8 fused / int8 count table) and whether it carries y: decided ONCE,
+        # for the whole call -- the rule looks at nrep, and neither a replicate slab nor a later call on the same pre-pass block
+        # may fall on the other side of one of its thresholds (a block holds y's tables only when the kernel carries y)
+        kern = L.txm_resample_kernel(N, C, nrep, order, opts.path, int(y is not None), int(_table_operands_ok(x2, ls, C, y)))
     if sampler is not None and _slab is None:
-        slab = _slab_size(L, N, C, nrep, order, opts.path, y is not None)
+        slab = _slab_size(L, N, C, nrep, order, kern & 0xFF, y is not None)
         if slab < nrep:
-            # replicate slabs: the kernel FAMILY is decided once, for the whole call (the shape rule looks at nrep; a slab must
-            # not fall on the other side of it), then every slab is an ordinary call on its rows of the sampler
-            fam = opts.path
-            if fam == -1:
-                fam = 1 if L.txm_resample_path(N, C, nrep, order) == 1 else 0
+            # replicate slabs: every slab is an ordinary call on its rows of the sampler with the whole call's kernel as its path
             ym = torch.empty((nrep, C), dtype=F64, device="cuda") if y is not None else None
             for a in range(0, nrep, slab):
                 b = min(nrep, a + slab)
-                r = resample_vals(x, u, order, sampler=sampler.rows(a, b), w=w, pivot=pivot, out=out[a:b], path=path, prep=prep,
-                                  info=info, y=y, prep_src=prep_src if prep_src is not None else (x, u, w, pivot, y), _slab=fam)
+                r = resample_vals(x, u, order, sampler=sampler.rows(a, b), w=w, pivot=pivot, out=out[a:b], prep=prep,
+                                  info=info, y=y, prep_src=prep_src if prep_src is not None else (x, u, w, pivot, y),
+                                  _slab=kern & 0xFF)
                 if y is not None:
                     ym[a:b] = r[1] if y.dim() > 1 else r[1][:, None]
             res = out[:, 0] if squeeze else out
             return (res, (ym[:, 0] if y.dim() == 1 else ym)) if y is not None else res
-    if _slab is not None:
-        opts.path = _slab if opts.path == -1 else opts.path
     ymean = y2 = None
     if y is not None:
         _check_f64_cuda(y, "y")
@@ -496,13 +518,13 @@ def resample_vals(
         opts.y, opts.ldy_s, opts.out_y = y2.data_ptr(), max(y2.stride(0) if N > 1 else C, C), ymean.data_ptr()
     key = None
     if prep is not None and freq is None:
-        takes_i8 = (opts.path in (1, 2, 3) and L.txm_resample_i8_supported(N, C, nrep, order) == 1) or (
-            opts.path == -1 and L.txm_resample_path(N, C, nrep, order) == 1)
-        if takes_i8:
-            # (the path is part of the key: whether a second matrix's tables sit in the block depends on the kernel that carries it)
-            # nrep is NOT part of it: pivot, window table, guard flags and fallback list do not depend on the replicate count,
-            # so the replicate slabs of one call (and calls with other counts) share the block
-            key = (src_key, N, C, order, opts.path)
+        if (kern & 0xFF) != _PATHS["fp64"]:
+            # the block holds pivot, window table, guard flags and fallback list of the caller's tensors -- and the second
+            # matrix's tables exactly when the call's kernel carries y (txm_resample_kernel's WITH_Y bit; narrow tail groups
+            # follow it too).  So the key is the kernel word, not nrep and not the path the caller asked for: the replicate
+            # slabs of one call share the block, a call with another count shares it when the rule gives it the same kernel,
+            # and gets a block of its own when it does not (order 4 with y: fused below two replicate groups, table above)
+            key = (src_key, N, C, order, kern)
             kept = prep.lookup(key)
             if kept is not None:  # same caller tensors, unedited: the operands of the call that filled the block
                 x2, u, w, pivot, y2 = kept
