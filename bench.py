@@ -62,7 +62,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-fp64-leg", action="store_true", help="skip timing the same shape with the FP64 kernel")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU baseline duration")
-    p.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0: min(cores, 16), the 1-GPU box share)")
+    p.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0: min(host cores, N_obs) -- the reference threads over observables only)")
     p.add_argument("--dry-run", action="store_true",
                    help="no GPU: ranks rendezvous over gloo and run the sharded step with a stand-in compute (tests the launcher)")
     return p.parse_args()
@@ -252,16 +252,14 @@ def csrc_sha():
     return f()
 
 
-def pmc_traffic(kernel_prefix, shape):
-    """HBM bytes per launch from the newest committed PMC summary of this workload (separate rocprofv3
-    --pmc passes of this same command, tools/collect_profiles.py) and the file it came from; (None, reason)
-    if no committed profile matches this run's shape AND the kernel sources it was measured on (`csrc_sha` in the
-    summary against the sources of this checkout: a PMC figure for other code is not reported).  NOT measured in this run."""
+def _traffic_files(shape):
+    """(dict, file name) of every committed PMC summary of this workload shape measured on THIS checkout's kernel sources,
+    newest first; and the reason when one exists for other sources only."""
     import glob
 
     sha = csrc_sha()
     stale = None
-
+    hits = []
     for f in sorted(glob.glob(str(ROOT / "profiles" / "*_traffic.json")), reverse=True):
         try:
             d = json.loads(Path(f).read_text())
@@ -274,13 +272,65 @@ def pmc_traffic(kernel_prefix, shape):
         if d.get("csrc_sha") != sha:
             stale = stale or f"profiles/{Path(f).name} was measured on other kernel sources (csrc_sha {d.get('csrc_sha')} != {sha})"
             continue
+        hits.append((d, f"profiles/{Path(f).name} (csrc_sha {sha})"))
+    return hits, stale
+
+
+def pmc_traffic(kernel_prefix, shape):
+    """HBM bytes per launch of ONE kernel from the newest committed PMC summary of this workload (separate rocprofv3
+    --pmc passes of this same command, tools/collect_profiles.py) and the file it came from; (None, reason)
+    if no committed profile matches this run's shape AND the kernel sources it was measured on (`csrc_sha` in the
+    summary against the sources of this checkout: a PMC figure for other code is not reported).  NOT measured in this run."""
+    hits, stale = _traffic_files(shape)
+    for d, src in hits:
         # several instantiations can share the prefix (e.g. the FP64 kernel's empty listed-mode launches): the
         # one that moved the most bytes is the kernel of this workload
-        hits = [v.get("hbm_bytes_per_launch") for k, v in d.get("kernels", {}).items() if k.startswith(kernel_prefix)]
-        hits = [h for h in hits if h is not None]
-        if hits:
-            return max(hits), f"profiles/{Path(f).name} (csrc_sha {sha})"
+        vals = [v.get("hbm_bytes_per_launch") for k, v in d.get("kernels", {}).items() if k.startswith(kernel_prefix)]
+        vals = [h for h in vals if h is not None]
+        if vals:
+            return max(vals), src
     return None, stale
+
+
+# the kernels ONE txm_resample_vals call on the int8 path launches, by name prefix (txm_resample.hip: resample_vals_impl):
+# the contraction kernel(s) of the path, the guard's FP64 kernel in listed mode (template mode 1: empty on ordinary data),
+# the finalize kernels, the info word; the count-table generator on the table path; the pre-pass when the caller's block
+# is not reused.  Every one of them runs once per 32-column group except the generator, the pivot and the info kernel.
+_CALL_KERNELS = {
+    "int8_table": ("txm::count_table_kernel", "txm::resample_i8g_kernel", "txm::resample_i8t_kernel"),
+    "int8_fused": ("txm::resample_i8t_kernel",),
+}
+_CALL_COMMON = ("txm::resample_finalize_i8_kernel", "txm::resample_finalize_y_kernel", "txm::i8_info_kernel")
+_CALL_PREPASS = ("txm::pivot_kernel", "txm::i8_stats_kernel", "txm::i8_table_kernel", "txm::i8_list_kernel")
+_ONCE_PER_CALL = ("txm::count_table_kernel", "txm::i8_info_kernel", "txm::pivot_kernel")
+
+
+def call_traffic(kernels: dict, int8_kernel: str, n_obs: int, prepass: bool = False):
+    """HBM bytes ONE bootstrap call moves, from a traffic summary's per-kernel per-launch figures: the SUM over the
+    kernels of the call (round-5 verdict: the bench line carried one launch's 132 GB where the call moves 370).
+    -> (total, {kernel: bytes per call})."""
+    groups = -(-int(n_obs) // 32)
+    names = _CALL_KERNELS[int8_kernel] + _CALL_COMMON + (_CALL_PREPASS if prepass else ())
+    per = {}
+    for k, v in kernels.items():
+        b = v.get("hbm_bytes_per_launch")
+        if b is None:
+            continue
+        listed = k.startswith("txm::resample_kernel<") and k.rstrip(">").split(",")[-2].strip() == "1"  # RS_LISTED
+        if not (listed or any(k.startswith(n) for n in names)):
+            continue
+        per[k] = b * (1 if any(k.startswith(n) for n in _ONCE_PER_CALL) else groups)
+    return sum(per.values()), per
+
+
+def pmc_call_traffic(shape, int8_kernel, prepass=False):
+    hits, stale = _traffic_files(shape)
+    for d, src in hits:
+        total, per = call_traffic(d.get("kernels", {}), int8_kernel, shape[1], prepass)
+        main_kernel = "txm::resample_i8g_kernel" if int8_kernel == "int8_table" else "txm::resample_i8t_kernel"
+        if any(k.startswith(main_kernel) for k in per):   # (a summary of this shape that saw the call's contraction kernel)
+            return total, per, src
+    return None, None, stale
 
 
 def main():
@@ -398,6 +448,7 @@ def main():
         step(args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
+    dt_local = dt
     recording["on"] = False
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
@@ -538,12 +589,21 @@ def main():
                            "contraction_frac_of_int8_peak": i8_ops / (t_con * 1e-3) / 1e12 / INT8_PEAK_TOPS,
                            "how": "generator timed alone with HIP events after the timed region; contraction = the call minus it "
                                   "(finalize and memsets included); profiles/*_kernel_stats.csv has the rocprofv3 per-kernel durations"}
-        tr, src = pmc_traffic(kname, shape)
+        # HBM bytes of the timed CALL: the sum over its kernels (generator + every contraction pass + finalize ...), not one launch
+        tr, tr_kernels, src = pmc_call_traffic(shape, info.get("kernel") or "int8_fused", prepass=not info.get("prep_reused"))
         roofline = {
             "kernel": f"{kname} ({kdesc}) + pre-pass (unless reused) and finalize kernels",
             "bound": "mfma-i8", "pipe": "int8",
             "achieved": tops, "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": tops / INT8_PEAK_TOPS,
             "traffic": tr, "traffic_source": src,
+            "traffic_ratio": (tr / alg_bytes) if tr else None,
+            "hbm_executed_GBs": (tr / (t_boot * 1e-3) / 1e9) if tr else None,
+            "hbm_executed_frac": (tr / (t_boot * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None,
+            "kernels": tr_kernels,
+            "traffic_note": "traffic = HBM bytes of ONE timed bootstrap call = the sum over the kernels it launches (count-table "
+                            "generator, every contraction pass, finalize, info; the pre-pass when not reused) of the per-launch "
+                            "FETCH_SIZE x2 + WRITE_SIZE figures of the committed rocprofv3 --pmc summary; kernels = the addends; "
+                            "traffic_ratio = traffic / algorithmic_bytes",
             "ms": t_boot, "measured": live,
             "executed_int8_ops": i8_ops,
             "algorithmic_flops": alg_flops, "algorithmic_bytes": alg_bytes,
@@ -578,6 +638,15 @@ def main():
     }
 
     ranks_seen = ranks_identity(torch, dist, world)
+    # what every rank ran (the first SCALE record can be held against DESIGN 6's prediction rank by rank): its replicate slab
+    # of the stream, the kernel the dispatch rule gave it, its own bootstrap-call and step times
+    mine = {"rank": rank, "rep0": (txd.shard_range(nrep, rank, world).start if replicas else rank * nrep), "nrep": nrep_rank,
+            "kernel": info.get("kernel") or path, "bootstrap_call_ms": round(t_boot, 3), "sampler_ms": round(ph[0], 3),
+            "step_ms_local": round(1e3 * dt_local / args.steps, 3)}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     if rank == 0:
         par = f"replicate-slabs x{world} (nrep/{world} per GPU, same state point)" if replicas else f"state-points x{world}"
@@ -605,6 +674,7 @@ def main():
             },
             "replicate_samples_per_s": value * nrep,
             "ranks_seen": ranks_seen,
+            "per_rank": per_rank,
             "sampler_ms": t_samp,
             "roofline": roofline,
             "roofline_reduce": roofline_reduce,
@@ -615,7 +685,9 @@ def main():
             rec["parity_check"] = parity
         rec["step_breakdown_ms"] = step_breakdown
         if world == 1 and not args.no_cpu_baseline:
-            nthr = args.cpu_threads or min(os.cpu_count() or 1, 16)
+            # the reference's parallelism is over observables only (cmomy's numba threads span broadcast dims, never the sample
+            # axis: SURVEY 8(d)) -- effective cores = min(N_obs, host cores)
+            nthr = args.cpu_threads or min(os.cpu_count() or 1, C)
             rec["cpu_baseline"] = cpu_baseline(C, order, nrep, args.cpu_seconds, nthr)
             rec["cpu_baseline"]["host_cores"] = os.cpu_count()   # `cores` = the threads the baseline ran on
         rec["host_cores"] = os.cpu_count()

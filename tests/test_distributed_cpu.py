@@ -130,6 +130,18 @@ WORKER = textwrap.dedent(
     want = sums_fn(xx, uu, Kk - 1, seen["piv"], None)
     assert torch.allclose(tot, want, rtol=1e-12, atol=1e-9)
     ref_t = tot.clone(); dist.broadcast(ref_t, src=0); assert torch.equal(tot, ref_t)  # identical on every rank
+    # an EMPTY shard (round-5 advice: a rank without samples failed locally and left the others in the broadcast): rank 0 holds
+    # nothing, rank 1 everything -- the first non-empty rank estimates the pivot, the empty one adds zero sums, same state everywhere
+    mine = slice(0, 0) if rank == 0 else slice(0, 1001)
+    tot2 = D.sharded_reduce(xx[mine], uu[mine], Kk - 1, ops=(piv_fn, sums_fn, fin_fn))
+    assert torch.equal(seen["piv"], piv_fn(xx, uu)) and torch.equal(seen["stack"][0], torch.zeros(2, 2, Kk, dtype=torch.float64))
+    assert torch.allclose(tot2, sums_fn(xx, uu, Kk - 1, seen["piv"], None), rtol=1e-12, atol=1e-9)
+    ref_t = tot2.clone(); dist.broadcast(ref_t, src=0); assert torch.equal(tot2, ref_t)
+    try:
+        D.sharded_reduce(xx[:0], uu[:0], Kk - 1, ops=(piv_fn, sums_fn, fin_fn))
+        raise SystemExit("sharded_reduce accepted all-empty shards")
+    except ValueError as e:
+        assert "empty" in str(e)
     # input_GP_from_states(sharded=...): every raise is decided from gathered words, on EVERY rank -- a world larger than the
     # number of states, an empty local list or ineligible states on one rank must fail everywhere, not leave the other ranks
     # blocked in the all-gather (round-4 advice).  (No compute is reached: the checks come first.)

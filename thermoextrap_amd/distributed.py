@@ -112,10 +112,25 @@ def sharded_reduce(x: torch.Tensor, u: torch.Tensor, order: int, w: torch.Tensor
 
     pivot_fn, sums_fn, finish_fn = ops if ops is not None else (
         engine.reduce_pivot, lambda x_, u_, o_, p_, w_: engine.reduce_sums(x_, u_, o_, p_, w=w_), engine.sums_to_state)
-    piv = pivot_fn(x, u)                      # every rank estimates (same launch shape); rank 0's is the one used
-    piv = broadcast_tensor(piv, 0, group)
-    sums = sums_fn(x, u, order, piv, w)
-    stack = all_gather_slabs(sums.unsqueeze(0), None if world()[1] == 1 else [1] * world()[1], group)
+    # shard sizes first: a rank with an EMPTY shard (more ranks than samples, an uneven loader) must neither fail locally
+    # on the library's N >= 1 -- the other ranks would then block in the broadcast below until the timeout -- nor supply
+    # the pivot.  Every decision below is made from the gathered sizes, i.e. identically on every rank.
+    sizes = all_gather_ints(int(x.shape[0]), group)
+    if not any(sizes):
+        raise ValueError("sharded_reduce: every rank's shard is empty")
+    src = next(r for r, n in enumerate(sizes) if n > 0)     # the first rank that holds samples estimates the pivot
+    rank, nw = world()
+    C = 1 if x.dim() == 1 else int(x.shape[1])
+    if sizes[rank] > 0:
+        piv = pivot_fn(x, u) if rank == src else torch.empty(1 + C, dtype=torch.float64, device=x.device)
+    else:
+        piv = torch.empty(1 + C, dtype=torch.float64, device=x.device)
+    piv = broadcast_tensor(piv, src, group)
+    if sizes[rank] > 0:
+        sums = sums_fn(x, u, order, piv, w)
+    else:                                                   # an empty shard adds nothing: zero sums of the common shape
+        sums = torch.zeros((C, 2, order + 1), dtype=torch.float64, device=x.device)
+    stack = all_gather_slabs(sums.unsqueeze(0), None if nw == 1 else [1] * nw, group)
     return finish_fn(stack, piv)
 
 
