@@ -86,6 +86,9 @@ def truth_err(orc, got, x, u, order, freq, reps, w=None, sc=None):
     (40000, 16, 4, 70, False),      # 8 < C <= 16: two powers per observable column, three row sets
     (30000, 12, 5, 64, True),       # ... order 5, weighted
     (30000, 9, 7, 65, False),       # ... order 7: four row sets
+    (50000, 4, 3, 100, False),      # narrow states, a last replicate group of 33 .. 63 live replicates (config 5's 100 = 64 + 36)
+    (30000, 8, 4, 45, True),
+    (60001, 12, 2, 127, False),     # ... 63 live, slid last tile
 ])
 def test_i8_matches_fp64_on_same_stream(eng, orc, N, C, order, nrep, weighted):
     x, u = data(N, C, 5)

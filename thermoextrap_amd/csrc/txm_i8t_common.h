@@ -35,6 +35,11 @@ constexpr int T_XD = TXM_T_XD;  // k-steps between the request of an x chunk and
 // ... of the narrow-state variant: its k-steps are short (a few MFMAs per wave), so the same memory latency is more
 // k-steps (measured at BASELINE config 2: depth 2 left the k-steps waiting for x -- 850 cycles each for 3 MFMAs)
 constexpr int T_XDN = TXM_T_XDN;
+#ifndef TXM_T_XDN1
+#define TXM_T_XDN1 4
+#endif
+constexpr int T_XDN1 = TXM_T_XDN1;  // ... of one-quad states (C <= 4)
+static_assert(T_XDN1 == 1 || T_XDN1 == 2 || T_XDN1 == 4 || T_XDN1 == 8, "ring depth");
 static_assert((T_XD == 1 || T_XD == 2 || T_XD == 4 || T_XD == 8) && (T_XDN == 1 || T_XDN == 2 || T_XDN == 4 || T_XDN == 8), "ring depth");
 // 1.5 * 2^52 + 0x80 in each of the six low mantissa bytes (the digits come out biased by 128; byte 6 holds
 // 0x38 + digit 6, taken out at flush time as 56 * draws; byte 7 is the sign/exponent byte: the dead slot)
@@ -85,6 +90,19 @@ __device__ __forceinline__ void t_fill_call(uint32_t *cntw, uint32_t k0, uint32_
     // shared mask into shift, and, and per field
     uint32_t lo2 = word & 0x00300C03u;
     asm volatile("" : "+v"(lo2));
+#ifdef TXM_FILL_BYTE_TILE  // (timing stand-in, round 6: a byte-per-(sample, replicate) tile [sample][64 replicates] -- the increment is
+    // a per-lane constant, the address one bfe + one lshl_add: 2 instead of 4 vector instructions per draw.  Four replicates share
+    // a count word, so the 32 lanes of a DS pass hit 8 + 8 banks instead of 32: what the ds_add costs then is what this measures)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      uint32_t fld = __builtin_amdgcn_ubfe(word, 10 * k, 10);
+      asm volatile("" : "+v"(fld));
+      uint32_t incb = 1u << ((lane4 & 12u) << 1);
+      if (!ALL_VALID) incb = (first + (uint32_t)(wi * 3 + k) < n) ? incb : 0u;
+      atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(cntw) + (fld << 6) + ((lane4 >> 2) & ~3u)), incb);
+    }
+    continue;
+#endif
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       uint32_t q = __builtin_amdgcn_ubfe(word, 10 * k + 2, 8);  // field >> 2: the count word of the sample

@@ -42,20 +42,26 @@ namespace txm {
 // ds_read2_b64 pair and not a multiple of 64 lines (ds_read2st64_b64 would pair them again): two ds_read_b64 (2 LDS
 // cycles each) instead of one paired read (8).  Same-box A/B, round 4: 36.4 -> 35.8 ms at N = 2e7, 165.8 -> 163.2 ms at
 // the north star (-1.6 %); TXM_T_PAIRREAD restores the adjacent layout.
-// (PU = the unit stride in lines: 513, or 545 where a tile stages 33 chunks -- chunk groups, see the kernel)
+// (PU = the unit stride in lines: 513, or 545 / 577 where a tile stages 33 / 35 chunks -- chunk groups, see the kernel)
 #ifndef TXM_T_PAIRREAD
 #define T_PIDX(e) (((((e) >> 4) & 1) * T_PUNIT) + (((e) >> 5) * 16) + ((e) & 15))
-#define T_PUNIT_OF(cg) ((cg) > 1 ? 545 : 513)
-#define T_PLINES_OF(cg) (T_PUNIT_OF(cg) + ((cg) > 1 ? 33 : 32) * 16)
+#define T_PUNIT_OF(cg) ((cg) > 2 ? 577 : (cg) > 1 ? 545 : 513)
+#define T_PLINES_OF(cg) (T_PUNIT_OF(cg) + (31 + (cg)) * 16)
 #else
 #define T_PIDX(e) (e)
 #define T_PUNIT_OF(cg) 16
-#define T_PLINES_OF(cg) ((cg) > 1 ? SM_T + 32 : SM_T)
+#define T_PLINES_OF(cg) (SM_T + 32 * ((cg) - 1))
 #endif
 // chunk groups of a launch: 2 for one-quad states, for two-quad states with at most six powers and for four-quad states with at
 // most four (see the kernel; beyond that the row sets of a wave and the staged tiles of 33 chunks do not fit the LDS -- with four
-// quads a wave of a group holds every power of its quad), else 1
-#define T_CG_OF(nq, jn) (((nq) == 1 || ((nq) == 2 && (jn) <= 6) || ((nq) == 4 && (jn) <= 4)) ? 2 : 1)
+// quads a wave of a group holds every power of its quad), else 1.  One-quad states with at most four powers (orders 1-3; BASELINE
+// config 5's states): FOUR groups of two waves (round 6) -- a wave then holds two row sets and walks 8 k-steps per tile instead of
+// one row set over 16: the same work per wave in half as many latency chains, each with two independent row sets in flight
+// (five and more powers need four u-row waves per group, and from seven on the staged tiles do not fit next to the regions)
+#ifndef TXM_T_CG1
+#define TXM_T_CG1 4
+#endif
+#define T_CG_OF(nq, jn) (((nq) == 1 && (jn) <= 4) ? TXM_T_CG1 : ((nq) == 1 || ((nq) == 2 && (jn) <= 6) || ((nq) == 4 && (jn) <= 4)) ? 2 : 1)
 
 // K = order + 1 is a run-time argument (it only enters the flush addresses); one launch slices the JN powers
 // J0 .. J0 + JN - 1.
@@ -110,6 +116,8 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   constexpr int CG = T_CG_OF(NQ, JN);
   constexpr int T_PUNIT = T_PUNIT_OF(CG);
   constexpr int STEPS = T_STEPS / CG;            // k-steps (chunks) of a wave per tile
+  constexpr int WPG = T_WAVES / CG;              // waves of a chunk group
+  static_assert(CG == 1 || CG == 2 || CG == 4, "chunk groups");
   constexpr int GS = 8 / NQ / CG;             // waves per column quad and chunk group = stride of a wave's powers
   constexpr int NSW = (JN + GS - 1) / GS;     // power row sets per wave
   static_assert(JN >= 1 && NSW + (YS ? 1 : 0) <= 5 && J0 + JN <= 8, "power range");
@@ -421,7 +429,8 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     bool first_tile = true;
     uint32_t *cnt_cur = cnt_a, *cnt_nxt = cnt_b;
-    constexpr int XD = NQ == 8 ? T_XD : T_XDN, UNR = XD > 4 ? XD : 4;
+    // (one-quad states: depth 4 -- config 5's batched launch 6.76 -> 6.57 ms, same box, gpurun_out/r6_exp1.log; two quads: 8 and 4 tie)
+    constexpr int XD = NQ == 8 ? T_XD : NQ == 1 ? T_XDN1 : T_XDN, UNR = XD > 4 ? XD : 4;
     XIn XR[XD];  // the wave's columns of a chunk, requested XD k-steps ahead: chunk c lives in slot c % XD
     // The rows of the next chunk to request, as RUNNING wave-uniform pointers: chunks follow each other in memory inside a
     // tile and from tile to tile (all but the slid last tile of the series), so a request is two scalar adds -- the row
@@ -494,11 +503,14 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       // entries 992 .. 1023 = the next tile's first chunk
       // (chunk groups: entries 1024 .. 1055 = the next tile's chunk 16, which the second group slices at its last k-step)
       constexpr int NSTG = CG > 1 ? 3 : 2;
+      static_assert(SM_T + 32 * (CG - 1) <= NSTG * T_BLOCK, "staging rounds");
       double su[NSTG], sw[NSTG];
 #pragma unroll
       for (int q = 0; q < NSTG; ++q) {
         const int e = (int)threadIdx.x + q * T_BLOCK;
-        const int64_t i = e < SM_T - 32 ? wbase + 32 + e : e < SM_T ? wnext + (e - (SM_T - 32)) : wnext + SM_T / 2 + ((e - SM_T) & 31);
+        // (entries past 1024: the next tile's first chunk of chunk group 1, 2, ... -- chunk STEPS, 2 STEPS, ... of that tile)
+        const int64_t i = e < SM_T - 32 ? wbase + 32 + e : e < SM_T ? wnext + (e - (SM_T - 32))
+                                                         : wnext + 32 * STEPS * (1 + (((e - SM_T) >> 5) % (CG > 1 ? CG - 1 : 1))) + ((e - SM_T) & 31);
         su[q] = a.u[i];
         sw[q] = 1.0;
         if constexpr (WEIGHTED) sw[q] = a.w[i];
@@ -600,7 +612,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
       for (int q = 0; q < NSTG; ++q) {
         const int e = (int)threadIdx.x + q * T_BLOCK;
-        if (q == 2 && e >= SM_T + 32) continue;  // (only 32 entries of the third round exist)
+        if (q == 2 && e >= SM_T + 32 * (CG - 1)) continue;  // (only 32 entries per further chunk group exist in the third round)
         const double du = (su[q] - pu) * inv_du;
         double pw = WEIGHTED ? sw[q] * inv_w : 1.0;
         if constexpr (NPT > JN) ptile[T_PIDX(e) * NPT + JN] = pw;  // plain w for the y row set
@@ -636,7 +648,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
           } else step_q();
           // entry of the sliced chunk in the staged tiles: the next chunk of the tile, or -- last k-step -- the next tile's
           // first chunk of the group (entries 992 .. for chunk 0, 1024 .. for chunk 16)
-          const int e0 = (CG > 1 && sq == STEPS - 1) ? (cgrp ? SM_T : SM_T - 32) : (coff + sq) * 32;
+          const int e0 = (CG > 1 && sq == STEPS - 1) ? (cgrp ? SM_T + 32 * (cgrp - 1) : SM_T - 32) : (coff + sq) * 32;
           kstep(YES, YES, coff + sq, cur_x, e0, no_d, no_w);
           T_TICK(5);
         }
@@ -657,31 +669,34 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       // chunk groups: the second group hands its int32 accumulators to the first through the (now idle) count tile, four tiles
       // per wave and round; the sums are exact, so what is flushed is what one group contracting all 32 chunks would have flushed
       constexpr int NT = 2 * NS + 1;  // tiles of a wave: NS row sets x 2 replicate halves + the u-row tile
-      uint32_t *xch = cntw + (size_t)((wave & 3) * 4) * 16 * 64 + lane;
+      uint32_t *xch = cntw + (size_t)((wave % WPG) * 4) * 16 * 64 + lane;
       auto tile_of = [&](int tt) -> v16i & { return tt < 2 * NS ? acc[tt >> 1][tt & 1] : accu; };
+#pragma unroll 1
+      for (int src = 1; src < CG; ++src) {  // group src -> group 0, wave for wave (same quad, same powers)
 #pragma unroll
-      for (int t0 = 0; t0 < NT; t0 += 4) {
-        if (cgrp == 1) {
+        for (int t0 = 0; t0 < NT; t0 += 4) {
+          if (cgrp == src) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (t0 + k < NT) {
-              v16i &T = tile_of(t0 + k);
+            for (int k = 0; k < 4; ++k)
+              if (t0 + k < NT) {
+                v16i &T = tile_of(t0 + k);
 #pragma unroll
-              for (int r = 0; r < 16; ++r) xch[(k * 16 + r) * 64] = (uint32_t)T[r];
-              T = (v16i)(0);
-            }
+                for (int r = 0; r < 16; ++r) xch[(k * 16 + r) * 64] = (uint32_t)T[r];
+                T = (v16i)(0);
+              }
+          }
+          __syncthreads();
+          if (cgrp == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (t0 + k < NT) {
+                v16i &T = tile_of(t0 + k);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) T[r] += (int)xch[(k * 16 + r) * 64];
+              }
+          }
+          if (t0 + 4 < NT || src + 1 < CG) __syncthreads();  // (the next round overwrites the slots)
         }
-        __syncthreads();
-        if (cgrp == 0) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (t0 + k < NT) {
-              v16i &T = tile_of(t0 + k);
-#pragma unroll
-              for (int r = 0; r < 16; ++r) T[r] += (int)xch[(k * 16 + r) * 64];
-            }
-        }
-        if (t0 + 4 < NT) __syncthreads();  // (the next round overwrites the slots)
       }
     }
     if (CG == 1 || cgrp == 0) {  // wave-uniform
