@@ -329,6 +329,18 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     *(lds_u32)(lds + base + off + 256 + T_PLANE + 128) = hi1;
     return;
 #endif
+#ifdef TXM_G_PLAIN_STORES_ASM  // (experiment, round 6: the SAME two paired stores the compiler makes of TXM_G_PLAIN_STORES, but inside an
+    // asm it cannot count -- the two builds differ only in how strict the s_waitcnt lgkmcnt values behind them are)
+    {
+      const uint32_t base = wreg + g_lane_now() * 4u + (uint32_t)off;
+      asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:0 offset1:1\n\t"
+                   "ds_write2st64_b32 %3, %4, %5 offset0:0 offset1:1"
+                   :
+                   : "v"(base), "v"(lo0), "v"(lo1), "v"(base + (uint32_t)(T_PLANE + 128)), "v"(hi0), "v"(hi1)
+                   : "memory");
+      return;
+    }
+#endif
     asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\t"
                  "ds_write_addtid_b32 %0 offset:%5\n\t"
                  "ds_write_addtid_b32 %1 offset:%6\n\t"
