@@ -279,6 +279,9 @@ int txm_resample_path(int64_t N, int64_t C, int64_t nrep, int order);
  * the other side of a replicate-count threshold of the rule. */
 #define TXM_KERNEL_WITH_Y 0x100
 int txm_resample_kernel(int64_t N, int64_t C, int64_t nrep, int order, int path, int has_y, int aligned);
+/* `aligned` for a pair of operands as txm_resample_vals would see them (device or host pointer values: only the address bits and
+ * the row pitches are looked at; y may be NULL): 1 when the count-table kernel can take them */
+int txm_resample_operands_aligned(const double *x, int64_t ldx_s, int64_t C, const double *y, int64_t ldy_s);
 int txm_set_resample_path(int path);
 int txm_resample_vals_info(const void *ws, int64_t N, int64_t C, int64_t nrep, int order,
                            int64_t *info_host, txm_stream stream);

@@ -254,6 +254,17 @@ def test_kernel_word_is_what_a_prep_block_is_keyed_on(lib):
     assert Kn(N, 8, 1000, 3, -1, 1, 1) == FUSED and Kn(N, 8, 1000, 3, TABLE, 0, 1) == FUSED
     assert Kn(N, 32, 16, 4, -1, 0, 1) == FP64 and Kn(N, 32, 1000, 4, FP64, 1, 1) == FP64 and Kn(N, 32, 1000, 8, -1, 0, 1) == FP64
     assert Kn(0, 32, 1000, 4, -1, 0, 1) == FP64
+    # `aligned` as the library itself judges a pair of operands (address bits and row pitches only: no device needed)
+    import ctypes as ct
+
+    Al = lib.txm_resample_operands_aligned
+    p = lambda a: ct.c_void_p(a)  # noqa: E731
+    assert Al(p(256), 32, 32, None, 0) == 1 and Al(p(256), 40, 34, p(4096), 36) == 1
+    assert Al(p(264), 32, 32, None, 0) == 0          # x not 16-byte aligned
+    assert Al(p(256), 33, 32, None, 0) == 0          # odd row pitch
+    assert Al(p(256), 34, 34, None, 0) == 0          # 34 columns round up to 36: no room for the last quad in a 34-double row
+    assert Al(p(256), 32, 32, p(520), 32) == 0 and Al(p(256), 32, 32, p(512), 31) == 0   # the second matrix likewise
+    assert Al(None, 32, 32, None, 0) == 0
     # consistent with the workspace query: a call whose kernel word says TABLE is sized with the table
     W = lib.txm_resample_vals_ws_bytes_opts
     for nrep in (64, 128, 129, 200, 1000):

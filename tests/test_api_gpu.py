@@ -611,6 +611,33 @@ def test_from_sympy_equals_factory_derivatives_on_device(xtrap, legacy, kw):
                                    rtol=1e-10)
 
 
+def test_state_collection_with_plain_callable_derivatives(xtrap, legacy):
+    """A collection whose models carry user callables (Derivatives(funcs)) keeps the reference's per-state loop (models.py:614-671) --
+    resample, map_concat("derivs") and predict through the same API -- and agrees with the table-evaluated built-in model."""
+    fx = FixtureData(xtrap, legacy, order=2)
+
+    class Funcs:  # <x>'s first two beta derivatives on central moments, by hand (beta.py:52-54, 110-116)
+        def __getitem__(self, i):
+            return [lambda x1, du, dxdu: x1, lambda x1, du, dxdu: -dxdu[1], lambda x1, du, dxdu: dxdu[2]][i]
+
+    mine = xtrap.models.Derivatives(Funcs())
+    ref_d = xtrap.beta.factory_derivatives(central=True)
+    datas = [xtrap.DataCentralMomentsVals.from_vals(xv=fx.x, uv=fx.u, order=2, central=True),
+             xtrap.DataCentralMomentsVals.from_vals(xv=fx.xb, uv=fx.ub, order=2, central=True)]
+    coll = xtrap.StateCollection([xtrap.ExtrapModel(b, d, mine, order=2) for b, d in zip((0.5, 0.6), datas)])
+    ref = xtrap.StateCollection([xtrap.ExtrapModel(b, d, ref_d, order=2) for b, d in zip((0.5, 0.6), datas)])
+    assert coll._batch_eligible() is None and ref._batch_eligible() is not None
+    np.testing.assert_allclose(coll.map_concat("derivs").transpose(*ref.map_concat("derivs").dims).values,
+                               ref.map_concat("derivs").values, rtol=1e-12)
+    spec = {"nrep": 8, "seed": 3, "device": True}
+    a, b = coll.resample(spec), ref.resample(spec, batched=False)
+    for sa, sb in zip(a, b):
+        da, db = sa.derivs(), sb.derivs()
+        np.testing.assert_allclose(da.transpose(*db.dims).values, db.values, rtol=1e-12)
+        np.testing.assert_allclose(sa.predict([0.45, 0.55]).transpose(*sb.predict([0.45, 0.55]).dims).values,
+                                   sb.predict([0.45, 0.55]).values, rtol=1e-12)
+
+
 def test_notebook_data_organization(xtrap, kat, idealgas_data, post_data_rng):
     """Data_Organization.ipynb cells 10-52 through the class API."""
     from conftest import rel_close

@@ -85,6 +85,7 @@ SIGNATURES = {
     "txm_sampler_count_table": (c_int, [ct.POINTER(SamplerSpec), c_void_p, c_i64, c_i64, c_void_p, c_void_p]),
     "txm_resample_path": (c_int, [c_i64, c_i64, c_i64, c_int]),
     "txm_resample_kernel": (c_int, [c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int]),
+    "txm_resample_operands_aligned": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64]),
     "txm_set_resample_path": (c_int, [c_int]),
     "txm_resample_vals_info": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_int, ct.POINTER(c_i64), c_void_p]),
     "txm_resample_prep_bytes": (c_size, [c_i64, c_i64, c_i64, c_int]),

@@ -978,6 +978,13 @@ extern "C" int txm_resample_kernel(int64_t N, int64_t C, int64_t nrep, int order
   return (table ? TXM_PATH_INT8_TABLE : TXM_PATH_INT8_FUSED) | (with_y ? TXM_KERNEL_WITH_Y : 0);
 }
 
+// the `aligned` argument of txm_resample_kernel for a given pair of operands (y may be NULL): what the count-table kernel's
+// LDS-DMA asks of them -- ONE statement of it, the one the call itself applies (i8g_applicable)
+extern "C" int txm_resample_operands_aligned(const double *x, int64_t ldx_s, int64_t C, const double *y, int64_t ldy_s) {
+  if (x == nullptr || C < 1) return 0;
+  return i8g_applicable(x, ldx_s, C > 16 ? C : 17, y, ldy_s) ? 1 : 0;  // (alignment only: narrow states are txm_resample_kernel's business)
+}
+
 extern "C" size_t txm_resample_prep_bytes(int64_t N, int64_t C, int64_t nrep, int order) {
   if (N < 1 || C < 1 || nrep < 1 || order < 0 || order > TXM_MAX_ORDER) return 0;
   if (!i8_supported(N, C, nrep, order + 1)) return 256;

@@ -390,21 +390,18 @@ def _call_path(path) -> int:
 
 
 def _table_operands_ok(x2: torch.Tensor, ls: int, C: int, y: torch.Tensor | None) -> bool:
-    """The count-table kernel's operand requirement (txm_resample_kernel's `aligned`): 16-byte aligned, even row pitch
-    that holds C rounded up to 4 columns -- for x and for a second matrix."""
-    cq = (C + 3) // 4 * 4
-
-    def ok(t, pitch):
-        return t.data_ptr() % 16 == 0 and pitch % 2 == 0 and cq <= pitch
-
-    if not ok(x2, ls):
-        return False
+    """txm_resample_kernel's `aligned` for the operands a call will hand the library (the library's own statement of what the
+    count-table kernel's DMA needs: txm_resample_operands_aligned).  A second matrix that resample_vals will have to copy
+    (not row-major with unit column stride) is judged as the contiguous copy it becomes: pitch C, torch's 256-byte alignment."""
+    L = _L()
+    yp, ldy = None, 0
     if y is not None:
         y2 = y.unsqueeze(1) if y.dim() == 1 else y
         if y2.dim() != 2 or y2.stride(1) != 1 or (y2.shape[0] > 1 and y2.stride(0) < C):
-            return C % 2 == 0 and cq <= C      # copied contiguous below: pitch C, torch allocations are 256-byte aligned
-        return ok(y2, max(y2.stride(0) if y2.shape[0] > 1 else C, C))
-    return True
+            yp, ldy = ct.c_void_p(256), C          # (an address with torch's allocation alignment stands in for the copy's)
+        else:
+            yp, ldy = ct.c_void_p(y2.data_ptr()), max(y2.stride(0) if y2.shape[0] > 1 else C, C)
+    return L.txm_resample_operands_aligned(ct.c_void_p(x2.data_ptr()), ls, C, yp, ldy) == 1
 
 
 def resample_vals(

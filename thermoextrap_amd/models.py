@@ -553,6 +553,8 @@ class StateCollection(_Params):
             d = getattr(st, "data", None)
             if not isinstance(st, ExtrapModel) or type(d) is not DataCentralMomentsVals or type(d.meta) is not DataCallback:
                 return None
+            if getattr(st.derivatives, "series", None) is None:
+                return None          # plain callables (Derivatives(funcs)): evaluated state by state on the host, as the reference does
             if d.x_is_u or d.xv.dims[0] != d.rec_dim or d.uv.dims != (d.rec_dim,):
                 return None
             k = (tuple(d.xv.shape), tuple(d.xv.dims), d.order, d.weight is None, d.central, d.deriv_dim,
