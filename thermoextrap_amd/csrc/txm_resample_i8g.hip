@@ -55,6 +55,12 @@ __device__ __forceinline__ void g_dma4(const void *sbase, uint32_t voff, uint32_
 #endif
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_dst) : "memory", "m0");
 }
+// (TXM_G_ADIR experiment) 16 bytes per lane from saddr + voff into registers, as an asm the compiler does not track: it cannot count
+// the DMA pieces above either, and for a load it DOES see across the loop's back edge it falls back to s_waitcnt vmcnt(0) at the top of
+// every block -- the waits are written by hand (g_wait_vm) from the issue order of the block
+__device__ __forceinline__ void g_load16(v4i &dst, const void *sbase, uint32_t voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
 // sixteen progress words of a window, read past the scalar cache (glc): SMEM counts on lgkmcnt, so a poll does not touch
 // the wave's vmcnt queue of DMAs
 typedef uint32_t g_v16u __attribute__((ext_vector_type(16)));
@@ -114,6 +120,15 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   static_assert(G_BS * NQ % T_WAVES == 0, "count pieces per wave");
   constexpr int OFF_A = T_WAVES * WREG;                           // [2][G_BS][A_STEP] count words
   constexpr bool XBLK = !YS;                                      // x requested per block (8-slot ring) / per step (4 slots, + y)
+#ifdef TXM_G_ADIR
+  // (experiment, round 6) the count words of a two-row-set pass straight from global memory into registers: the table is in
+  // MFMA-A-operand order already, a pass of two row sets has 64 registers to spare -- A[step of the block][quarter], reloaded for
+  // the NEXT block right behind the operand's last MFMA (one block = four k-steps of lead).  No count ring in the LDS (32 of the
+  // 100 KiB a k-step moves through it), no count pieces among the loader waves' DMA (16 of 50 a block).
+  constexpr bool ADIR = XBLK && NS == 2;
+#else
+  constexpr bool ADIR = false;
+#endif
   constexpr int XRN = XBLK ? G_XRB : G_XR;
   constexpr int OFF_X = OFF_A + 2 * G_BS * A_STEP;                // [wave][XRN][32 samples][4 columns] doubles
   constexpr int OFF_Y = OFF_X + T_WAVES * XRN * 1024;
@@ -409,7 +424,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (nothing of the compiler's is in flight behind the DMAs below)
   raw_request(0);
   raw_request(1);
-  a_request(0);
+  if constexpr (!ADIR) a_request(0);
   if constexpr (XBLK) {  // chunk c lives in slot (c - 1) & 7: chunk 0 in slot 7, block 0's chunks 1..4 in slots 0..3
     x_request(7);
 #pragma unroll
@@ -418,6 +433,22 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
     for (int c = 0; c < G_XR; ++c) x_request(c);
   }
+  v4i AD[
+#ifdef TXM_G_ADIR
+      (XBLK && NS == 2) ? G_BS : 1
+#else
+      1
+#endif
+  ][NQ];  // (ADIR) the count operands of the block's four steps
+#ifdef TXM_G_ADIR
+  if constexpr (XBLK && NS == 2) {
+    const uint32_t l16 = g_lane_now() * 16u;
+#pragma unroll
+    for (int pp = 0; pp < G_BS; ++pp)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) g_load16(AD[pp][q], tab + (size_t)pp * G_KSTEP_BYTES + qoff[q], l16);
+  }
+#endif
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   stage_factors(0);
   {
@@ -501,7 +532,9 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   {
     const uint32_t a_va0 = (uint32_t)OFF_A + (uint32_t)lane * 16u;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) A[q] = *(lds_cv4)(lds + a_va0 + q * 1024);
+    for (int q = 0; q < NQ; ++q) {
+      if constexpr (!ADIR) A[q] = *(lds_cv4)(lds + a_va0 + q * 1024);
+    }
     Bt[0][0] = T_TRREAD((lds_v2i)(lds + rd_off));
     Bt[0][1] = T_TRREAD((lds_v2i)(lds + rd_off + 128));
     read_factors(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, f_va, f);
@@ -542,9 +575,18 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     auto a_piece = [&](int Q) {
 #ifndef TXM_G_NO_ADMA
-      if (loader) g_dma16(blk_asrc + qoff[Q], blk_l16, blk_adst + (uint32_t)(Q * 1024));
+      if constexpr (!ADIR)
+        if (loader) g_dma16(blk_asrc + qoff[Q], blk_l16, blk_adst + (uint32_t)(Q * 1024));
 #endif
     };
+    // (ADIR) the next block's count words: this lane's 16 bytes of every (step, quarter) piece
+    const unsigned char *nb_src = nullptr;
+    uint32_t nb_l16 = 0;
+    if constexpr (ADIR) {
+      const int Bn = B + 1 < nblk ? B + 1 : nblk - 1;
+      nb_src = tab + (size_t)(Bn * G_BS) * G_KSTEP_BYTES;
+      nb_l16 = g_lane_now() * 16u;
+    }
     auto x_chunk = [&](int i) {  // chunk cq -> slot i of the ring half the next block reads: the wave's own columns and its partner's
 #ifndef TXM_G_NO_XDMA
       if (loader) {
@@ -581,13 +623,18 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     auto issue_items = [&](auto kc) {
       constexpr int k = decltype(kc)::value;
       if constexpr (SPREAD && k < ISSUE_SLOTS) {
+        if constexpr (ADIR) {  // four x chunks over the four slots of steps 0 and 1
+          static_assert(!ADIR || ISSUE_SLOTS == G_BS, "one x chunk a slot");
+          x_chunk(k);
+        } else {
 #pragma unroll
-        for (int j = 0; j < NQ + 4; ++j)
-          if (j * ISSUE_SLOTS / (NQ + 4) == k) {  // interleaved: count piece, x chunk, count piece, ... then the remaining count pieces
-            if (j < 8 && (j & 1) == 0) a_piece(j >> 1);
-            else if (j < 8) x_chunk(j >> 1);
-            else a_piece(j - 4);
-          }
+          for (int j = 0; j < NQ + 4; ++j)
+            if (j * ISSUE_SLOTS / (NQ + 4) == k) {  // interleaved: count piece, x chunk, count piece, ... then the remaining count pieces
+              if (j < 8 && (j & 1) == 0) a_piece(j >> 1);
+              else if (j < 8) x_chunk(j >> 1);
+              else a_piece(j - 4);
+            }
+        }
       }
     };
     G_TICK(2);
@@ -606,15 +653,41 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // row set; the waits the compiler derives are lgkmcnt(6) and up -- nothing drains but the block's barrier.
     // (An experiment that let the younger wave of a SIMD take the barrier behind the last row set's MFMAs -- the waves of a
     // SIMD out of phase -- was slower: 114.4 against 107.9 ms at order 2.)
+#ifdef TXM_G_NO_PIN
+#define G_PIN() do {} while (0)
+#else
+#define G_PIN() __builtin_amdgcn_sched_barrier(0)
+#endif
     t_static_for<G_BS>([&](auto pc) {
       constexpr int p = decltype(pc)::value;
       double dx[2], dy[2] = {0.0, 0.0};
+      if constexpr (ADIR) {
+        // AD[p][*] were requested behind step p's last MFMAs ONE BLOCK AGO.  Vector-memory operations complete in order; issued
+        // behind AD[p][3] since then: the twelve count loads of the three other steps, and on a loader wave a block's DMA --
+        // R raw pieces at the block's top and the x pieces of steps 0 and 1 (two per slot): of those, four x pieces lie behind
+        // AD[0][3] / AD[1][3] and eight behind AD[2][3] / AD[3][3]
+        constexpr int R = WEIGHTED ? 2 : 1;
+        constexpr int NL = 12 + (p < 2 ? 4 : 8) + R;
+        // (no register operands on the waits: tied through the two branches they made the compiler copy the operands -- in one
+        // branch in FRONT of the wait; the scheduling barriers keep the step's MFMAs behind them instead)
+        G_PIN();
+        if (loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        G_PIN();
+      }
       t_static_for<NS>([&](auto fic) {
         constexpr int fi = decltype(fic)::value;
         constexpr bool last = fi == NS - 1;
         if constexpr (p == G_BS - 1 && last) {
           G_TICK(3);
-          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(XBLK ? 0 : 3 * NX) : "memory");
+          if constexpr (ADIR) {
+            // the block's DMA (raw pieces at its top, the x pieces in the slots of steps 0 and 1) has landed when at most the
+            // seven count loads issued behind the last x piece are in flight: A[1] quarters 1..3 and A[2]; waves 4..7 issue no DMA
+            if (loader) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(XBLK ? 0 : 3 * NX) : "memory");
+          }
 #ifndef TXM_G_NO_BARRIER  // (ablation build: no barrier)
           asm volatile("s_barrier" ::: "memory");  // the block's barrier
 #endif
@@ -657,10 +730,13 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // MFMAs back to back, and a wave that waits for the matrix pipe between two of its own MFMAs issues nothing else).
         auto mfma_q = [&](auto qc) {
           constexpr int q = decltype(qc)::value;
-          t_mfma<true>(acc[fi][q], A[q], Bv);
+          if constexpr (ADIR) t_mfma<true>(acc[fi][q], AD[p][q], Bv);
+          else t_mfma<true>(acc[fi][q], A[q], Bv);
           // quarter q's count operand of the NEXT step into the registers just used for the last time
 #ifndef TXM_G_NO_AREAD  // (ablation build)
-          if constexpr (last) {
+          if constexpr (last && ADIR) {  // step p of the NEXT block into the registers this block's step p has just finished with
+            g_load16(AD[p][q], nb_src + (size_t)p * G_KSTEP_BYTES + qoff[q], nb_l16);
+          } else if constexpr (last) {
             if constexpr (p == G_BS - 1) {  // the other ring buffer: the next block's step 0 (address formed here, not held)
               const uint32_t a_vn = (uint32_t)(OFF_A + ((B + 1) & 1) * (G_BS * A_STEP)) + g_lane_now() * 16u;
               A[q] = *(lds_cv4)(lds + a_vn + q * 1024);
@@ -670,11 +746,6 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
           }
 #endif
         };
-#ifdef TXM_G_NO_PIN
-#define G_PIN() do {} while (0)
-#else
-#define G_PIN() __builtin_amdgcn_sched_barrier(0)
-#endif
         G_PIN();
         t_static_for<(0 + 1) * NQ / 4 - 0 * NQ / 4>([&](auto jc) { mfma_q(std::integral_constant<int, 0 * NQ / 4 + decltype(jc)::value>{}); });
         G_PIN();
