@@ -198,9 +198,8 @@ class Derivatives(_Params):
             raise TypeError("Derivatives needs funcs (callables, or a polynomial series)")
         self.funcs = funcs
         self.args = args
-        self.series = getattr(funcs, "series", None)
-        if self.series is None and self._looks_like_poly_series(funcs):
-            self.series = funcs
+        # the polynomial series behind the functions, when there is one: from_sympy's translation, or the functions ARE polynomials
+        self.series = funcs.series if isinstance(funcs, _SympyFuncs) else (funcs if self._looks_like_poly_series(funcs) else None)
         self.exprs = exprs if exprs is not None else (_ExprView(self.series) if self.series is not None else None)
         self._tables: dict = {}
 
