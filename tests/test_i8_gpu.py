@@ -89,6 +89,10 @@ def truth_err(orc, got, x, u, order, freq, reps, w=None, sc=None):
     (50000, 4, 3, 100, False),      # narrow states, a last replicate group of 33 .. 63 live replicates (config 5's 100 = 64 + 36)
     (30000, 8, 4, 45, True),
     (60001, 12, 2, 127, False),     # ... 63 live, slid last tile
+    (40000, 3, 2, 70, True),        # one-quad states with <= 4 powers: four chunk groups of two waves (round 6) -- weighted,
+    (300000, 4, 1, 64, True),       # ... several scaling windows (the groups' accumulators meet in the count tile at every flush),
+    (9000, 2, 3, 200, False),       # ... four replicate groups, the last one packed
+    (70001, 1, 3, 65, False),       # ... 1-D observable, slid last tile
 ])
 def test_i8_matches_fp64_on_same_stream(eng, orc, N, C, order, nrep, weighted):
     x, u = data(N, C, 5)
