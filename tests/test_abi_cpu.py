@@ -229,7 +229,10 @@ def test_dispatch_rule_matches_the_header_thresholds(lib):
     assert W(N, 32, 130, 2, AUTO, 0) == W(N, 32, 130, 2, FUSED, 0)      # 130 -> 256 against 192
     assert W(N, 32, 100, 2, AUTO, 0) == W(N, 32, 100, 2, TABLE, 0)      # 100 -> 128 either way
     assert W(N, 32, 260, 2, AUTO, 0) == W(N, 32, 260, 2, TABLE, 0)      # 260 -> 384 against 320
-    assert W(N, 8, 1000, 2, TABLE, 0) == W(N, 8, 1000, 2, FUSED, 0)     # narrow states never use the table
+    # narrow states: the table kernel of txm_resample_i8gn.hip on request only (order >= 1), never by the rule
+    assert table(1000) <= W(N, 8, 1000, 2, TABLE, 0) - W(N, 8, 1000, 2, FUSED, 0) < table(1000) + 4096
+    assert W(N, 8, 1000, 2, AUTO, 0) == W(N, 8, 1000, 2, FUSED, 0)
+    assert W(N, 8, 1000, 0, TABLE, 0) == W(N, 8, 1000, 0, FUSED, 0)     # order 0 of a narrow state: no int8 kernel at all
     assert W(N, 32, 1000, 2, FP64, 0) <= W(N, 32, 1000, 2, FUSED, 0)
     assert lib.txm_sampler_count_table_bytes(N, 1000) == table(1000)
 
@@ -248,10 +251,12 @@ def test_kernel_word_is_what_a_prep_block_is_keyed_on(lib):
     assert Kn(N, 32, 64, 6, -1, 1, 1) == FUSED | WY and Kn(N, 32, 1000, 6, -1, 1, 1) == TABLE | WY
     # without y: orders 3 and 4 from two replicate groups on
     assert Kn(N, 32, 128, 4, -1, 0, 1) == FUSED and Kn(N, 32, 256, 4, -1, 0, 1) == TABLE and Kn(N, 32, 1000, 2, -1, 0, 1) == TABLE
-    # a forced path is honoured (a slab of 40 replicates of a table call), misaligned operands and narrow states never ride the table
+    # a forced path is honoured (a slab of 40 replicates of a table call), misaligned operands never ride the table; narrow states
+    # (txm_resample_i8gn.hip) on request only, and a second matrix never rides a narrow call
     assert Kn(N, 32, 40, 4, TABLE, 1, 1) == TABLE | WY and Kn(N, 32, 1000, 4, FUSED, 1, 1) == FUSED
     assert Kn(N, 32, 1000, 4, -1, 1, 0) == FUSED and Kn(N, 32, 1000, 4, TABLE, 0, 0) == FUSED
-    assert Kn(N, 8, 1000, 3, -1, 1, 1) == FUSED and Kn(N, 8, 1000, 3, TABLE, 0, 1) == FUSED
+    assert Kn(N, 8, 1000, 3, -1, 1, 1) == FUSED and Kn(N, 8, 1000, 3, TABLE, 0, 1) == TABLE and Kn(N, 8, 1000, 3, TABLE, 1, 1) == TABLE
+    assert Kn(N, 8, 1000, 3, TABLE, 0, 0) == FUSED and Kn(N, 8, 1000, 0, TABLE, 0, 1) == FUSED  # (order 0: no narrow variant)
     assert Kn(N, 32, 16, 4, -1, 0, 1) == FP64 and Kn(N, 32, 1000, 4, FP64, 1, 1) == FP64 and Kn(N, 32, 1000, 8, -1, 0, 1) == FP64
     assert Kn(0, 32, 1000, 4, -1, 0, 1) == FP64
     # `aligned` as the library itself judges a pair of operands (address bits and row pitches only: no device needed)
@@ -383,9 +388,10 @@ def test_inline_asm_clobbers_are_complete():
         assert not _asm_violations(text), (f.name, _asm_violations(text))
     assert n >= 25, n                                     # the scanner sees the statements (i8g: 21, i8t: 5, common: 4)
     # the statements that write M0 today are found and are covered
-    i8g = (ROOT / "thermoextrap_amd" / "csrc" / "txm_resample_i8g.hip").read_text()
-    m0 = [st for st in _asm_statements(i8g) if "s_mov_b32 m0" in st[1]]
-    assert len(m0) >= 3 and all("m0" in st[2] for st in m0)
+    m0 = []
+    for name in ("txm_i8g.h", "txm_resample_i8g.hip", "txm_resample_i8gn.hip"):  # (the DMA helpers are shared by the two table kernels)
+        m0 += [st for st in _asm_statements((ROOT / "thermoextrap_amd" / "csrc" / name).read_text()) if "s_mov_b32 m0" in st[1]]
+    assert len(m0) >= 4 and all("m0" in st[2] for st in m0)
     # negative controls: round 5's faulting statement (SCC written, not clobbered), and the same mistakes for M0 / VCC / EXEC
     reverted = 'uint32_t c; asm volatile("s_lshr_b32 %0, %1, 1" : "=s"(c) : "s"(wave));'
     v = _asm_violations(reverted)

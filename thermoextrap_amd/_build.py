@@ -15,7 +15,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libtxmom.so"
 SOURCES = ["txm_api.hip", "txm_reduce.hip", "txm_sampler.hip", "txm_small.hip", "txm_resample.hip", "txm_resample_i8.hip",
-           "txm_resample_i8t.hip", "txm_resample_i8g.hip", "txm_count_table.hip", "txm_perturb.hip"]
+           "txm_resample_i8t.hip", "txm_resample_i8g.hip", "txm_resample_i8gn.hip", "txm_count_table.hip", "txm_perturb.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed"]
 # per-file flags.  txm_resample_i8t.hip: 11 int32 accumulator tiles (176 registers) per wave at two waves per SIMD only
 # fit when the 256 registers are ONE file -- MFMA accumulators in VGPRs, no AGPR split (see the file's header)
@@ -29,7 +29,7 @@ _I8T = ["-mllvm", "-amdgpu-mfma-vgpr-form", "-Wno-inline-asm"]
 # run of sixteen and whole tiles are spilled (any small edit flipped the kernel between 2 and 200+ spilled registers).  With
 # the widest register classes assigned first every instance builds with 0-9 spills, none inside the k-steps.
 _I8G = _I8T + ["-mllvm", "-greedy-regclass-priority-trumps-globalness=1"]
-EXTRA_FLAGS = {"txm_resample_i8t.hip": _I8T, "txm_resample_i8g.hip": _I8G, "txm_sampler.hip": ["-ffp-contract=off"]}
+EXTRA_FLAGS = {"txm_resample_i8t.hip": _I8T, "txm_resample_i8g.hip": _I8G, "txm_resample_i8gn.hip": _I8G, "txm_sampler.hip": ["-ffp-contract=off"]}
 
 
 def _hipcc() -> str:

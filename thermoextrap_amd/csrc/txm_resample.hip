@@ -814,7 +814,8 @@ static I8Plan plan_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   // the rule (table_kernel_pays) or the caller asks for it AND the workspace it was given reaches total_table
   p.off_gprog = p.off_prep + align_up(p.prep_total, 256);
   p.off_table = p.off_gprog + align_up((size_t)cdiv(p.nwin, 8) * 8 * 16 * sizeof(uint32_t), 256);
-  p.table_bytes = (C > 16 && N >= SM_T) ? count_table_bytes(p.ntiles, nrep) : 0;
+  // (narrow states -- C <= 16, order >= 1 -- have a table-fed kernel of their own since round 6: txm_resample_i8gn.hip)
+  p.table_bytes = (N >= SM_T && (C > 16 || K >= 2)) ? count_table_bytes(p.ntiles, nrep) : 0;
   p.total = p.off_table;
   p.total_table = p.off_table + align_up(p.table_bytes, 256);
   return p;
@@ -867,9 +868,28 @@ static bool table_kernel_pays(int64_t nrep, int K, bool has_y) {
 // ONE statement of "does this call run the count-table kernel" for the call itself, the workspace query and
 // txm_resample_kernel (what the host keys a kept pre-pass block on): `eff` is the call's path after the process-wide
 // override, `applicable` = i8g_applicable() of the operands.  The call additionally needs the table's bytes in its workspace.
-static bool table_call_rule(size_t table_bytes, int eff, int64_t nrep, int K, bool has_y, bool applicable) {
-  return eff != TXM_PATH_FP64 && eff != TXM_PATH_INT8_FUSED && table_bytes != 0 && applicable &&
-         (eff == TXM_PATH_INT8_TABLE || table_kernel_pays(nrep, K, has_y));
+// Narrow states (C <= 16): the table-fed kernel of txm_resample_i8gn.hip (128 replicates per workgroup, no fill phase) against the
+// quad-sharing variant of the kernel that draws in place -- bit for bit the same sums, so again a rule on speed alone (measured
+// on MI355X, tools/narrow_time.py; profiles/r06_experiments.md section 2).
+static bool narrow_table_pays(int64_t N, int64_t C, int64_t nrep, int K) {
+#ifdef TXM_NARROW_TABLE_AUTO
+  (void)C; (void)K;
+  const int64_t pad128 = cdiv(nrep, G_REPS) * G_REPS, pad64 = cdiv(nrep, I8_REPS) * I8_REPS;
+  return N >= 786432 && 4 * pad128 <= 5 * pad64;
+#else
+  (void)N; (void)C; (void)nrep; (void)K;
+  return false;
+#endif
+}
+static bool table_call_rule(size_t table_bytes, int eff, int64_t N, int64_t C, int64_t nrep, int K, bool has_y, bool applicable) {
+  if (eff == TXM_PATH_FP64 || eff == TXM_PATH_INT8_FUSED || table_bytes == 0 || !applicable) return false;
+  if (eff == TXM_PATH_INT8_TABLE) return true;
+  return C > 16 ? table_kernel_pays(nrep, K, has_y) : narrow_table_pays(N, C, nrep, K);
+}
+// what the table-fed kernels ask of the operands (16-byte LDS-DMA pieces): wide states txm_resample_i8g.hip, narrow ones
+// txm_resample_i8gn.hip (a second matrix never rides a narrow call: it is bootstrapped on its own)
+static bool table_operands_ok(const double *x, int64_t ldx_s, int64_t C, int K, const double *y, int64_t ldy_s) {
+  return C > 16 ? i8g_applicable(x, ldx_s, C, y, ldy_s) : i8gn_applicable(x, ldx_s, C, K);
 }
 
 static bool use_i8(int64_t N, int64_t C, int64_t nrep, int K, int call_path = TXM_PATH_AUTO) {
@@ -973,8 +993,8 @@ extern "C" int txm_resample_kernel(int64_t N, int64_t C, int64_t nrep, int order
   if (!use_i8(N, C, nrep, K, path)) return TXM_PATH_FP64;
   const I8Plan q = plan_i8(N, C, nrep, K);
   const int eff = path != TXM_PATH_AUTO ? path : path_override();
-  const bool table = table_call_rule(q.table_bytes, eff, nrep, K, has_y != 0, aligned != 0 && C > 16);
-  const bool with_y = has_y != 0 && (table || i8t_carries_y(C, K));
+  const bool table = table_call_rule(q.table_bytes, eff, N, C, nrep, K, has_y != 0, aligned != 0);
+  const bool with_y = has_y != 0 && ((table && C > 16) || i8t_carries_y(C, K));
   return (table ? TXM_PATH_INT8_TABLE : TXM_PATH_INT8_FUSED) | (with_y ? TXM_KERNEL_WITH_Y : 0);
 }
 
@@ -982,7 +1002,7 @@ extern "C" int txm_resample_kernel(int64_t N, int64_t C, int64_t nrep, int order
 // LDS-DMA asks of them -- ONE statement of it, the one the call itself applies (i8g_applicable)
 extern "C" int txm_resample_operands_aligned(const double *x, int64_t ldx_s, int64_t C, const double *y, int64_t ldy_s) {
   if (x == nullptr || C < 1) return 0;
-  return i8g_applicable(x, ldx_s, C > 16 ? C : 17, y, ldy_s) ? 1 : 0;  // (alignment only: narrow states are txm_resample_kernel's business)
+  return table_operands_ok(x, ldx_s, C, 2, y, ldy_s) ? 1 : 0;  // (K only decides whether a narrow shape is served at all: txm_resample_kernel's business)
 }
 
 extern "C" size_t txm_resample_prep_bytes(int64_t N, int64_t C, int64_t nrep, int order) {
@@ -1016,7 +1036,7 @@ extern "C" size_t txm_resample_vals_ws_bytes_opts(int64_t N, int64_t C, int64_t 
   if (i8_supported(N, C, nrep, order + 1)) {
     const I8Plan q = plan_i8(N, C, nrep, order + 1);
     const int eff = path != TXM_PATH_AUTO ? path : path_override();
-    const bool table = table_call_rule(q.table_bytes, eff, nrep, order + 1, has_y != 0, true);
+    const bool table = table_call_rule(q.table_bytes, eff, N, C, nrep, order + 1, has_y != 0, true);
     const size_t m = table ? q.total_table : q.total;
     if (m > n) n = m;
   }
@@ -1170,8 +1190,8 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
     // TXM_PATH_INT8_FUSED keep the kernel that draws in place; narrow states and narrow tail groups always run it.
     const int eff_path = path != TXM_PATH_AUTO ? path : path_override();
     const bool table_call = ws_bytes >= q.total_table &&
-                            table_call_rule(q.table_bytes, eff_path, nrep, K, y != nullptr, i8g_applicable(x, ldx_s, C, y, ldy_s));
-    const bool with_y = y != nullptr && (table_call || i8t_carries_y(C, K));
+                            table_call_rule(q.table_bytes, eff_path, N, C, nrep, K, y != nullptr, table_operands_ok(x, ldx_s, C, K, y, ldy_s));
+    const bool with_y = y != nullptr && ((table_call && C > 16) || i8t_carries_y(C, K));
     if (ws_bytes < q.total) {
       set_error("resample_vals: workspace too small (%zu < %zu)", ws_bytes, q.total);
       return TXM_ERR_WORKSPACE;
@@ -1277,7 +1297,8 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
         }
         I8Args bg = b;
         bg.progress = (throttle_on() && nrep > G_REPS) ? (uint32_t *)((char *)ws + q.off_gprog) : nullptr;
-        rc = launch_resample_i8g(bg, K, w != nullptr, table, 0, (int)cdiv(nrep, G_REPS), st);
+        rc = C > 16 ? launch_resample_i8g(bg, K, w != nullptr, table, 0, (int)cdiv(nrep, G_REPS), st)
+                    : launch_resample_i8gn(bg, K, w != nullptr, table, 0, (int)cdiv(nrep, G_REPS), 0, st);
       } else {
         rc = launch_resample_i8(b, K, w != nullptr, q.prog_bytes, st);
       }

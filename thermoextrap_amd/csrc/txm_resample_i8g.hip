@@ -27,7 +27,6 @@
 
 namespace txm {
 
-constexpr int G_BS = 4;  // k-steps per block (one barrier per block)
 constexpr int G_XR = 4;  // chunks in a wave's x ring when x is requested step by step (second-matrix passes; = G_BS)
 static_assert(G_XR == G_BS && G_BS == 4, "the wait counts below are written for blocks of four k-steps");
 // ... and when a block's four x chunks are requested together with its count words (passes without a second matrix): eight.
@@ -36,57 +35,6 @@ static_assert(G_XR == G_BS && G_BS == 4, "the wait counts below are written for 
 // per k-step stalled every step's LDS reads for an L2 round trip.  One DMA event per block instead of five.
 constexpr int G_XRB = 8;
 constexpr int G_FU = 2176;           // bytes between the factor lines of a lane's two 16-sample units (> 2040: no ds_read2 pairing)
-constexpr int G_RAW = 2 * G_BS * 256;  // one raw buffer: u then w of a block's chunks
-#ifndef TXM_G_LEAD
-#define TXM_G_LEAD 2
-#endif
-constexpr uint32_t G_LEAD = TXM_G_LEAD;  // tiles a replicate group may run ahead of the slowest one of its window
-
-// LDS-DMA: 16 (4) bytes per lane from saddr + voff to the LDS address in M0 + 16 (4) * lane
-__device__ __forceinline__ void g_dma16(const void *sbase, uint32_t voff, uint32_t lds_dst) {
-#ifdef TXM_G_NO_DMA  // ablation build
-  return;
-#endif
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_dst) : "memory", "m0");
-}
-__device__ __forceinline__ void g_dma4(const void *sbase, uint32_t voff, uint32_t lds_dst) {
-#ifdef TXM_G_NO_DMA
-  return;
-#endif
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_dst) : "memory", "m0");
-}
-// (TXM_G_ADIR experiment) 16 bytes per lane from saddr + voff into registers, as an asm the compiler does not track: it cannot count
-// the DMA pieces above either, and for a load it DOES see across the loop's back edge it falls back to s_waitcnt vmcnt(0) at the top of
-// every block -- the waits are written by hand (g_wait_vm) from the issue order of the block
-__device__ __forceinline__ void g_load16(v4i &dst, const void *sbase, uint32_t voff) {
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
-}
-// sixteen progress words of a window, read past the scalar cache (glc): SMEM counts on lgkmcnt, so a poll does not touch
-// the wave's vmcnt queue of DMAs
-typedef uint32_t g_v16u __attribute__((ext_vector_type(16)));
-__device__ __forceinline__ uint32_t g_min_progress(const uint32_t *pg) {
-  g_v16u v;
-  asm volatile("s_load_dwordx16 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(pg) : "memory");
-  uint32_t m = 0xffffffffu;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const uint32_t e = v[i] == 0u ? 0xffffffffu : v[i];  // 0: a group that has not started (or does not exist)
-    m = e < m ? e : m;
-  }
-  return m;
-}
-// the lane id, recomputed where it is used: addresses that are a function of the lane and are needed once a block (the DMA
-// offsets, the staging addresses) would otherwise be held in registers across the k-steps -- the kernel has none to spare,
-// they were spilled, and every reload put a scratch round trip + s_waitcnt vmcnt on the block's critical path
-__device__ __forceinline__ uint32_t g_lane_now() {
-  uint32_t l;
-  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-  return l;
-}
-template <int N>
-__device__ __forceinline__ void g_wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 // replicate QUARTERS (32 replicates = one MFMA row block = one 1-KiB piece of a table k-step) per workgroup: four (128 replicates),
 // and eight in a pass of ONE row set (order 0), which has the registers for eight accumulator tiles per wave: every x chunk, sliced

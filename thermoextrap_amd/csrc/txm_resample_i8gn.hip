@@ -1,0 +1,593 @@
+// txm_resample_i8gn.hip -- the table-fed int8 bootstrap contraction for NARROW states (C <= 16 observables; round 6).
+//
+// Same sums, same fixed-point words, same partial-sum slots as the quad-sharing variant of resample_i8t_kernel
+// (cmomy.wrap_resample_vals as called from thermoextrap data.py:1803-1810, 1354-1366; StateCollection.resample,
+// models.py:614-641):
+//        S1[r][c][j] = sum_i f[r][i] w_i du_i^j dx_ic        S0[r][j] = sum_i f[r][i] w_i du_i^j
+// with the counts f read from the table count_table_kernel (txm_count_table.hip) wrote in MFMA-A-operand order.
+//
+// Why.  The narrow-state launches of the kernel that draws in place are bound by what ONE workgroup per CU can overlap between
+// its barriers (profiles/r06_experiments.md section 2: fill 31-35 % of the call, slicing 25-28 %, the parts add), and the
+// 64 KiB count tile of a 1024-sample sampler tile rules out both a 128-replicate workgroup (128 KiB of the CU's 160) and a
+// second resident workgroup.  Fed from the table a workgroup needs no count tile at all -- a 32 KiB ring of count words --
+// so it takes 128 replicates (every sliced word feeds four MFMAs instead of two, every chore of a k-step serves twice the
+// replicates), has no fill phase, no zeroing, no per-tile barriers; the generator runs at the same Philox-bound rate as the
+// fill it replaces, with four waves per SIMD.
+//
+// Workgroup = 8 waves x 128 replicates x NCQ column quads (1, 2 or 4) x the powers J0 .. J0 + JN - 1.  The GS = 8 / NCQ waves
+// that share a quad split the powers (wave w: quad w % NCQ, powers g, g + GS, ... with g = w / NCQ); the S0 monomials w du^j
+// (dx = 1) are u-row fragments of four monomials x eight digit slots on the LAST waves (the ones with the fewest powers).
+// Counts, x, u and w arrive by LDS-DMA as in resample_i8g_kernel: waves 0..3 request a block of four k-steps at a time, one
+// s_barrier per block; the x ring is per QUAD (the waves of a quad read the same chunk).
+// The int32 sums of a window are exact and the flush is the expression of resample_i8t_kernel: the two kernels agree BIT FOR
+// BIT (tests/test_i8gn_gpu.py).
+#include "txm_i8g.h"
+
+namespace txm {
+
+// Who does the block's chores.  A wave's matrix work is its live power row sets + its u-row fragment; the DMA requests (four
+// loader waves, a block step each) and the staging of the factors (two waves) go to the waves with the LEAST of it -- with one quad
+// and four powers the waves 4..6 have none at all, and the first cut had the four working waves issue every DMA piece and the
+// u-row wave stage the factors in front of its k-steps (890 cycles a k-step for 20 MFMAs).
+template <int JN, int NCQ>
+struct GnRoles {
+  static constexpr int GS = T_WAVES / NCQ, UF = (JN + 3) / 4;
+  static constexpr int work(int w) {  // (a u-row step costs more than a power row's: ldexp + add per word, phase clocks 2190 against 1840 cycles a block)
+    int n = 0;
+    for (int j = w / NCQ; j < JN; j += GS) n += 2;
+    return n + (w >= T_WAVES - UF ? 3 : 0);
+  }
+  static constexpr int idle() {
+    int n = 0;
+    for (int w = 0; w < T_WAVES; ++w) n += work(w) == 0 ? 1 : 0;
+    return n;
+  }
+  static constexpr int first_idle(int skip) {
+    for (int w = 0; w < T_WAVES; ++w)
+      if (work(w) == 0 && skip-- == 0) return w;
+    return 0;
+  }
+  // first wave of the run of `len` consecutive waves with the smallest total work (ties: the later run -- away from wave 0's polling)
+  static constexpr int best_run(int len) {
+    int best = 0, bw = 1 << 30;
+    for (int w0 = 0; w0 + len <= T_WAVES; ++w0) {
+      int t = 0;
+      for (int k = 0; k < len; ++k) t += work(w0 + k);
+      if (t <= bw) { bw = t; best = w0; }
+    }
+    return best;
+  }
+  // two waves without matrix work take all the requests (two block steps each) and the staging; otherwise the requests are spread
+  // over the four least loaded consecutive waves (a block step each) and the staging goes to the two least loaded
+  static constexpr int NLD = idle() >= 2 ? 2 : 4;
+  static constexpr int LOAD0 = idle() >= 2 ? first_idle(0) : best_run(4);
+  static constexpr int STAGE0 = idle() >= 3 ? first_idle(1) : idle() >= 2 ? first_idle(0) : best_run(2);
+  static_assert(idle() < 2 || first_idle(1) == first_idle(0) + 1, "idle waves are consecutive");
+};
+
+template <int J0, int JN, bool WEIGHTED, int NCQ, bool BATCHED = false>
+__global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void resample_i8gn_kernel(
+    const I8Args a_in, const int K, const unsigned char *__restrict__ table_in, const int64_t rep_begin, const int n_grp,
+    const size_t table_state_stride) {
+  static_assert(NCQ == 1 || NCQ == 2 || NCQ == 4, "column quads of a narrow state");
+  constexpr int GS = T_WAVES / NCQ;            // waves per quad = stride of a wave's powers
+  constexpr int NSW = (JN + GS - 1) / GS;      // power row sets per wave
+  constexpr int UF = (JN + 3) / 4;             // u-row fragments (four monomials each)
+  constexpr int NQ = 4;                        // replicate quarters (A operands, tiles per row set)
+  constexpr int NPT = JN;                      // staged factors per sample
+  static_assert(JN >= 1 && J0 + JN <= 8 && NSW <= 3 && UF <= 2, "power range");
+  static_assert(NSW + 1 <= 3 || UF == 0, "a wave with a u-row fragment holds at most two power row sets (12 tiles)");
+  constexpr int WREG = (NSW + 1) * T_PB;       // a wave's X region: its power row sets + one u-row fragment
+  // DMA lead: a narrow k-step is short (a few MFMAs a wave: 200-600 cycles), and a request to HBM takes 2-3 us to land -- the ONE
+  // block of lead resample_i8g_kernel lives on (its k-steps take 1800 cycles) left every block's barrier waiting for the DMA
+  // (first cut: 1200 cycles a k-step for 20 MFMAs).  Block B + D is requested at the top of block B, into rings of D + 1 blocks.
+  constexpr int D = NCQ == 4 ? 2 : 3, NB = D + 1;
+  constexpr int A_STEP = NQ * 1024;            // count words of one k-step: [quarter][1024]
+  constexpr int OFF_A = T_WAVES * WREG;        // [NB][G_BS][A_STEP]
+  constexpr int XSLOTS = NB * G_BS;            // chunks in a quad's x ring
+  constexpr int OFF_X = OFF_A + NB * G_BS * A_STEP;           // [quad][XSLOTS][32 samples][4 columns] doubles
+  constexpr int NR = D + 2;                                   // raw buffers: requested D + 1 blocks ahead of their k-steps
+  constexpr int OFF_RAW = OFF_X + NCQ * XSLOTS * 1024;        // [NR][u | w][G_BS * 32] doubles
+  constexpr int FU = G_BS * 16 * NPT * 8 + 136;               // bytes between the factor lines of a lane's two 16-sample units
+  constexpr int OFF_F = OFF_RAW + NR * G_RAW;                 // [3][unit][FU]: line (chunk-in-block, sample) x NPT factors
+  // DMA pieces a loader wave issues at the top of a block: the count words, the x of every quad and the raw u / w of its block steps
+  constexpr int PIECES = (G_BS / GnRoles<JN, NCQ>::NLD) * (NQ + NCQ + (WEIGHTED ? 2 : 1));
+  constexpr int OFF_FS = OFF_F + 3 * 2 * FU;                  // [128] draws per replicate in the window
+  static_assert(T_WAVES * WREG <= 65536, "X regions within the first 64 KiB (ds_write_addtid takes its base from M0[15:0])");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  uint32_t *fsum = reinterpret_cast<uint32_t *>(lds + OFF_FS);
+
+  typedef const __attribute__((address_space(4))) I8Args *const_args_p;
+  auto pick_args = [&]() -> decltype(auto) {
+    if constexpr (BATCHED) return (*(const_args_p)(uintptr_t)(a_in.batch_args + blockIdx.y));
+    else return (a_in);
+  };
+  const auto &a = pick_args();
+  const unsigned char *table = table_in + (BATCHED ? (size_t)blockIdx.y * table_state_stride : (size_t)0);
+
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int n32 = lane & 31, half = lane >> 5;
+  const uint32_t wreg = (uint32_t)(wave * WREG);
+  const int quad = wave % NCQ, g = wave / NCQ;  // the wave's column quad and its first power (relative to J0)
+  auto row_live = [&](int fi) { return g + fi * GS < JN; };
+  // u-row fragment fu on wave 7 - fu (wave-uniform)
+  const bool has_ut = wave >= T_WAVES - UF;
+  const int fu = has_ut ? T_WAVES - 1 - wave : 0;
+  const bool any_work = has_ut || g < JN;  // wave-uniform
+
+  // ---- which window, which replicate group (the groups of a window share an XCD: b and b + 8 land on the same one)
+  const int b = blockIdx.x;
+  const int64_t win = (int64_t)((b >> 3) / n_grp) * 8 + (b & 7);
+  const int grp = (b >> 3) % n_grp;
+  if (win >= a.nwin) return;
+  if (a.wflag[win] != 0u) return;  // precision guard: this window goes to the FP64 kernel
+  const int64_t rep0 = rep_begin + (int64_t)grp * G_REPS;
+  const int64_t WT = a.win_tiles;
+  const int64_t t0 = win * WT;
+  const int64_t t1 = t0 + WT < a.ntiles ? t0 + WT : a.ntiles;
+  const int nsteps = (int)(t1 - t0) * T_STEPS;  // k-steps (32-sample chunks) of the window
+  const int nblk = nsteps / G_BS;
+  const unsigned char *tab = table + ((size_t)grp * (size_t)a.ntiles + (size_t)t0) * G_TILE_BYTES;  // the window in this group's table
+
+  // ---- producer role: lane = (sample l >> 2 of a 16-sample unit, column l & 3 of the wave's quad)
+  const int ps = lane >> 2, cl = lane & 3;
+  const int col = 4 * quad + cl;
+  const int ccol = col < a.C ? col : 0;  // columns >= C re-read column 0: their sums are never flushed
+  // ---- consumer role (as resample_i8t_kernel)
+  const uint32_t rd_off = wreg + (uint32_t)(((lane >> 4) & 1) * (T_PLANE + 128) + (16 * half + ((lane & 15) >> 1)) * 16 + (lane & 1) * 8);
+  const int tcl = (n32 >> 2) & 3, tdg = 4 * (n32 >> 4) + (n32 & 3);
+  const int um = 4 * fu + cl;             // this lane's u-row monomial
+  const int umc = um < JN ? um : 0;       // (the unused slots of a short fragment repeat monomial 0: never flushed)
+
+  const double *wt = a.wtab + win * I8_WT_STRIDE;
+  const double pu = a.pivot[0];
+  const double inv_du = wt[I8_WT_INVDU];
+  const double inv_w = WEIGHTED ? wt[I8_WT_INVW] : 1.0;
+  const double sc = wt[I8_WT_SC + ccol];
+  const double px = a.pivot[1 + a.col0 + ccol];
+
+  v16i acc[NSW][NQ];
+  v16i accu[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+    for (int e = 0; e < NSW; ++e) acc[e][q] = (v16i)(0);
+    accu[q] = (v16i)(0);
+  }
+
+  // first sample of chunk c of the window (the last tile of the series slides its window back)
+  auto chunk_sample = [&](int c) -> int64_t {
+    int64_t b0 = (t0 + (c >> 5)) * SM_T;
+    if (b0 > a.N - SM_T) b0 = a.N - SM_T;
+    return b0 + 32 * (c & 31);
+  };
+  // ---- requests (loader waves 0..3: the older wave of every SIMD, as in resample_i8g_kernel)
+  constexpr int LOAD0 = GnRoles<JN, NCQ>::LOAD0, STAGE0 = GnRoles<JN, NCQ>::STAGE0, NLD = GnRoles<JN, NCQ>::NLD;
+  constexpr int SPL = G_BS / NLD;                         // block steps per loader wave
+  const bool loader = wave >= LOAD0 && wave < LOAD0 + NLD;  // uniform
+  const int lw = wave - LOAD0;                            // this loader requests the pieces of block steps lw SPL .. lw SPL + SPL - 1
+  int cq = 0;                    // chunk of the next x request (uniform)
+  const char *xq = reinterpret_cast<const char *>(a.x + chunk_sample(0) * a.ldx_s);
+  const int64_t xstep = 32 * a.ldx_s * 8;
+  // chunk cq -> slot `slot` of every quad's ring (lane L fetches the 16-byte half L & 1 of row L >> 1 of the quad's four columns)
+  // (every loader wave walks the chunks; loader lw requests the lw-th chunk of a block -- `mine`)
+  auto x_request = [&](int slot, bool mine) {
+    if (loader && mine) {
+      const uint32_t ln = g_lane_now();
+      const uint32_t row = (ln >> 1) * (uint32_t)(a.ldx_s * 8) + (ln & 1) * 16u + (uint32_t)(a.col0 * 8);
+#pragma unroll
+      for (int qd = 0; qd < NCQ; ++qd) {
+        const int qsrc = 4 * qd < a.C ? qd : 0;  // quads past C re-read quad 0 (never flushed)
+        g_dma16(xq, row + (uint32_t)(32 * qsrc), (uint32_t)(OFF_X + (qd * XSLOTS + slot) * 1024));
+      }
+    }
+    ++cq;
+    if (cq < nsteps) {
+      if ((cq & 31) == 0) xq = reinterpret_cast<const char *>(a.x + chunk_sample(cq) * a.ldx_s);  // a new tile
+      else xq += xstep;
+    }
+  };
+  // count words of block B -> ring buffer B & 1: loader wave w the four 1-KiB pieces of the block's k-step w
+  auto a_request = [&](int B) {
+    if (!loader) return;
+    const int Bc = B < nblk ? B : nblk - 1;
+    const uint32_t l16 = g_lane_now() * 16u;
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+      const int st = lw * SPL + k;
+      const unsigned char *src = tab + (size_t)(Bc * G_BS + st) * G_KSTEP_BYTES;
+      const uint32_t dst = (uint32_t)(OFF_A + (B % NB) * (G_BS * A_STEP) + st * A_STEP);
+#pragma unroll
+      for (int Q = 0; Q < NQ; ++Q) g_dma16(src + (size_t)Q * 1024, l16, dst + (uint32_t)(Q * 1024));
+    }
+  };
+  // raw u / w of factor block B (the chunks B * G_BS + 1 .. B * G_BS + G_BS: what block B's k-steps slice): loader wave w chunk w
+  auto raw_request = [&](int B) {
+    if (!loader) return;
+    const uint32_t l4 = g_lane_now() * 4u;
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+      const int st = lw * SPL + k;
+      int c = B * G_BS + 1 + st;
+      if (c > nsteps - 1) c = nsteps - 1;
+      const int64_t i0 = chunk_sample(c);
+      g_dma4(a.u + i0, l4, (uint32_t)(OFF_RAW + (B % NR) * G_RAW + st * 256));
+      if constexpr (WEIGHTED) g_dma4(a.w + i0, l4, (uint32_t)(OFF_RAW + (B % NR) * G_RAW + G_BS * 256 + st * 256));
+    }
+  };
+  // factors of block B from raw buffer B % 3 into factor buffer B % 3 (waves 6 and 7, one sample per lane)
+  auto stage_factors = [&](int B) {
+    if (wave < STAGE0 || wave >= STAGE0 + 2) return;  // uniform
+    const int e = (int)g_lane_now() + (wave - STAGE0) * 64;  // entry: chunk-in-block e >> 5, sample e & 31
+    const double *raw = reinterpret_cast<const double *>(lds + OFF_RAW + (B % NR) * G_RAW);
+    const double du = (raw[e] - pu) * inv_du;
+    double pw = WEIGHTED ? raw[G_BS * 32 + e] * inv_w : 1.0;
+    double *f = reinterpret_cast<double *>(lds + OFF_F + (B % 3) * (2 * FU) + ((e >> 4) & 1) * FU) + (((e >> 5) * 16 + (e & 15)) * NPT);
+#pragma unroll
+    for (int k = 0; k < J0; ++k) pw *= du;
+#pragma unroll
+    for (int jj = 0; jj < JN; ++jj) {
+      f[jj] = pw;
+      pw *= du;
+    }
+  };
+  // ---- store the fixed-point words of the wave's two units of one row set (as resample_i8t_kernel: four 256-byte runs)
+  auto store_x2 = [&](uint64_t bits0, uint64_t bits1, int off) {
+    const uint32_t lo0 = (uint32_t)bits0 ^ 0x80808080u, hi0 = (uint32_t)(bits0 >> 32) ^ 0x00008080u;
+    const uint32_t lo1 = (uint32_t)bits1 ^ 0x80808080u, hi1 = (uint32_t)(bits1 >> 32) ^ 0x00008080u;
+    asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                 "ds_write_addtid_b32 %0 offset:%5\n\t"
+                 "ds_write_addtid_b32 %1 offset:%6\n\t"
+                 "ds_write_addtid_b32 %2 offset:%7\n\t"
+                 "ds_write_addtid_b32 %3 offset:%8"
+                 :
+                 : "v"(lo0), "v"(hi0), "v"(lo1), "v"(hi1), "s"(wreg), "n"(off), "n"(off + T_PLANE + 128), "n"(off + 256),
+                   "n"(off + 256 + T_PLANE + 128)
+                 : "memory", "m0");
+  };
+  typedef __attribute__((address_space(3))) const double *lds_cd;
+  typedef __attribute__((address_space(3))) const v4i *lds_cv4;
+  // the words of chunk c + 1 for this wave's row sets (and its u-row fragment): dx of the lane's two samples, the factors
+  // `fac(entry, unit)`
+  auto produce = [&](const double (&dx)[2], auto &&fac) {
+    t_static_for<NSW>([&](auto fic) {
+      constexpr int fi = decltype(fic)::value;
+      if (row_live(fi)) {  // wave-uniform
+        const int j = g + fi * GS;
+        store_x2((uint64_t)__double_as_longlong(fma(fac(j, 0), dx[0], T_MAGIC)),
+                 (uint64_t)__double_as_longlong(fma(fac(j, 1), dx[1], T_MAGIC)), fi * T_PB);
+      }
+    });
+    if (has_ut)  // wave-uniform (ldexp + add: exact, as resample_i8t_kernel)
+      store_x2((uint64_t)__double_as_longlong(__builtin_ldexp(fac(umc, 0), 50) + T_MAGIC),
+               (uint64_t)__double_as_longlong(__builtin_ldexp(fac(umc, 1), 50) + T_MAGIC), NSW * T_PB);
+  };
+
+  // ================= prologue =================
+  // draws per replicate in the window (the top digit's bias is removed with them at the flush)
+  if (threadIdx.x < G_REPS) {
+    const int64_t r = rep0 + threadIdx.x;
+    uint32_t s = 0;
+    if (r < a.nrep)
+      for (int64_t t = t0; t < t1; ++t) s += a.counts[(size_t)r * a.ntiles + t];
+    fsum[threadIdx.x] = s;
+  }
+  // zero the X regions once (the padding between the planes is never written)
+  for (int e = threadIdx.x; e < T_WAVES * WREG / 16; e += T_BLOCK) reinterpret_cast<uint4 *>(lds)[e] = make_uint4(0, 0, 0, 0);
+  // chunk 0's u / w straight from memory (the direct path of resample_i8t_kernel)
+  double d_du[2], d_w[2] = {1.0, 1.0};
+  {
+    const int64_t i0 = chunk_sample(0);
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) {
+      d_du[uu] = (a.u[i0 + 16 * uu + ps] - pu) * inv_du;
+      if constexpr (WEIGHTED) d_w[uu] = a.w[i0 + 16 * uu + ps] * inv_w;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (nothing of the compiler's is in flight behind the DMAs below)
+  // blocks 0 .. D - 1 (and the raw u / w of blocks 0 .. D); chunk c lives in slot (c - 1) mod XSLOTS: chunk 0 in the last slot,
+  // block B's chunks 4 B + 1 .. 4 B + 4 in slots 4 (B mod NB) ...
+  x_request(XSLOTS - 1, lw == 0);  // (one more piece per quad on loader 0: the prologue waits for everything)
+#pragma unroll
+  for (int Bq = 0; Bq < D; ++Bq) {
+    raw_request(Bq);
+    a_request(Bq);
+#pragma unroll
+    for (int c = 0; c < G_BS; ++c) x_request(Bq * G_BS + c, lw == c / SPL);
+  }
+  raw_request(D);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  stage_factors(0);
+  const uint32_t x_va0 = (uint32_t)(OFF_X + quad * XSLOTS * 1024 + ps * 32 + cl * 8);
+  {
+    // the X words of chunk 0 (no matrix work yet): powers multiplied up from du / w of the direct path
+    double dx[2];
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) dx[uu] = (*(lds_cd)(lds + x_va0 + (XSLOTS - 1) * 1024 + uu * 512) - px) * sc;
+    produce(dx, [&](int j, int uu) {
+      double pw = WEIGHTED ? d_w[uu] : 1.0;
+      if constexpr (!WEIGHTED) asm volatile("" : "+v"(pw));  // (opaque: the staged arithmetic, two roundings -- see resample_i8t_kernel)
+      for (int q = 0; q < J0 + j; ++q) pw *= d_du[uu];
+      return pw;
+    });
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // factors of block 0 visible; chunk 0's x slot free
+
+  // ================= the blocks =================
+  // Step s = B * 4 + p contracts chunk s (count words: ring buffer B & 1, X words: the wave's regions) and slices chunk s + 1
+  // (x from ring slot (B & 1) * 4 + p, factors from buffer B % 3 line p).  The loader waves request block B + 1's count words and
+  // x, and block B + 2's raw u / w, at the top of block B; waves 6, 7 stage block B + 1's factors there.  ONE barrier per block,
+  // behind its last step: everything requested at the block's top has landed (every loader waited), the staged factors are
+  // visible, and nobody reads this block's ring halves any more.
+  uint32_t *pg = a.progress != nullptr ? a.progress + (size_t)win * 16 : nullptr;
+#ifdef TXM_GN_TIMING  // diagnostic build: cycles of one workgroup's waves in the block tops, the k-steps and at the barrier
+  long long tm_top = 0, tm_steps = 0, tm_bar = 0, tk = clock64();
+#define GN_TICK(v) do { const long long t1_ = clock64(); v += t1_ - tk; tk = t1_; } while (0)
+#else
+#define GN_TICK(v) do {} while (0)
+#endif
+#pragma unroll 1
+  for (int B = 0; B < nblk; ++B) {
+    if (pg != nullptr && wave == 0 && (B & 7) == 0) {  // L2-sharing hint (uniform; bounded, no result depends on it)
+      const uint32_t done = (uint32_t)(B >> 3) + 1u;
+      if (lane == 0) __hip_atomic_store(&pg[grp & 15], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll 1
+      for (int spin = 0; spin < I8_THROTTLE_SPINS; ++spin) {
+        if (done <= g_min_progress(pg) + G_LEAD) break;
+        __builtin_amdgcn_s_sleep(32);
+      }
+    }
+    stage_factors(B + 1);
+    raw_request(B + D + 1);
+    a_request(B + D);
+#pragma unroll
+    for (int i = 0; i < G_BS; ++i) x_request(((B + D) % NB) * G_BS + i, lw == i / SPL);
+    GN_TICK(tm_top);
+    const uint32_t a_va = (uint32_t)(OFF_A + (B % NB) * (G_BS * A_STEP)) + (uint32_t)lane * 16u;
+    const uint32_t f_va = (uint32_t)(OFF_F + (B % 3) * (2 * FU) + ps * NPT * 8);
+    const uint32_t x_va = x_va0 + (uint32_t)((B % NB) * G_BS * 1024);
+    if (any_work) {  // wave-uniform: a wave without a live power row set and without a u-row fragment only does the block's chores
+      // Operands one step AHEAD inside the block: the count words and the raw x of step p + 1 are requested from the LDS at the top
+      // of step p, behind this step's own B-operand reads (a wave's LDS operations complete in order) and in front of its MFMAs -- a
+      // step then starts with its operands in registers instead of a wait for six reads.  (Across the block's barrier nothing is
+      // read ahead: the next block's ring halves are only known to have landed behind it.)
+      // (instances whose waves hold two power row sets AND a u-row fragment -- twelve tiles, 192 registers -- have no room for the
+      // second set of count operands: they read a step's operands at its top; AHEAD instances are the ones with one row set a wave)
+      constexpr bool AHEAD = NSW == 1;
+      v4i A[AHEAD ? 2 : 1][NQ];
+      double xr[2][2];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) A[0][q] = *(lds_cv4)(lds + a_va + q * 1024);
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu) xr[0][uu] = *(lds_cd)(lds + x_va + uu * 512);
+      t_static_for<G_BS>([&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        constexpr int cur = p & 1, nxt = cur ^ 1;
+        constexpr int ac = AHEAD ? cur : 0, an = AHEAD ? nxt : 0;
+        // this step's B operands (the words of chunk s, stored a step ago): all of them up front where the registers allow
+        v2i Ba[NSW + 1], Bb[NSW + 1];
+        if constexpr (AHEAD) {
+#pragma unroll
+          for (int fi = 0; fi < NSW; ++fi)
+            if (row_live(fi)) {
+              Ba[fi] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB));
+              Bb[fi] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB + 128));
+            }
+          if (has_ut) {
+            Ba[NSW] = T_TRREAD((lds_v2i)(lds + rd_off + NSW * T_PB));
+            Bb[NSW] = T_TRREAD((lds_v2i)(lds + rd_off + NSW * T_PB + 128));
+          }
+        }
+        // the factors of the chunk this step slices
+        // (always the staged value, also the 1.0 of an unweighted power 0 -- as the quad-sharing variant of resample_i8t_kernel
+        // does: with the constant visible the compiler turns fma(1, dx, magic) into dx + magic and contracts it with dx's own
+        // multiply -- ONE rounding where the other kernel has two, and the words of a few per cent of the samples differ by a unit)
+        auto fac = [&](int j, int uu) -> double { return *(lds_cd)(lds + f_va + uu * FU + (p * 16 * NPT + j) * 8); };
+        double fr[NSW + 1][2];
+        if constexpr (AHEAD) {
+#pragma unroll
+          for (int fi = 0; fi < NSW; ++fi)
+            if (row_live(fi)) {
+              fr[fi][0] = fac(g + fi * GS, 0);
+              fr[fi][1] = fac(g + fi * GS, 1);
+            }
+          if (has_ut) {
+            fr[NSW][0] = fac(umc, 0);
+            fr[NSW][1] = fac(umc, 1);
+          }
+        }
+        // ... and step p + 1's raw x (and, AHEAD, its count words)
+        if constexpr (p + 1 < G_BS) {
+          if constexpr (AHEAD) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) A[an][q] = *(lds_cv4)(lds + a_va + (p + 1) * A_STEP + q * 1024);
+          }
+#pragma unroll
+          for (int uu = 0; uu < 2; ++uu) xr[nxt][uu] = *(lds_cd)(lds + x_va + (p + 1) * 1024 + uu * 512);
+        }
+        double dx[2];
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) dx[uu] = (xr[cur][uu] - px) * sc;
+        t_static_for<NSW>([&](auto fic) {
+          constexpr int fi = decltype(fic)::value;
+          if (row_live(fi)) {  // wave-uniform
+            if constexpr (!AHEAD) {
+              Ba[fi] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB));
+              Bb[fi] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB + 128));
+              fr[fi][0] = fac(g + fi * GS, 0);
+              fr[fi][1] = fac(g + fi * GS, 1);
+            }
+            const v4i Bv = {Ba[fi][0], Ba[fi][1], Bb[fi][0], Bb[fi][1]};
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) t_mfma<true>(acc[fi][q], A[ac][q], Bv);
+            // the words of chunk s + 1, row set fi: behind the MFMAs that took chunk s's (the region is single-buffered)
+            store_x2((uint64_t)__double_as_longlong(fma(fr[fi][0], dx[0], T_MAGIC)),
+                     (uint64_t)__double_as_longlong(fma(fr[fi][1], dx[1], T_MAGIC)), fi * T_PB);
+          }
+        });
+        if (has_ut) {  // wave-uniform: the u-row fragment
+          if constexpr (!AHEAD) {
+            Ba[NSW] = T_TRREAD((lds_v2i)(lds + rd_off + NSW * T_PB));
+            Bb[NSW] = T_TRREAD((lds_v2i)(lds + rd_off + NSW * T_PB + 128));
+            fr[NSW][0] = fac(umc, 0);
+            fr[NSW][1] = fac(umc, 1);
+          }
+          const v4i Bv = {Ba[NSW][0], Ba[NSW][1], Bb[NSW][0], Bb[NSW][1]};
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) t_mfma<true>(accu[q], A[ac][q], Bv);
+          store_x2((uint64_t)__double_as_longlong(__builtin_ldexp(fr[NSW][0], 50) + T_MAGIC),
+                   (uint64_t)__double_as_longlong(__builtin_ldexp(fr[NSW][1], 50) + T_MAGIC), NSW * T_PB);
+        }
+        if constexpr (!AHEAD && p + 1 < G_BS) {  // the next step's count words, into the registers this step has finished with
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) A[0][q] = *(lds_cv4)(lds + a_va + (p + 1) * A_STEP + q * 1024);
+        }
+      });
+    }
+    // the block's barrier: block B + 1's count words, x and block B + 2's raw u / w -- requested at the top of block B + 1 - D -- have
+    // landed when at most the pieces of the D - 1 block tops since then are in flight (a wave's DMAs complete in order; waves 4..7
+    // issue none)
+    GN_TICK(tm_steps);
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((D - 1) * PIECES) : "memory");
+    GN_TICK(tm_bar);
+  }
+
+#ifdef TXM_GN_TIMING
+  if (lane == 0 && blockIdx.x == 16 && blockIdx.y == 0)
+    printf("wave %d  blocks %d  top %lld  steps %lld  barrier %lld cycles per block\n", wave, nblk, tm_top / nblk, tm_steps / nblk, tm_bar / nblk);
+#endif
+  // ================= flush: int32 accumulators of the window -> its slot of the partial sums =================
+  // D layout of v_mfma_i32_32x32x32_i8: column = lane & 31, row = 8 * (reg / 4) + 4 * (lane >> 5) + reg % 4
+  if (pg != nullptr && threadIdx.x == 0) __hip_atomic_store(&pg[grp & 15], 0xfffffff0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  auto flush_tile = [&](v16i &T, int q, int rs, bool urow) {
+    uint32_t z = 0;
+    asm volatile("" : "+v"(z));  // opaque zero: the addresses are formed where they are used, not hoisted and spilled
+    const int64_t opq = (int64_t)z;
+    const int64_t rrow = rep0 + 32 * q + 4 * half;
+    bool valid = tdg < I8_NSL;
+    int j;
+    double dsc;
+    double *base;
+    size_t stride;
+    const int64_t cpad = a.cpad;
+    if (!urow) {
+      const int c = 4 * quad + tcl;
+      const bool live = row_live(rs);
+      valid = valid && c < a.C && live;
+      j = J0 + (live ? g + rs * GS : 0);
+      dsc = wt[I8_WT_DSP + j] * wt[I8_WT_DSC + (c < a.C ? c : 0)];
+      base = a.part_x + ((((size_t)win * a.nrep_pad + rrow) * K + j) * 8 + tdg) * cpad + c + opq;
+      stride = (size_t)K * cpad * 8;
+    } else {
+      const int m = 4 * fu + tcl;
+      valid = valid && m < JN;
+      j = J0 + (m < JN ? m : 0);
+      dsc = wt[I8_WT_DSP + j] * 0x1p-50;
+      base = a.part_u + (((size_t)win * a.nrep_pad + rrow) * K + j) * 8 + tdg + opq;
+      stride = (size_t)K * 8;
+    }
+    dsc *= (double)((int64_t)1 << (8 * (tdg < I8_NSL ? tdg : 0)));
+    const int bias = tdg == I8_NSL - 1 ? T_D6_BIAS : 0;
+    if (valid) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r >> 2) * 8 + (r & 3);
+        if (rrow + m < a.nrep) {
+          const int v = T[r] - bias * (int)fsum[32 * q + m + 4 * half];
+          base[(size_t)m * stride] = (double)v * dsc;
+        }
+      }
+    }
+  };
+#pragma unroll
+  for (int fi = 0; fi < NSW; ++fi)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) flush_tile(acc[fi][q], q, fi, false);
+  if (has_ut) {  // wave-uniform
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) flush_tile(accu[q], q, 0, true);
+  }
+}
+
+// ---------------------------------------------------------------------------
+template <int J0, int JN, bool WEIGHTED, int NCQ>
+static int launch_pass_gn(const I8Args &a, int K, const unsigned char *table, int64_t rep_begin, int n_grp, size_t table_state_stride,
+                          hipStream_t st) {
+  constexpr int GS = T_WAVES / NCQ, NSW = (JN + GS - 1) / GS;
+  constexpr int D = NCQ == 4 ? 2 : 3, NB = D + 1;   // (the kernel's DMA lead and ring depth)
+  const size_t lds = (size_t)T_WAVES * (NSW + 1) * T_PB + (size_t)NB * G_BS * 4 * 1024 + (size_t)NCQ * NB * G_BS * 1024 + (size_t)(D + 2) * G_RAW +
+                     3 * 2 * (size_t)(G_BS * 16 * JN * 8 + 136) + G_REPS * sizeof(uint32_t);
+  const int64_t S = a.states != nullptr ? a.S : 1;
+  const dim3 grid((unsigned)(cdiv(a.nwin, 8) * 8 * n_grp), (unsigned)S);
+  if (a.progress != nullptr) TXM_HIP(hipMemsetAsync(a.progress, 0, (size_t)cdiv(a.nwin, 8) * 8 * 16 * sizeof(uint32_t), st));
+  if (a.states != nullptr) {
+    TXM_SET_MAX_LDS((&resample_i8gn_kernel<J0, JN, WEIGHTED, NCQ, true>), lds);
+    hipLaunchKernelGGL((resample_i8gn_kernel<J0, JN, WEIGHTED, NCQ, true>), grid, dim3(T_BLOCK), lds, st, a, K, table, rep_begin, n_grp,
+                       table_state_stride);
+  } else {
+    TXM_SET_MAX_LDS((&resample_i8gn_kernel<J0, JN, WEIGHTED, NCQ, false>), lds);
+    hipLaunchKernelGGL((resample_i8gn_kernel<J0, JN, WEIGHTED, NCQ, false>), grid, dim3(T_BLOCK), lds, st, a, K, table, rep_begin, n_grp,
+                       table_state_stride);
+  }
+  TXM_LAUNCH_CHECK();
+  return TXM_OK;
+}
+
+// what the narrow table kernel takes: whole column quads readable inside a row through 16-byte DMA pieces, orders 1 .. 7
+bool i8gn_applicable(const double *x, int64_t ldx_s, int64_t C, int K) {
+  if (C < 1 || C > 16 || K < 2 || K > 8) return false;
+  const int64_t cq = (C + 3) / 4 * 4;
+  if (((uintptr_t)x & 15) != 0 || (ldx_s & 1) != 0 || cq > ldx_s) return false;
+  return true;
+}
+
+// the passes of a narrow state over the count table of replicate groups [rep_begin, rep_begin + 128 n_grp): a wave holds at most
+// three power row sets (two where it also carries a u-row fragment), so one quad takes every order in one pass, two quads
+// orders 1..7 in one pass (order 7: two), four quads orders 1..3 in one pass and 4..7 in two
+template <int NCQ>
+static int launch_gn_t(const I8Args &a, int K, bool weighted, const unsigned char *table, int64_t rep_begin, int n_grp,
+                       size_t table_state_stride, hipStream_t st) {
+#define GN_PASS(J0_, JN_) (weighted ? launch_pass_gn<J0_, JN_, true, NCQ>(a, K, table, rep_begin, n_grp, table_state_stride, st) \
+                                    : launch_pass_gn<J0_, JN_, false, NCQ>(a, K, table, rep_begin, n_grp, table_state_stride, st))
+  // powers a pass can take: the u-row waves (the last ceil(JN / 4)) hold NSW + 1 row sets <= 3
+  constexpr int GS = T_WAVES / NCQ;
+  constexpr int JMAX = 2 * GS < 8 ? 2 * GS : 8;  // NSW <= 2 everywhere: every wave may carry a u-row fragment
+  int rc = TXM_OK;
+  if (K <= JMAX) {
+    switch (K) {
+      case 2: return GN_PASS(0, 2);
+      case 3: return GN_PASS(0, 3);
+      case 4: return GN_PASS(0, 4);
+      case 5: if constexpr (JMAX >= 5) return GN_PASS(0, 5); break;
+      case 6: if constexpr (JMAX >= 6) return GN_PASS(0, 6); break;
+      case 7: if constexpr (JMAX >= 7) return GN_PASS(0, 7); break;
+      case 8: if constexpr (JMAX >= 8) return GN_PASS(0, 8); break;
+      default: break;
+    }
+  } else if constexpr (JMAX == 4) {  // four quads: 4 + (K - 4) powers
+    rc = GN_PASS(0, 4);
+    if (rc != TXM_OK) return rc;
+    switch (K) {
+      case 5: return GN_PASS(4, 1);
+      case 6: return GN_PASS(4, 2);
+      case 7: return GN_PASS(4, 3);
+      case 8: return GN_PASS(4, 4);
+      default: break;
+    }
+  }
+#undef GN_PASS
+  set_error("resample_i8gn: order out of range");
+  return TXM_ERR_INVALID;
+}
+
+int launch_resample_i8gn(const I8Args &a, int K, bool weighted, const unsigned char *table, int64_t rep_begin, int n_grp,
+                         size_t table_state_stride, hipStream_t st) {
+  const int nq = i8t_narrow_nq(a.C_call, K);
+  if (nq == 1) return launch_gn_t<1>(a, K, weighted, table, rep_begin, n_grp, table_state_stride, st);
+  if (nq == 2) return launch_gn_t<2>(a, K, weighted, table, rep_begin, n_grp, table_state_stride, st);
+  if (nq == 4) return launch_gn_t<4>(a, K, weighted, table, rep_begin, n_grp, table_state_stride, st);
+  set_error("resample_i8gn: not a narrow state");
+  return TXM_ERR_INVALID;
+}
+
+}  // namespace txm

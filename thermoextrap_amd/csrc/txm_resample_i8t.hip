@@ -310,7 +310,13 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       auto factor = [&](int fi, int uu) {  // row set fi = power J0 + g + fi GS
         if (NQ == 8 && !WEIGHTED && J0 == 0 && fi == 0) return 1.0;
         if (staged) return pt_at(pt_b, fi * GS + T_PUNIT * NPT * uu);
+        // (narrow states: the 1.0 of an unweighted power 0 is kept OPAQUE on this direct path of a window's first chunk.  Where a
+        // wave's first power is a compile-time 0 -- four quads in two chunk groups: one wave per quad and group -- the compiler
+        // otherwise folds fma(1, dx, magic) into dx + magic and contracts that with dx's own multiply: ONE rounding for these 32
+        // samples where every staged chunk has two, and the words then depend on which chunk a chunk group starts a window with.
+        // With it the direct path is the staged arithmetic, and resample_i8gn_kernel -- one chunk group -- agrees bit for bit)
         double pw = WEIGHTED ? d_w[uu] : 1.0;
+        if constexpr (NQ < 8 && !WEIGHTED) asm volatile("" : "+v"(pw));
         for (int q = 0; q < J0 + g + fi * GS; ++q) pw *= d_du[uu];
         return pw;
       };

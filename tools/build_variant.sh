@@ -10,6 +10,7 @@ O=tools/build/$(basename "$OUT" .so)_$(basename "$SRC" .hip).o
 EXTRA=""
 if [ "$SRC" = txm_sampler.hip ]; then EXTRA="-ffp-contract=off"; fi
 if [ "$SRC" = txm_resample_i8t.hip ]; then EXTRA="-mllvm -amdgpu-mfma-vgpr-form -Wno-inline-asm"; fi   # as thermoextrap_amd/_build.py
+if [ "$SRC" = txm_resample_i8gn.hip ]; then EXTRA="-mllvm -amdgpu-mfma-vgpr-form -mllvm -greedy-regclass-priority-trumps-globalness=1 -Wno-inline-asm"; fi
 if [ "$SRC" = txm_resample_i8g.hip ]; then EXTRA="-mllvm -amdgpu-mfma-vgpr-form -mllvm -greedy-regclass-priority-trumps-globalness=1 -Wno-inline-asm"; fi
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-pass-failed $EXTRA "$@" -c $C/$SRC -o $O
 OBJS=""

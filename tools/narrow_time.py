@@ -14,6 +14,8 @@ what = sys.argv[1] if len(sys.argv) > 1 else "both"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 txa.require_gpu(0)
 tag = os.path.basename(os.environ.get("TXM_LIBRARY", "default"))
+KP = os.environ.get("TXM_KPATH")  # int8_table / int8_fused: the int8 kernel of the narrow launch (None: the library's rule)
+tag += f" [{KP}]" if KP else ""
 
 
 def med(fn):
@@ -34,7 +36,7 @@ if what in ("c2", "both"):
     s = engine.DeviceSampler(0, nrep, N)
     prep = engine.ResamplePrep()
     o = torch.empty((nrep, C, 2, order + 1), dtype=torch.float64, device="cuda")
-    m, lo = med(lambda: engine.resample_vals(x, u, order, sampler=s, out=o, prep=prep))
+    m, lo = med(lambda: engine.resample_vals(x, u, order, sampler=s, out=o, prep=prep, path=KP))
     out.append(f"c2 call {m:6.3f} ms (min {lo:6.3f}) [{engine.resample_info()['kernel']}]")
     del x, u
 if what in ("c5", "both"):
@@ -42,6 +44,6 @@ if what in ("c5", "both"):
     xs, us = zip(*[_state_xu(torch, s_, N, C) for s_ in range(S)])
     smp = engine.DeviceSampler(1, S * nrep, N)
     prep = engine.ResamplePrep()
-    m, lo = med(lambda: engine.resample_vals_batched(list(xs), list(us), order, nrep=nrep, sampler=smp, prep=prep))
+    m, lo = med(lambda: engine.resample_vals_batched(list(xs), list(us), order, nrep=nrep, sampler=smp, prep=prep, path=KP))
     out.append(f"c5 batched call {m:6.3f} ms (min {lo:6.3f}) [{engine.batched_info().get('path')}]")
 print("  ".join(out), flush=True)
