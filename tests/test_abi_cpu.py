@@ -229,9 +229,12 @@ def test_dispatch_rule_matches_the_header_thresholds(lib):
     assert W(N, 32, 130, 2, AUTO, 0) == W(N, 32, 130, 2, FUSED, 0)      # 130 -> 256 against 192
     assert W(N, 32, 100, 2, AUTO, 0) == W(N, 32, 100, 2, TABLE, 0)      # 100 -> 128 either way
     assert W(N, 32, 260, 2, AUTO, 0) == W(N, 32, 260, 2, TABLE, 0)      # 260 -> 384 against 320
-    # narrow states: the table kernel of txm_resample_i8gn.hip on request only (order >= 1), never by the rule
+    # narrow states: the table kernel of txm_resample_i8gn.hip (order >= 1) from two replicate groups on where 128s pad no worse than 64s
     assert table(1000) <= W(N, 8, 1000, 2, TABLE, 0) - W(N, 8, 1000, 2, FUSED, 0) < table(1000) + 4096
-    assert W(N, 8, 1000, 2, AUTO, 0) == W(N, 8, 1000, 2, FUSED, 0)
+    assert W(N, 8, 1000, 2, AUTO, 0) == W(N, 8, 1000, 2, TABLE, 0) and W(N, 8, 200, 4, AUTO, 0) == W(N, 8, 200, 4, TABLE, 0)
+    assert W(N, 8, 128, 2, AUTO, 0) == W(N, 8, 128, 2, FUSED, 0) and W(N, 8, 130, 2, AUTO, 0) == W(N, 8, 130, 2, FUSED, 0)
+    assert W(N, 16, 1000, 4, AUTO, 0) == W(N, 16, 1000, 4, FUSED, 0)    # four column quads at order 4: two table passes against one
+    assert W(500_000, 8, 1000, 2, AUTO, 0) == W(500_000, 8, 1000, 2, FUSED, 0)  # short series
     assert W(N, 8, 1000, 0, TABLE, 0) == W(N, 8, 1000, 0, FUSED, 0)     # order 0 of a narrow state: no int8 kernel at all
     assert W(N, 32, 1000, 2, FP64, 0) <= W(N, 32, 1000, 2, FUSED, 0)
     assert lib.txm_sampler_count_table_bytes(N, 1000) == table(1000)
@@ -251,11 +254,12 @@ def test_kernel_word_is_what_a_prep_block_is_keyed_on(lib):
     assert Kn(N, 32, 64, 6, -1, 1, 1) == FUSED | WY and Kn(N, 32, 1000, 6, -1, 1, 1) == TABLE | WY
     # without y: orders 3 and 4 from two replicate groups on
     assert Kn(N, 32, 128, 4, -1, 0, 1) == FUSED and Kn(N, 32, 256, 4, -1, 0, 1) == TABLE and Kn(N, 32, 1000, 2, -1, 0, 1) == TABLE
-    # a forced path is honoured (a slab of 40 replicates of a table call), misaligned operands never ride the table; narrow states
-    # (txm_resample_i8gn.hip) on request only, and a second matrix never rides a narrow call
+    # a forced path is honoured (a slab of 40 replicates of a table call), misaligned operands never ride the table; a second matrix
+    # never rides a narrow call (txm_resample_i8gn.hip)
     assert Kn(N, 32, 40, 4, TABLE, 1, 1) == TABLE | WY and Kn(N, 32, 1000, 4, FUSED, 1, 1) == FUSED
     assert Kn(N, 32, 1000, 4, -1, 1, 0) == FUSED and Kn(N, 32, 1000, 4, TABLE, 0, 0) == FUSED
-    assert Kn(N, 8, 1000, 3, -1, 1, 1) == FUSED and Kn(N, 8, 1000, 3, TABLE, 0, 1) == TABLE and Kn(N, 8, 1000, 3, TABLE, 1, 1) == TABLE
+    assert Kn(N, 8, 1000, 3, -1, 1, 1) == TABLE and Kn(N, 8, 100, 3, -1, 0, 1) == FUSED and Kn(N, 8, 1000, 3, FUSED, 0, 1) == FUSED
+    assert Kn(N, 8, 40, 3, TABLE, 0, 1) == TABLE and Kn(N, 8, 1000, 3, TABLE, 1, 1) == TABLE and Kn(N, 8, 1000, 3, -1, 0, 0) == FUSED
     assert Kn(N, 8, 1000, 3, TABLE, 0, 0) == FUSED and Kn(N, 8, 1000, 0, TABLE, 0, 1) == FUSED  # (order 0: no narrow variant)
     assert Kn(N, 32, 16, 4, -1, 0, 1) == FP64 and Kn(N, 32, 1000, 4, FP64, 1, 1) == FP64 and Kn(N, 32, 1000, 8, -1, 0, 1) == FP64
     assert Kn(0, 32, 1000, 4, -1, 0, 1) == FP64

@@ -85,3 +85,18 @@ def test_narrow_table_rows_equal_offset_call_and_padded_rows(eng):
     part = eng.resample_vals(x, u, order, sampler=s.rows(128, 300), path="int8_table")
     assert torch.equal(whole[128:300], part)
     assert torch.equal(whole, eng.resample_vals(x.contiguous(), u, order, sampler=s, path="int8_fused"))
+
+
+def test_rule_takes_the_narrow_table_from_two_replicate_groups_on(eng):
+    """Left to the library (path=None) a long narrow series rides the table kernel from two 128-replicate groups on, the fused one
+    below (tools/narrow_table_sweep.py; txm_resample.hip narrow_table_pays) -- and the choice does not move a bit."""
+    N, C, order = 1_000_000, 8, 4                 # BASELINE config 2's state shape, a tenth of its length
+    x, u = data(N, C, 41)
+    s = eng.DeviceSampler(5, 200, N)
+    auto = eng.resample_vals(x, u, order, sampler=s)
+    assert eng.resample_info()["kernel"] == "int8_table"
+    assert torch.equal(auto, eng.resample_vals(x, u, order, sampler=s, path="int8_fused"))
+    eng.resample_vals(x, u, order, sampler=eng.DeviceSampler(5, 128, N))
+    assert eng.resample_info()["kernel"] == "int8_fused"
+    eng.resample_vals(x[:500_000], u[:500_000], order, sampler=eng.DeviceSampler(5, 200, 500_000))
+    assert eng.resample_info()["kernel"] == "int8_fused"

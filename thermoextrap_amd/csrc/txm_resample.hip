@@ -869,17 +869,15 @@ static bool table_kernel_pays(int64_t nrep, int K, bool has_y) {
 // txm_resample_kernel (what the host keys a kept pre-pass block on): `eff` is the call's path after the process-wide
 // override, `applicable` = i8g_applicable() of the operands.  The call additionally needs the table's bytes in its workspace.
 // Narrow states (C <= 16): the table-fed kernel of txm_resample_i8gn.hip (128 replicates per workgroup, no fill phase) against the
-// quad-sharing variant of the kernel that draws in place -- bit for bit the same sums, so again a rule on speed alone (measured
-// on MI355X, tools/narrow_time.py; profiles/r06_experiments.md section 2).
+// quad-sharing variant of the kernel that draws in place -- bit for bit the same sums, so again a rule on speed alone.  Measured on
+// MI355X (tools/narrow_table_sweep.py: N = 1e6 and 1e7, C = 4 .. 16, orders 1 .. 6, 64 .. 1000 replicates;
+// profiles/r06_narrow_table_sweep.txt): 0.6 - 0.9 x at 64 replicates (the padding to 128 doubles the work), 0.9 - 1.2 x with ONE
+// group of 128 (the generator is a launch of its own there: 100 and 128 replicates), 1.0 - 1.27 x from two groups on -- except where
+// the table kernel takes two passes over the counts and the fused one a single pass (four column quads at order 4: 0.92 - 1.0 x).
 static bool narrow_table_pays(int64_t N, int64_t C, int64_t nrep, int K) {
-#ifdef TXM_NARROW_TABLE_AUTO
-  (void)C; (void)K;
   const int64_t pad128 = cdiv(nrep, G_REPS) * G_REPS, pad64 = cdiv(nrep, I8_REPS) * I8_REPS;
-  return N >= 786432 && 4 * pad128 <= 5 * pad64;
-#else
-  (void)N; (void)C; (void)nrep; (void)K;
-  return false;
-#endif
+  if (N < 786432 || nrep <= G_REPS || pad128 > pad64) return false;
+  return !(i8t_narrow_nq(C, K) == 4 && K == 5);
 }
 static bool table_call_rule(size_t table_bytes, int eff, int64_t N, int64_t C, int64_t nrep, int K, bool has_y, bool applicable) {
   if (eff == TXM_PATH_FP64 || eff == TXM_PATH_INT8_FUSED || table_bytes == 0 || !applicable) return false;

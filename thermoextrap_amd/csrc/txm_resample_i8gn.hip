@@ -65,35 +65,64 @@ struct GnRoles {
   static_assert(idle() < 2 || first_idle(1) == first_idle(0) + 1, "idle waves are consecutive");
 };
 
+// The shape of one instance: what a wave holds, the depth of the rings, the LDS map (shared by the kernel and its launcher).
+// A wave's matrix work is a list of SLOTS, each four accumulator tiles (one per replicate quarter): its power rows g, g + GS, ...
+// first, then -- on the last UF waves -- one u-row fragment.  A slot's fixed-point word is fma(factor, m, magic) with m = dx for a
+// power row and 2^50 for a u-row monomial (= the ldexp + add of resample_i8t_kernel, bit for bit: the product is exact either way).
+template <int JN, int NCQ, bool WEIGHTED>
+struct GnGeom {
+  static constexpr int GS = T_WAVES / NCQ, UF = (JN + 3) / 4, NQ = 4, NPT = JN;
+  static constexpr int rows(int w) { return w / NCQ < JN ? (JN - 1 - w / NCQ) / GS + 1 : 0; }
+  static constexpr int slots(int w) { return rows(w) + (w >= T_WAVES - UF ? 1 : 0); }
+  static constexpr int max_slots() {
+    int m = 0;
+    for (int w = 0; w < T_WAVES; ++w) m = slots(w) > m ? slots(w) : m;
+    return m;
+  }
+  static constexpr int MAXS = max_slots();
+  // k-steps a wave takes TOGETHER.  A narrow k-step is a handful of MFMAs between two LDS round trips (read the words stored a step
+  // ago -- contract -- store the next ones): with one workgroup on the CU and one or two working waves on a SIMD nothing hides them
+  // (phase clocks of the first cut, one power row a wave: 460 cycles a k-step for 4 MFMAs).  With two X regions a wave the words are
+  // sliced TWO chunks ahead: a pair of k-steps reads both regions' words, both steps' count words, factors and x in one go, issues
+  // the MFMAs of both, then stores the two chunks after next -- one round trip per pair.  (Twelve tiles -- three slots -- leave no
+  // registers for the second set of operands: those instances take their k-steps one at a time.)
+  static constexpr int W = MAXS <= 2 ? 2 : 1;
+  static constexpr int WREG = W * MAXS * T_PB;       // a wave's X regions: [step of the pair][slot]
+  static constexpr int A_STEP = NQ * 1024;           // count words of one k-step: [quarter][1024]
+  static constexpr int FU = G_BS * 16 * NPT * 8 + 136;  // bytes between the factor lines of a lane's two 16-sample units
+  static constexpr int lds_bytes(int d) {
+    return T_WAVES * WREG + (d + 1) * G_BS * A_STEP + NCQ * (d + 1) * G_BS * 1024 + (d + 2) * G_RAW + 3 * 2 * FU + G_REPS * 4;
+  }
+  // DMA lead: a narrow k-step is short (200-600 cycles), and a request to HBM takes 2-3 us to land -- the ONE block of lead
+  // resample_i8g_kernel lives on (its k-steps take 1800 cycles) left every block's barrier waiting for the DMA (first cut: 1200
+  // cycles a k-step for 20 MFMAs).  Block B + D is requested at the top of block B, into rings of D + 1 blocks: three blocks
+  // where the CU's 160 KiB hold them.
+  static constexpr int D = NCQ < 4 && lds_bytes(3) <= 160 * 1024 ? 3 : 2;
+  static constexpr int NB = D + 1, XSLOTS = NB * G_BS, NR = D + 2;
+  static constexpr int OFF_A = T_WAVES * WREG;                 // [NB][G_BS][A_STEP]
+  static constexpr int OFF_X = OFF_A + NB * G_BS * A_STEP;     // [quad][XSLOTS][32 samples][4 columns] doubles
+  static constexpr int OFF_RAW = OFF_X + NCQ * XSLOTS * 1024;  // [NR][u | w][G_BS * 32] doubles
+  static constexpr int OFF_F = OFF_RAW + NR * G_RAW;           // [3][unit][FU]: line (chunk-in-block, sample) x NPT factors
+  static constexpr int OFF_FS = OFF_F + 3 * 2 * FU;            // [128] draws per replicate in the window
+  static constexpr int LDS = OFF_FS + G_REPS * 4;
+  static_assert(LDS == lds_bytes(D) && LDS <= 160 * 1024, "the instance fits the CU's LDS");
+  static_assert(T_WAVES * WREG <= 65536, "X regions within the first 64 KiB (ds_write_addtid takes its base from M0[15:0])");
+  static_assert(MAXS >= 1 && MAXS <= 3 && UF <= 2, "at most twelve accumulator tiles a wave");
+};
+
 template <int J0, int JN, bool WEIGHTED, int NCQ, bool BATCHED = false>
 __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void resample_i8gn_kernel(
     const I8Args a_in, const int K, const unsigned char *__restrict__ table_in, const int64_t rep_begin, const int n_grp,
     const size_t table_state_stride) {
   static_assert(NCQ == 1 || NCQ == 2 || NCQ == 4, "column quads of a narrow state");
-  constexpr int GS = T_WAVES / NCQ;            // waves per quad = stride of a wave's powers
-  constexpr int NSW = (JN + GS - 1) / GS;      // power row sets per wave
-  constexpr int UF = (JN + 3) / 4;             // u-row fragments (four monomials each)
-  constexpr int NQ = 4;                        // replicate quarters (A operands, tiles per row set)
-  constexpr int NPT = JN;                      // staged factors per sample
-  static_assert(JN >= 1 && J0 + JN <= 8 && NSW <= 3 && UF <= 2, "power range");
-  static_assert(NSW + 1 <= 3 || UF == 0, "a wave with a u-row fragment holds at most two power row sets (12 tiles)");
-  constexpr int WREG = (NSW + 1) * T_PB;       // a wave's X region: its power row sets + one u-row fragment
-  // DMA lead: a narrow k-step is short (a few MFMAs a wave: 200-600 cycles), and a request to HBM takes 2-3 us to land -- the ONE
-  // block of lead resample_i8g_kernel lives on (its k-steps take 1800 cycles) left every block's barrier waiting for the DMA
-  // (first cut: 1200 cycles a k-step for 20 MFMAs).  Block B + D is requested at the top of block B, into rings of D + 1 blocks.
-  constexpr int D = NCQ == 4 ? 2 : 3, NB = D + 1;
-  constexpr int A_STEP = NQ * 1024;            // count words of one k-step: [quarter][1024]
-  constexpr int OFF_A = T_WAVES * WREG;        // [NB][G_BS][A_STEP]
-  constexpr int XSLOTS = NB * G_BS;            // chunks in a quad's x ring
-  constexpr int OFF_X = OFF_A + NB * G_BS * A_STEP;           // [quad][XSLOTS][32 samples][4 columns] doubles
-  constexpr int NR = D + 2;                                   // raw buffers: requested D + 1 blocks ahead of their k-steps
-  constexpr int OFF_RAW = OFF_X + NCQ * XSLOTS * 1024;        // [NR][u | w][G_BS * 32] doubles
-  constexpr int FU = G_BS * 16 * NPT * 8 + 136;               // bytes between the factor lines of a lane's two 16-sample units
-  constexpr int OFF_F = OFF_RAW + NR * G_RAW;                 // [3][unit][FU]: line (chunk-in-block, sample) x NPT factors
+  static_assert(JN >= 1 && J0 + JN <= 8, "power range");
+  using Geo = GnGeom<JN, NCQ, WEIGHTED>;
+  constexpr int GS = Geo::GS, UF = Geo::UF, NQ = Geo::NQ, NPT = Geo::NPT, MAXS = Geo::MAXS, W = Geo::W;
+  constexpr int D = Geo::D, NB = Geo::NB, XSLOTS = Geo::XSLOTS, NR = Geo::NR, A_STEP = Geo::A_STEP, FU = Geo::FU;
+  constexpr int OFF_A = Geo::OFF_A, OFF_X = Geo::OFF_X, OFF_RAW = Geo::OFF_RAW, OFF_F = Geo::OFF_F, OFF_FS = Geo::OFF_FS;
   // DMA pieces a loader wave issues at the top of a block: the count words, the x of every quad and the raw u / w of its block steps
   constexpr int PIECES = (G_BS / GnRoles<JN, NCQ>::NLD) * (NQ + NCQ + (WEIGHTED ? 2 : 1));
-  constexpr int OFF_FS = OFF_F + 3 * 2 * FU;                  // [128] draws per replicate in the window
-  static_assert(T_WAVES * WREG <= 65536, "X regions within the first 64 KiB (ds_write_addtid takes its base from M0[15:0])");
+  static_assert((D - 1) * PIECES < 64, "the block barrier's vmcnt");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   uint32_t *fsum = reinterpret_cast<uint32_t *>(lds + OFF_FS);
 
@@ -107,13 +136,13 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int n32 = lane & 31, half = lane >> 5;
-  const uint32_t wreg = (uint32_t)(wave * WREG);
+  const uint32_t wreg = (uint32_t)(wave * Geo::WREG);
   const int quad = wave % NCQ, g = wave / NCQ;  // the wave's column quad and its first power (relative to J0)
-  auto row_live = [&](int fi) { return g + fi * GS < JN; };
-  // u-row fragment fu on wave 7 - fu (wave-uniform)
+  // the wave's slots (all wave-uniform): nrows power rows, then the u-row fragment fu on wave 7 - fu
+  const int nrows = g < JN ? (JN - 1 - g) / GS + 1 : 0;
   const bool has_ut = wave >= T_WAVES - UF;
   const int fu = has_ut ? T_WAVES - 1 - wave : 0;
-  const bool any_work = has_ut || g < JN;  // wave-uniform
+  const int nslots = nrows + (has_ut ? 1 : 0);
 
   // ---- which window, which replicate group (the groups of a window share an XCD: b and b + 8 land on the same one)
   const int b = blockIdx.x;
@@ -138,6 +167,8 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const int tcl = (n32 >> 2) & 3, tdg = 4 * (n32 >> 4) + (n32 & 3);
   const int um = 4 * fu + cl;             // this lane's u-row monomial
   const int umc = um < JN ? um : 0;       // (the unused slots of a short fragment repeat monomial 0: never flushed)
+  // the factor a slot's word takes (index into a sample's line of NPT staged factors)
+  auto slot_power = [&](int s) { return s < nrows ? g + s * GS : umc; };
 
   const double *wt = a.wtab + win * I8_WT_STRIDE;
   const double pu = a.pivot[0];
@@ -146,14 +177,11 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const double sc = wt[I8_WT_SC + ccol];
   const double px = a.pivot[1 + a.col0 + ccol];
 
-  v16i acc[NSW][NQ];
-  v16i accu[NQ];
+  v16i acc[MAXS][NQ];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
+  for (int s = 0; s < MAXS; ++s)
 #pragma unroll
-    for (int e = 0; e < NSW; ++e) acc[e][q] = (v16i)(0);
-    accu[q] = (v16i)(0);
-  }
+    for (int q = 0; q < NQ; ++q) acc[s][q] = (v16i)(0);
 
   // first sample of chunk c of the window (the last tile of the series slides its window back)
   auto chunk_sample = [&](int c) -> int64_t {
@@ -161,7 +189,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (b0 > a.N - SM_T) b0 = a.N - SM_T;
     return b0 + 32 * (c & 31);
   };
-  // ---- requests (loader waves 0..3: the older wave of every SIMD, as in resample_i8g_kernel)
+  // ---- requests
   constexpr int LOAD0 = GnRoles<JN, NCQ>::LOAD0, STAGE0 = GnRoles<JN, NCQ>::STAGE0, NLD = GnRoles<JN, NCQ>::NLD;
   constexpr int SPL = G_BS / NLD;                         // block steps per loader wave
   const bool loader = wave >= LOAD0 && wave < LOAD0 + NLD;  // uniform
@@ -187,7 +215,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       else xq += xstep;
     }
   };
-  // count words of block B -> ring buffer B & 1: loader wave w the four 1-KiB pieces of the block's k-step w
+  // count words of block B -> ring buffer B % NB: a loader wave the four 1-KiB pieces of each of its block steps
   auto a_request = [&](int B) {
     if (!loader) return;
     const int Bc = B < nblk ? B : nblk - 1;
@@ -201,21 +229,21 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       for (int Q = 0; Q < NQ; ++Q) g_dma16(src + (size_t)Q * 1024, l16, dst + (uint32_t)(Q * 1024));
     }
   };
-  // raw u / w of factor block B (the chunks B * G_BS + 1 .. B * G_BS + G_BS: what block B's k-steps slice): loader wave w chunk w
+  // raw u / w of factor block B (the chunks B * G_BS + W .. B * G_BS + W + G_BS - 1: what block B's k-steps slice)
   auto raw_request = [&](int B) {
     if (!loader) return;
     const uint32_t l4 = g_lane_now() * 4u;
 #pragma unroll
     for (int k = 0; k < SPL; ++k) {
       const int st = lw * SPL + k;
-      int c = B * G_BS + 1 + st;
+      int c = B * G_BS + W + st;
       if (c > nsteps - 1) c = nsteps - 1;
       const int64_t i0 = chunk_sample(c);
       g_dma4(a.u + i0, l4, (uint32_t)(OFF_RAW + (B % NR) * G_RAW + st * 256));
       if constexpr (WEIGHTED) g_dma4(a.w + i0, l4, (uint32_t)(OFF_RAW + (B % NR) * G_RAW + G_BS * 256 + st * 256));
     }
   };
-  // factors of block B from raw buffer B % 3 into factor buffer B % 3 (waves 6 and 7, one sample per lane)
+  // factors of block B from raw buffer B % NR into factor buffer B % 3 (two waves, one sample per lane)
   auto stage_factors = [&](int B) {
     if (wave < STAGE0 || wave >= STAGE0 + 2) return;  // uniform
     const int e = (int)g_lane_now() + (wave - STAGE0) * 64;  // entry: chunk-in-block e >> 5, sample e & 31
@@ -231,7 +259,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       pw *= du;
     }
   };
-  // ---- store the fixed-point words of the wave's two units of one row set (as resample_i8t_kernel: four 256-byte runs)
+  // ---- store the fixed-point words of the wave's two units of one slot (as resample_i8t_kernel: four 256-byte runs)
   auto store_x2 = [&](uint64_t bits0, uint64_t bits1, int off) {
     const uint32_t lo0 = (uint32_t)bits0 ^ 0x80808080u, hi0 = (uint32_t)(bits0 >> 32) ^ 0x00008080u;
     const uint32_t lo1 = (uint32_t)bits1 ^ 0x80808080u, hi1 = (uint32_t)(bits1 >> 32) ^ 0x00008080u;
@@ -247,20 +275,19 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   };
   typedef __attribute__((address_space(3))) const double *lds_cd;
   typedef __attribute__((address_space(3))) const v4i *lds_cv4;
-  // the words of chunk c + 1 for this wave's row sets (and its u-row fragment): dx of the lane's two samples, the factors
-  // `fac(entry, unit)`
-  auto produce = [&](const double (&dx)[2], auto &&fac) {
-    t_static_for<NSW>([&](auto fic) {
-      constexpr int fi = decltype(fic)::value;
-      if (row_live(fi)) {  // wave-uniform
-        const int j = g + fi * GS;
-        store_x2((uint64_t)__double_as_longlong(fma(fac(j, 0), dx[0], T_MAGIC)),
-                 (uint64_t)__double_as_longlong(fma(fac(j, 1), dx[1], T_MAGIC)), fi * T_PB);
+  // the words of one chunk into region `R` (a step of the pair) of the wave's slots: dx of the lane's two samples, the factors
+  // `fac(slot, unit)`
+  auto produce = [&](auto rc, const double (&dx)[2], auto &&fac) {
+    constexpr int R = decltype(rc)::value;
+    t_static_for<MAXS>([&](auto sc_) {
+      constexpr int s = decltype(sc_)::value;
+      if (s < nslots) {  // wave-uniform
+        const bool row = s < nrows;
+        const double m0 = row ? dx[0] : 0x1p50, m1 = row ? dx[1] : 0x1p50;
+        store_x2((uint64_t)__double_as_longlong(fma(fac(s, 0), m0, T_MAGIC)),
+                 (uint64_t)__double_as_longlong(fma(fac(s, 1), m1, T_MAGIC)), (R * MAXS + s) * T_PB);
       }
     });
-    if (has_ut)  // wave-uniform (ldexp + add: exact, as resample_i8t_kernel)
-      store_x2((uint64_t)__double_as_longlong(__builtin_ldexp(fac(umc, 0), 50) + T_MAGIC),
-               (uint64_t)__double_as_longlong(__builtin_ldexp(fac(umc, 1), 50) + T_MAGIC), NSW * T_PB);
   };
 
   // ================= prologue =================
@@ -273,21 +300,24 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     fsum[threadIdx.x] = s;
   }
   // zero the X regions once (the padding between the planes is never written)
-  for (int e = threadIdx.x; e < T_WAVES * WREG / 16; e += T_BLOCK) reinterpret_cast<uint4 *>(lds)[e] = make_uint4(0, 0, 0, 0);
-  // chunk 0's u / w straight from memory (the direct path of resample_i8t_kernel)
-  double d_du[2], d_w[2] = {1.0, 1.0};
-  {
-    const int64_t i0 = chunk_sample(0);
+  for (int e = threadIdx.x; e < T_WAVES * Geo::WREG / 16; e += T_BLOCK) reinterpret_cast<uint4 *>(lds)[e] = make_uint4(0, 0, 0, 0);
+  // the first W chunks' u / w straight from memory (the direct path of resample_i8t_kernel)
+  double d_du[W][2], d_w[W][2];
+#pragma unroll
+  for (int r = 0; r < W; ++r) {
+    const int64_t i0 = chunk_sample(r);
 #pragma unroll
     for (int uu = 0; uu < 2; ++uu) {
-      d_du[uu] = (a.u[i0 + 16 * uu + ps] - pu) * inv_du;
-      if constexpr (WEIGHTED) d_w[uu] = a.w[i0 + 16 * uu + ps] * inv_w;
+      d_du[r][uu] = (a.u[i0 + 16 * uu + ps] - pu) * inv_du;
+      d_w[r][uu] = 1.0;
+      if constexpr (WEIGHTED) d_w[r][uu] = a.w[i0 + 16 * uu + ps] * inv_w;
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (nothing of the compiler's is in flight behind the DMAs below)
-  // blocks 0 .. D - 1 (and the raw u / w of blocks 0 .. D); chunk c lives in slot (c - 1) mod XSLOTS: chunk 0 in the last slot,
-  // block B's chunks 4 B + 1 .. 4 B + 4 in slots 4 (B mod NB) ...
-  x_request(XSLOTS - 1, lw == 0);  // (one more piece per quad on loader 0: the prologue waits for everything)
+  // blocks 0 .. D - 1 (and the raw u / w of blocks 0 .. D); chunk c lives in slot (c - W) mod XSLOTS: the first W chunks in the
+  // last slots, block B's chunks 4 B + W .. 4 B + W + 3 in slots 4 (B mod NB) ...
+#pragma unroll
+  for (int r = 0; r < W; ++r) x_request(XSLOTS - W + r, lw == 0);  // (W more pieces per quad on loader 0: the prologue waits for everything)
 #pragma unroll
   for (int Bq = 0; Bq < D; ++Bq) {
     raw_request(Bq);
@@ -299,26 +329,28 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   stage_factors(0);
   const uint32_t x_va0 = (uint32_t)(OFF_X + quad * XSLOTS * 1024 + ps * 32 + cl * 8);
-  {
-    // the X words of chunk 0 (no matrix work yet): powers multiplied up from du / w of the direct path
+  // the X words of the first W chunks (no matrix work yet): powers multiplied up from du / w of the direct path
+  t_static_for<W>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
     double dx[2];
 #pragma unroll
-    for (int uu = 0; uu < 2; ++uu) dx[uu] = (*(lds_cd)(lds + x_va0 + (XSLOTS - 1) * 1024 + uu * 512) - px) * sc;
-    produce(dx, [&](int j, int uu) {
-      double pw = WEIGHTED ? d_w[uu] : 1.0;
+    for (int uu = 0; uu < 2; ++uu) dx[uu] = (*(lds_cd)(lds + x_va0 + (XSLOTS - W + r) * 1024 + uu * 512) - px) * sc;
+    produce(rc, dx, [&](int s, int uu) {
+      double pw = d_w[r][uu];
       if constexpr (!WEIGHTED) asm volatile("" : "+v"(pw));  // (opaque: the staged arithmetic, two roundings -- see resample_i8t_kernel)
-      for (int q = 0; q < J0 + j; ++q) pw *= d_du[uu];
+      const int n = J0 + slot_power(s);
+      for (int q = 0; q < n; ++q) pw *= d_du[r][uu];
       return pw;
     });
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // factors of block 0 visible; chunk 0's x slot free
+  });
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // factors of block 0 visible; the first chunks' x slots free
 
   // ================= the blocks =================
-  // Step s = B * 4 + p contracts chunk s (count words: ring buffer B & 1, X words: the wave's regions) and slices chunk s + 1
-  // (x from ring slot (B & 1) * 4 + p, factors from buffer B % 3 line p).  The loader waves request block B + 1's count words and
-  // x, and block B + 2's raw u / w, at the top of block B; waves 6, 7 stage block B + 1's factors there.  ONE barrier per block,
-  // behind its last step: everything requested at the block's top has landed (every loader waited), the staged factors are
-  // visible, and nobody reads this block's ring halves any more.
+  // Step s = B * 4 + p contracts chunk s (count words: ring buffer B % NB, X words: region p % W of the wave) and slices chunk s + W
+  // into the same region (x from ring slot (B % NB) * 4 + p, factors from buffer B % 3 line p).  The loader waves request block
+  // B + D's count words and x, and block B + D + 1's raw u / w, at the top of block B; two waves stage block B + 1's factors there.
+  // ONE barrier per block, behind its last step: what was requested D - 1 block tops ago has landed (every loader waited), the
+  // staged factors are visible, and nobody reads this block's ring parts any more.
   uint32_t *pg = a.progress != nullptr ? a.progress + (size_t)win * 16 : nullptr;
 #ifdef TXM_GN_TIMING  // diagnostic build: cycles of one workgroup's waves in the block tops, the k-steps and at the barrier
   long long tm_top = 0, tm_steps = 0, tm_bar = 0, tk = clock64();
@@ -326,6 +358,10 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #else
 #define GN_TICK(v) do {} while (0)
 #endif
+  // per-lane byte offset of a slot's factor inside a sample's line
+  uint32_t f_slot[MAXS];
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s) f_slot[s] = (uint32_t)(slot_power(s) * 8);
 #pragma unroll 1
   for (int B = 0; B < nblk; ++B) {
     if (pg != nullptr && wave == 0 && (B & 7) == 0) {  // L2-sharing hint (uniform; bounded, no result depends on it)
@@ -346,107 +382,87 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const uint32_t a_va = (uint32_t)(OFF_A + (B % NB) * (G_BS * A_STEP)) + (uint32_t)lane * 16u;
     const uint32_t f_va = (uint32_t)(OFF_F + (B % 3) * (2 * FU) + ps * NPT * 8);
     const uint32_t x_va = x_va0 + (uint32_t)((B % NB) * G_BS * 1024);
-    if (any_work) {  // wave-uniform: a wave without a live power row set and without a u-row fragment only does the block's chores
-      // Operands one step AHEAD inside the block: the count words and the raw x of step p + 1 are requested from the LDS at the top
-      // of step p, behind this step's own B-operand reads (a wave's LDS operations complete in order) and in front of its MFMAs -- a
-      // step then starts with its operands in registers instead of a wait for six reads.  (Across the block's barrier nothing is
-      // read ahead: the next block's ring halves are only known to have landed behind it.)
-      // (instances whose waves hold two power row sets AND a u-row fragment -- twelve tiles, 192 registers -- have no room for the
-      // second set of count operands: they read a step's operands at its top; AHEAD instances are the ones with one row set a wave)
-      constexpr bool AHEAD = NSW == 1;
-      v4i A[AHEAD ? 2 : 1][NQ];
-      double xr[2][2];
+    if (nslots > 0) {  // wave-uniform: a wave without a slot only does the block's chores
+      if constexpr (W == 1) {
+        // twelve tiles: a step's count words and x at its top, each slot's words and factors where the slot takes them
+        t_static_for<G_BS>([&](auto pc) {
+          constexpr int p = decltype(pc)::value;
+          v4i A[NQ];
+          double dx[2];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) A[0][q] = *(lds_cv4)(lds + a_va + q * 1024);
+          for (int q = 0; q < NQ; ++q) A[q] = *(lds_cv4)(lds + a_va + p * A_STEP + q * 1024);
 #pragma unroll
-      for (int uu = 0; uu < 2; ++uu) xr[0][uu] = *(lds_cd)(lds + x_va + uu * 512);
-      t_static_for<G_BS>([&](auto pc) {
-        constexpr int p = decltype(pc)::value;
-        constexpr int cur = p & 1, nxt = cur ^ 1;
-        constexpr int ac = AHEAD ? cur : 0, an = AHEAD ? nxt : 0;
-        // this step's B operands (the words of chunk s, stored a step ago): all of them up front where the registers allow
-        v2i Ba[NSW + 1], Bb[NSW + 1];
-        if constexpr (AHEAD) {
+          for (int uu = 0; uu < 2; ++uu) dx[uu] = (*(lds_cd)(lds + x_va + p * 1024 + uu * 512) - px) * sc;
+          t_static_for<MAXS>([&](auto sc_) {
+            constexpr int s = decltype(sc_)::value;
+            if (s < nslots) {  // wave-uniform
+              const v2i Ba = T_TRREAD((lds_v2i)(lds + rd_off + s * T_PB)), Bb = T_TRREAD((lds_v2i)(lds + rd_off + s * T_PB + 128));
+              const double f0 = *(lds_cd)(lds + f_va + f_slot[s] + p * 16 * NPT * 8), f1 = *(lds_cd)(lds + f_va + f_slot[s] + FU + p * 16 * NPT * 8);
+              const v4i Bv = {Ba[0], Ba[1], Bb[0], Bb[1]};
 #pragma unroll
-          for (int fi = 0; fi < NSW; ++fi)
-            if (row_live(fi)) {
-              Ba[fi] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB));
-              Bb[fi] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB + 128));
+              for (int q = 0; q < NQ; ++q) t_mfma<true>(acc[s][q], A[q], Bv);
+              const bool row = s < nrows;
+              store_x2((uint64_t)__double_as_longlong(fma(f0, row ? dx[0] : 0x1p50, T_MAGIC)),
+                       (uint64_t)__double_as_longlong(fma(f1, row ? dx[1] : 0x1p50, T_MAGIC)), s * T_PB);
             }
-          if (has_ut) {
-            Ba[NSW] = T_TRREAD((lds_v2i)(lds + rd_off + NSW * T_PB));
-            Bb[NSW] = T_TRREAD((lds_v2i)(lds + rd_off + NSW * T_PB + 128));
-          }
-        }
-        // the factors of the chunk this step slices
-        // (always the staged value, also the 1.0 of an unweighted power 0 -- as the quad-sharing variant of resample_i8t_kernel
+          });
+        });
+      } else
+      t_static_for<G_BS / W>([&](auto gc) {
+        constexpr int p0 = decltype(gc)::value * W;
+        // every operand of the W steps up front: the X words stored a pair ago, the count words, and what the next slicing takes
+        v2i Ba[W][MAXS], Bb[W][MAXS];
+        v4i A[W][NQ];
+        double fr[W][MAXS][2], xr[W][2];
+#pragma unroll
+        for (int r = 0; r < W; ++r)
+#pragma unroll
+          for (int s = 0; s < MAXS; ++s)
+            if (s < nslots) {
+              Ba[r][s] = T_TRREAD((lds_v2i)(lds + rd_off + (r * MAXS + s) * T_PB));
+              Bb[r][s] = T_TRREAD((lds_v2i)(lds + rd_off + (r * MAXS + s) * T_PB + 128));
+            }
+#pragma unroll
+        for (int r = 0; r < W; ++r)
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) A[r][q] = *(lds_cv4)(lds + a_va + (p0 + r) * A_STEP + q * 1024);
+        // (always the staged factor, also the 1.0 of an unweighted power 0 -- as the quad-sharing variant of resample_i8t_kernel
         // does: with the constant visible the compiler turns fma(1, dx, magic) into dx + magic and contracts it with dx's own
         // multiply -- ONE rounding where the other kernel has two, and the words of a few per cent of the samples differ by a unit)
-        auto fac = [&](int j, int uu) -> double { return *(lds_cd)(lds + f_va + uu * FU + (p * 16 * NPT + j) * 8); };
-        double fr[NSW + 1][2];
-        if constexpr (AHEAD) {
 #pragma unroll
-          for (int fi = 0; fi < NSW; ++fi)
-            if (row_live(fi)) {
-              fr[fi][0] = fac(g + fi * GS, 0);
-              fr[fi][1] = fac(g + fi * GS, 1);
+        for (int r = 0; r < W; ++r) {
+#pragma unroll
+          for (int s = 0; s < MAXS; ++s)
+            if (s < nslots) {
+#pragma unroll
+              for (int uu = 0; uu < 2; ++uu) fr[r][s][uu] = *(lds_cd)(lds + f_va + f_slot[s] + uu * FU + (p0 + r) * 16 * NPT * 8);
             }
-          if (has_ut) {
-            fr[NSW][0] = fac(umc, 0);
-            fr[NSW][1] = fac(umc, 1);
-          }
+#pragma unroll
+          for (int uu = 0; uu < 2; ++uu) xr[r][uu] = *(lds_cd)(lds + x_va + (p0 + r) * 1024 + uu * 512);
         }
-        // ... and step p + 1's raw x (and, AHEAD, its count words)
-        if constexpr (p + 1 < G_BS) {
-          if constexpr (AHEAD) {
+        t_static_for<W>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          t_static_for<MAXS>([&](auto sc_) {
+            constexpr int s = decltype(sc_)::value;
+            if (s < nslots) {  // wave-uniform
+              const v4i Bv = {Ba[r][s][0], Ba[r][s][1], Bb[r][s][0], Bb[r][s][1]};
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) A[an][q] = *(lds_cv4)(lds + a_va + (p + 1) * A_STEP + q * 1024);
-          }
-#pragma unroll
-          for (int uu = 0; uu < 2; ++uu) xr[nxt][uu] = *(lds_cd)(lds + x_va + (p + 1) * 1024 + uu * 512);
-        }
-        double dx[2];
-#pragma unroll
-        for (int uu = 0; uu < 2; ++uu) dx[uu] = (xr[cur][uu] - px) * sc;
-        t_static_for<NSW>([&](auto fic) {
-          constexpr int fi = decltype(fic)::value;
-          if (row_live(fi)) {  // wave-uniform
-            if constexpr (!AHEAD) {
-              Ba[fi] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB));
-              Bb[fi] = T_TRREAD((lds_v2i)(lds + rd_off + fi * T_PB + 128));
-              fr[fi][0] = fac(g + fi * GS, 0);
-              fr[fi][1] = fac(g + fi * GS, 1);
+              for (int q = 0; q < NQ; ++q) t_mfma<true>(acc[s][q], A[r][q], Bv);
             }
-            const v4i Bv = {Ba[fi][0], Ba[fi][1], Bb[fi][0], Bb[fi][1]};
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) t_mfma<true>(acc[fi][q], A[ac][q], Bv);
-            // the words of chunk s + 1, row set fi: behind the MFMAs that took chunk s's (the region is single-buffered)
-            store_x2((uint64_t)__double_as_longlong(fma(fr[fi][0], dx[0], T_MAGIC)),
-                     (uint64_t)__double_as_longlong(fma(fr[fi][1], dx[1], T_MAGIC)), fi * T_PB);
-          }
+          });
         });
-        if (has_ut) {  // wave-uniform: the u-row fragment
-          if constexpr (!AHEAD) {
-            Ba[NSW] = T_TRREAD((lds_v2i)(lds + rd_off + NSW * T_PB));
-            Bb[NSW] = T_TRREAD((lds_v2i)(lds + rd_off + NSW * T_PB + 128));
-            fr[NSW][0] = fac(umc, 0);
-            fr[NSW][1] = fac(umc, 1);
-          }
-          const v4i Bv = {Ba[NSW][0], Ba[NSW][1], Bb[NSW][0], Bb[NSW][1]};
+        // the words of chunks s + W: behind the MFMAs that took chunk s's (their B operands are in registers by then)
+        t_static_for<W>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          double dx[2];
 #pragma unroll
-          for (int q = 0; q < NQ; ++q) t_mfma<true>(accu[q], A[ac][q], Bv);
-          store_x2((uint64_t)__double_as_longlong(__builtin_ldexp(fr[NSW][0], 50) + T_MAGIC),
-                   (uint64_t)__double_as_longlong(__builtin_ldexp(fr[NSW][1], 50) + T_MAGIC), NSW * T_PB);
-        }
-        if constexpr (!AHEAD && p + 1 < G_BS) {  // the next step's count words, into the registers this step has finished with
-#pragma unroll
-          for (int q = 0; q < NQ; ++q) A[0][q] = *(lds_cv4)(lds + a_va + (p + 1) * A_STEP + q * 1024);
-        }
+          for (int uu = 0; uu < 2; ++uu) dx[uu] = (xr[r][uu] - px) * sc;
+          produce(rc, dx, [&](int s, int uu) { return fr[r][s][uu]; });
+        });
       });
     }
     // the block's barrier: block B + 1's count words, x and block B + 2's raw u / w -- requested at the top of block B + 1 - D -- have
-    // landed when at most the pieces of the D - 1 block tops since then are in flight (a wave's DMAs complete in order; waves 4..7
-    // issue none)
+    // landed when at most the pieces of the D - 1 block tops since then are in flight (a wave's DMAs complete in order)
     GN_TICK(tm_steps);
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((D - 1) * PIECES) : "memory");
     GN_TICK(tm_bar);
@@ -459,7 +475,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // ================= flush: int32 accumulators of the window -> its slot of the partial sums =================
   // D layout of v_mfma_i32_32x32x32_i8: column = lane & 31, row = 8 * (reg / 4) + 4 * (lane >> 5) + reg % 4
   if (pg != nullptr && threadIdx.x == 0) __hip_atomic_store(&pg[grp & 15], 0xfffffff0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  auto flush_tile = [&](v16i &T, int q, int rs, bool urow) {
+  auto flush_tile = [&](v16i &T, int q, int s) {
     uint32_t z = 0;
     asm volatile("" : "+v"(z));  // opaque zero: the addresses are formed where they are used, not hoisted and spilled
     const int64_t opq = (int64_t)z;
@@ -470,15 +486,14 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     double *base;
     size_t stride;
     const int64_t cpad = a.cpad;
-    if (!urow) {
+    if (s < nrows) {  // a power row
       const int c = 4 * quad + tcl;
-      const bool live = row_live(rs);
-      valid = valid && c < a.C && live;
-      j = J0 + (live ? g + rs * GS : 0);
+      valid = valid && c < a.C;
+      j = J0 + g + s * GS;
       dsc = wt[I8_WT_DSP + j] * wt[I8_WT_DSC + (c < a.C ? c : 0)];
       base = a.part_x + ((((size_t)win * a.nrep_pad + rrow) * K + j) * 8 + tdg) * cpad + c + opq;
       stride = (size_t)K * cpad * 8;
-    } else {
+    } else {  // the u-row fragment
       const int m = 4 * fu + tcl;
       valid = valid && m < JN;
       j = J0 + (m < JN ? m : 0);
@@ -500,23 +515,18 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
   };
 #pragma unroll
-  for (int fi = 0; fi < NSW; ++fi)
+  for (int s = 0; s < MAXS; ++s)
+    if (s < nslots) {  // wave-uniform
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) flush_tile(acc[fi][q], q, fi, false);
-  if (has_ut) {  // wave-uniform
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) flush_tile(accu[q], q, 0, true);
-  }
+      for (int q = 0; q < NQ; ++q) flush_tile(acc[s][q], q, s);
+    }
 }
 
 // ---------------------------------------------------------------------------
 template <int J0, int JN, bool WEIGHTED, int NCQ>
 static int launch_pass_gn(const I8Args &a, int K, const unsigned char *table, int64_t rep_begin, int n_grp, size_t table_state_stride,
                           hipStream_t st) {
-  constexpr int GS = T_WAVES / NCQ, NSW = (JN + GS - 1) / GS;
-  constexpr int D = NCQ == 4 ? 2 : 3, NB = D + 1;   // (the kernel's DMA lead and ring depth)
-  const size_t lds = (size_t)T_WAVES * (NSW + 1) * T_PB + (size_t)NB * G_BS * 4 * 1024 + (size_t)NCQ * NB * G_BS * 1024 + (size_t)(D + 2) * G_RAW +
-                     3 * 2 * (size_t)(G_BS * 16 * JN * 8 + 136) + G_REPS * sizeof(uint32_t);
+  const size_t lds = (size_t)GnGeom<JN, NCQ, WEIGHTED>::LDS;
   const int64_t S = a.states != nullptr ? a.S : 1;
   const dim3 grid((unsigned)(cdiv(a.nwin, 8) * 8 * n_grp), (unsigned)S);
   if (a.progress != nullptr) TXM_HIP(hipMemsetAsync(a.progress, 0, (size_t)cdiv(a.nwin, 8) * 8 * 16 * sizeof(uint32_t), st));
