@@ -297,7 +297,7 @@ def pmc_traffic(kernel_prefix, shape):
 # the finalize kernels, the info word; the count-table generator on the table path; the pre-pass when the caller's block
 # is not reused.  Every one of them runs once per 32-column group except the generator, the pivot and the info kernel.
 _CALL_KERNELS = {
-    "int8_table": ("txm::count_table_kernel", "txm::resample_i8g_kernel", "txm::resample_i8t_kernel"),
+    "int8_table": ("txm::count_table_kernel", "txm::resample_i8g_kernel", "txm::resample_i8gn_kernel", "txm::resample_i8t_kernel"),
     "int8_fused": ("txm::resample_i8t_kernel",),
 }
 _CALL_COMMON = ("txm::resample_finalize_i8_kernel", "txm::resample_finalize_y_kernel", "txm::i8_info_kernel")
@@ -327,7 +327,8 @@ def pmc_call_traffic(shape, int8_kernel, prepass=False):
     hits, stale = _traffic_files(shape)
     for d, src in hits:
         total, per = call_traffic(d.get("kernels", {}), int8_kernel, shape[1], prepass)
-        main_kernel = "txm::resample_i8g_kernel" if int8_kernel == "int8_table" else "txm::resample_i8t_kernel"
+        # (wide states: txm_resample_i8g.hip; narrow states, C <= 16: txm_resample_i8gn.hip)
+        main_kernel = ("txm::resample_i8gn_kernel" if shape[1] <= 16 else "txm::resample_i8g_kernel") if int8_kernel == "int8_table" else "txm::resample_i8t_kernel"
         if any(k.startswith(main_kernel) for k in per):   # (a summary of this shape that saw the call's contraction kernel)
             return total, per, src
     return None, None, stale
@@ -556,7 +557,16 @@ def main():
                  "byte-transposed by the LDS transposing read (ds_read_b64_tr_b8: 8 digit slots per word, 7 used), "
                  "exact int32 accumulation, Philox stage 3 fused")
         ksteps = -(-nrep_rank // 64) * (-(-N // 1024) * 32) * -(-C // 32)   # replicate groups x k-steps x column groups
-        if info.get("kernel") == "int8_table":
+        if info.get("kernel") == "int8_table" and C <= 16:
+            # txm_resample_i8gn.hip: workgroup = 128 replicates x the state's 1, 2 or 4 column quads; per k-step 4 replicate
+            # quarters x (quads x powers + u-row fragments of four monomials) MFMAs; four quads take orders >= 4 in two passes
+            passes = [4, K - 4] if (nq == 4 and K >= 5) else [K]
+            n_mfma = sum(4 * (nq * jn + -(-jn // 4)) for jn in passes)
+            kname = "txm::resample_i8gn_kernel"
+            kdesc = (what + "bootstrap contraction on the int8 matrix pipe over a count table in HBM (txm::count_table_kernel, part of "
+                     f"the timed call): 128 replicates per workgroup, {len(passes)} pass(es), operands by LDS-DMA, two k-steps per LDS round trip")
+            ksteps = -(-nrep_rank // 128) * (-(-N // 1024) * 32)
+        elif info.get("kernel") == "int8_table":
             # txm_resample_i8g.hip: workgroup = 128 replicates x 32 columns; per k-step 4 replicate quarters x 8 column quads
             # per row set, the u-row in the words' dead byte (no extra MFMAs); K power row sets (+ the second matrix's) over
             # the fewest passes of <= 3; the count table of the call generated once (txm::count_table_kernel, inside the call)

@@ -212,14 +212,17 @@ int txm_sampler_count_table(const txm_sampler_spec *spec_host, const uint32_t *c
  *     - WIDE states, C > 16 (a last group of 1..16 columns behind full 32-column groups is allowed from order 1; at order 0
  *       it keeps the call on FP64): long series (N >= 786432) from nrep >= 32 at order >= 1 and nrep >= 100 at order 0;
  *       shorter series from nrep >= 64 at order >= 3, 128 at orders 1-2, 384 at order 0.
- *   Inside the int8 path two contraction kernels serve wide states and agree BIT FOR BIT (same int32 sums, same flush):
+ *   Inside the int8 path two contraction kernels serve every state and agree BIT FOR BIT (same int32 sums, same flush):
  *     - the kernel that draws the per-sample counts in place (64 replicates per workgroup; orders 0-4 one pass over the
- *       sampler stream, 5-7 two): orders 3 and 4 without a second matrix at nrep <= 128, replicate counts that pad badly to 128
- *       (4 * ceil128(nrep) > 5 * ceil64(nrep)), misaligned operands (x not 16-byte aligned or an odd row pitch), and
- *       every narrow state;
- *     - the count-table kernel (128 replicates per workgroup, at most three row sets per pass over ONE table of per-sample
- *       counts, txm_sampler_count_table; every call with a second matrix rides it): all other wide calls whose workspace
- *       holds the table (txm_resample_vals_ws_bytes_opts).  TXM_PATH_INT8_FUSED / TXM_PATH_INT8_TABLE force one of them.
+ *       sampler stream, 5-7 two): wide states at orders 3 and 4 without a second matrix at nrep <= 128, replicate counts that
+ *       pad badly to 128 (4 * ceil128(nrep) > 5 * ceil64(nrep)), misaligned operands (x not 16-byte aligned or an odd row
+ *       pitch); narrow states at nrep <= 128, where 128s pad worse than 64s (ceil128(nrep) > ceil64(nrep)), N < 786432, 13-16
+ *       observables at order 4, a row shorter than a whole column quad (C = 1..3 in a tight array);
+ *     - the count-table kernels (128 replicates per workgroup over ONE table of per-sample counts, txm_sampler_count_table --
+ *       wide states: at most three row sets per pass, every call with a second matrix rides it; narrow states: the column
+ *       quads and powers of the state in one pass, two for four quads from order 4): all other calls whose workspace holds the
+ *       table (txm_resample_vals_ws_bytes_opts).  TXM_PATH_INT8_FUSED / TXM_PATH_INT8_TABLE force one of them;
+ *       txm_resample_kernel reports the choice for a shape.
  *                  PRECISION GUARD (data dependent, automatic): the pre-pass also takes, per window, a robust
  *                  typical magnitude of the top-power monomial (the smallest of 64 group means of
  *                  |w du^order dx_c|); a window whose scale exceeds 275 sqrt(n) times it -- a heavy tail, an
@@ -232,11 +235,11 @@ int txm_sampler_count_table(const txm_sampler_spec *spec_host, const uint32_t *c
  * share no mutable state and are re-entrant per (workspace, stream).
  *
  * txm_resample_opts (HOST struct, NULL = all defaults):
- *   path        TXM_PATH_AUTO / TXM_PATH_FP64 / TXM_PATH_INT8 (/ _INT8_FUSED / _INT8_TABLE: which int8 kernel serves wide states) for this call.
+ *   path        TXM_PATH_AUTO / TXM_PATH_FP64 / TXM_PATH_INT8 (/ _INT8_FUSED / _INT8_TABLE: which int8 kernel) for this call.
  *   info        DEVICE pointer to 4 int64 (nullable), written on the stream, no synchronisation:
  *               [0] path taken, [1] scaling windows x column groups, [2] how many of them the precision guard sent
- *               to the FP64 kernel, [3] bit 0: the pre-pass tables came from `prep` (below) instead of being computed; bit 1: the wide
- *               column groups ran the count-table kernel (else the kernel that draws in place).
+ *               to the FP64 kernel, [3] bit 0: the pre-pass tables came from `prep` (below) instead of being computed; bit 1: the
+ *               column groups ran a count-table kernel (else the kernel that draws in place).
  *   prep, prep_bytes, prep_valid
  *               The int8 path's pre-pass (pivot + per-window scale table, guard flags and fallback list) depends on
  *               (x, u, w, pivot, N, C, nrep, order) only -- not on the sampler -- and costs one more read of the samples.

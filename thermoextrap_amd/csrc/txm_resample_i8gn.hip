@@ -9,16 +9,20 @@
 // Why.  The narrow-state launches of the kernel that draws in place are bound by what ONE workgroup per CU can overlap between
 // its barriers (profiles/r06_experiments.md section 2: fill 31-35 % of the call, slicing 25-28 %, the parts add), and the
 // 64 KiB count tile of a 1024-sample sampler tile rules out both a 128-replicate workgroup (128 KiB of the CU's 160) and a
-// second resident workgroup.  Fed from the table a workgroup needs no count tile at all -- a 32 KiB ring of count words --
-// so it takes 128 replicates (every sliced word feeds four MFMAs instead of two, every chore of a k-step serves twice the
-// replicates), has no fill phase, no zeroing, no per-tile barriers; the generator runs at the same Philox-bound rate as the
-// fill it replaces, with four waves per SIMD.
+// second resident workgroup.  Fed from the table a workgroup needs no count tile at all -- a ring of count words -- so it takes
+// 128 replicates (every sliced word feeds four MFMAs instead of two, every chore of a k-step serves twice the replicates), has no
+// fill phase, no zeroing, no per-tile barriers; the generator runs at the Philox-bound rate of the fill it replaces.
+// What it costs: the table crosses HBM twice (one byte per replicate and sample, written by the generator, read here), which for a
+// narrow state is 10-30 x the samples themselves -- measured against the fused kernel (tools/narrow_table_sweep.py,
+// profiles/r06_narrow_table_sweep.txt) the pair generator + this kernel is 1.0-1.27 x faster from two replicate groups on, even at
+// one group, slower at 64 replicates; the dispatch rule (txm_resample.hip narrow_table_pays) follows those numbers.
 //
 // Workgroup = 8 waves x 128 replicates x NCQ column quads (1, 2 or 4) x the powers J0 .. J0 + JN - 1.  The GS = 8 / NCQ waves
 // that share a quad split the powers (wave w: quad w % NCQ, powers g, g + GS, ... with g = w / NCQ); the S0 monomials w du^j
-// (dx = 1) are u-row fragments of four monomials x eight digit slots on the LAST waves (the ones with the fewest powers).
-// Counts, x, u and w arrive by LDS-DMA as in resample_i8g_kernel: waves 0..3 request a block of four k-steps at a time, one
-// s_barrier per block; the x ring is per QUAD (the waves of a quad read the same chunk).
+// (dx = 1) are u-row fragments of four monomials x eight digit slots on the LAST waves (the ones with the fewest powers).  Each
+// of these is a SLOT of four accumulator tiles (GnGeom below); waves with at most two slots take their k-steps in pairs.
+// Counts, x, u and w arrive by LDS-DMA as in resample_i8g_kernel: the loader waves (GnRoles) request a block of four k-steps at
+// a time, two or three blocks ahead, one s_barrier per block; the x ring is per QUAD (the waves of a quad read the same chunk).
 // The int32 sums of a window are exact and the flush is the expression of resample_i8t_kernel: the two kernels agree BIT FOR
 // BIT (tests/test_i8gn_gpu.py).
 #include "txm_i8g.h"

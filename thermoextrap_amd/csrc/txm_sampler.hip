@@ -209,28 +209,45 @@ __device__ __forceinline__ uint32_t split_left(uint32_t k0, uint32_t k1, const S
 // leaves left to right and splits the nodes it enters on the way down (depth-first; the pending right siblings of the
 // path sit in a D-entry stack in LDS).  All lanes run the same loop -- the tree has one shape -- so the only divergence
 // is inside a split (empty nodes, the rejection loop).
-// grid nrep, block TR_THREADS, dynamic LDS: heap[2^(L0+1)] + stack[(D + 1) * TR_THREADS]
-constexpr int TR_THREADS = 256;
-constexpr int TR_DEPTH = 5;    // lane-private subtree depth (when the tree is deeper than that)
+// A node's variate is a function of (level, index, replicate) alone: D and the workgroup size are execution parameters, the
+// table does not depend on them.  D = k - log2(threads) gives every lane a subtree (round 6: a fixed D = 5 left 32 of 256
+// lanes busy on the 977-tile series of BASELINE config 5 -- 5 + 63 dependent splits a replicate where 8 + 3 do; 690 us of
+// an 8 ms step); calls with few replicates take 1024 threads a replicate and several workgroups a replicate (below).
+// grid (nrep, 2^M), block THREADS, dynamic LDS: heap[2^(L0+1)] + stack[(D + 1) * THREADS]
 constexpr int TR_MAX_L0 = 13;  // the heap of the top levels: 2^(L0+1) words of LDS
+// log2 of the workgroups a replicate may be cut into.  The kernel takes any M (the tables do not depend on it), the launcher uses 0:
+// measured at N = 1e7, 200 replicates, four workgroups a replicate took 0.27 ms against 0.19 ms with one -- the dependent splits of
+// the top levels are the chain either way, and every part repeats its own path from the root.
+constexpr int TR_MAX_M = 0;
 
-__global__ __launch_bounds__(TR_THREADS) void sampler_tree_kernel(uint32_t k0, uint32_t k1key, uint32_t nsamp,
-                                                                  SamplerGeom g, uint32_t rep0, int D,
-                                                                  uint32_t *__restrict__ counts) {
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void sampler_tree_kernel(uint32_t k0, uint32_t k1key, uint32_t nsamp,
+                                                               SamplerGeom g, uint32_t rep0, int D, int M,
+                                                               uint32_t *__restrict__ counts) {
   extern __shared__ uint32_t tree_lds[];
-  const int k = g.k, L0 = k - D;
-  uint32_t *heap = tree_lds;                       // levels 0 .. L0, heap indexed
-  uint32_t *stk = heap + ((size_t)2 << L0);        // [D + 1][TR_THREADS]
+  // this workgroup's part of the replicate's tree: the subtree under node (M, part) -- 2^M workgroups a replicate where the
+  // replicates alone do not fill the chip; each walks the M splits of its own path from the root first
+  const int64_t part = (int64_t)blockIdx.y;
+  const int k = g.k - M, L0 = k - D;
+  uint32_t *heap = tree_lds;                       // levels 0 .. L0 of the part, heap indexed
+  uint32_t *stk = heap + ((size_t)2 << L0);        // [D + 1][THREADS]
   const uint32_t r = rep0 + blockIdx.x;            // replicate of the STREAM; row blockIdx.x of this call's table
   const int tid = (int)threadIdx.x;
 
-  if (tid == 0) heap[1] = nsamp;
+  if (tid == 0) {
+    uint32_t n = nsamp;
+    for (int l = 0; l < M; ++l) {
+      const uint32_t left = split_left(k0, k1key, g, l, part >> (M - l), r, n);
+      n = ((part >> (M - l - 1)) & 1) != 0 ? n - left : left;
+    }
+    heap[1] = n;
+  }
   __syncthreads();
   for (int l = 0; l < L0; ++l) {
     const uint32_t nn = 1u << l;
-    for (uint32_t i = (uint32_t)tid; i < nn; i += TR_THREADS) {
+    for (uint32_t i = (uint32_t)tid; i < nn; i += THREADS) {
       const uint32_t n = heap[nn + i];
-      const uint32_t left = split_left(k0, k1key, g, l, (int64_t)i, r, n);
+      const uint32_t left = split_left(k0, k1key, g, M + l, (part << l) + (int64_t)i, r, n);
       heap[2 * nn + 2 * i] = left;
       heap[2 * nn + 2 * i + 1] = n - left;
     }
@@ -238,7 +255,7 @@ __global__ __launch_bounds__(TR_THREADS) void sampler_tree_kernel(uint32_t k0, u
   }
 
   const uint32_t nroots = 1u << L0, nleaf = 1u << D;
-  for (uint32_t sub0 = 0; sub0 < nroots; sub0 += TR_THREADS) {
+  for (uint32_t sub0 = 0; sub0 < nroots; sub0 += THREADS) {
     const uint32_t sub = sub0 + (uint32_t)tid;
     const bool act = sub < nroots;
     uint32_t cur = act ? heap[nroots + sub] : 0u;
@@ -246,16 +263,16 @@ __global__ __launch_bounds__(TR_THREADS) void sampler_tree_kernel(uint32_t k0, u
     for (uint32_t c = 0; c < nleaf; ++c) {
       // the node entered at leaf c: depth dmin = D - ctz(c) (the root for c = 0), its count = the pending right sibling
       const int dmin = c == 0u ? 0 : D - __builtin_ctz(c);
-      if (c != 0u) cur = stk[dmin * TR_THREADS + tid];
+      if (c != 0u) cur = stk[dmin * THREADS + tid];
 #pragma unroll 1
       for (int d = dmin; d < D; ++d) {
-        const int64_t gi = ((int64_t)sub << d) + (int64_t)(c >> (D - d));
-        const uint32_t left = split_left(k0, k1key, g, L0 + d, gi, r, cur);
-        stk[(d + 1) * TR_THREADS + tid] = cur - left;
+        const int64_t gi = (part << (L0 + d)) + ((int64_t)sub << d) + (int64_t)(c >> (D - d));
+        const uint32_t left = split_left(k0, k1key, g, M + L0 + d, gi, r, cur);
+        stk[(d + 1) * THREADS + tid] = cur - left;
         cur = left;
       }
-      const int64_t leaf = ((int64_t)sub << D) + c;
-      const int64_t lo = (leaf * g.ntiles) >> k, hi = ((leaf + 1) * g.ntiles) >> k;
+      const int64_t leaf = (part << k) + ((int64_t)sub << D) + c;
+      const int64_t lo = (leaf * g.ntiles) >> g.k, hi = ((leaf + 1) * g.ntiles) >> g.k;
       if (act && hi > lo) counts[(size_t)blockIdx.x * g.ntiles + lo] = cur;
     }
   }
@@ -363,13 +380,25 @@ extern "C" int txm_sampler_tile_counts(const txm_sampler_spec *sp, uint32_t *cou
   (void)ws_bytes;
   hipStream_t st = (hipStream_t)stream;
   const uint32_t k0 = (uint32_t)sp->seed, k1 = (uint32_t)(sp->seed >> 32);
-  // lane-private subtrees of depth TR_DEPTH below a heap of at most 2^TR_MAX_L0 nodes
-  int D = g.k < TR_DEPTH ? g.k : TR_DEPTH;
-  if (g.k - D > TR_MAX_L0) D = g.k - TR_MAX_L0;
-  const size_t lds = (((size_t)2 << (g.k - D)) + (size_t)(D + 1) * TR_THREADS) * sizeof(uint32_t);
-  TXM_SET_MAX_LDS(sampler_tree_kernel, 160 * 1024);
-  hipLaunchKernelGGL(sampler_tree_kernel, dim3((unsigned)sp->nrep), dim3(TR_THREADS), lds, st, k0, k1, (uint32_t)nsamp, g,
-                     (uint32_t)sp->rep0, D, counts);
+  // few replicates: more lanes a replicate, and 2^M workgroups a replicate (each the subtree under a node of level M) until the
+  // grid covers the chip twice -- while a part keeps a subtree a lane
+  const bool wide = sp->nrep < 1024;
+  const int lg = wide ? 10 : 8, threads = wide ? 1024 : 256;
+  int M = 0;
+  while (M < TR_MAX_M && (sp->nrep << M) < 512 && g.k - M > lg) ++M;
+  // lane-private subtrees below a heap of at most 2^TR_MAX_L0 nodes: one subtree a lane where the tree is deep enough
+  const int kp = g.k - M;
+  int D = kp > lg ? kp - lg : 0;
+  if (kp - D > TR_MAX_L0) D = kp - TR_MAX_L0;
+  const size_t lds = (((size_t)2 << (kp - D)) + (size_t)(D + 1) * threads) * sizeof(uint32_t);
+  const dim3 grid((unsigned)sp->nrep, 1u << M);
+  if (wide) {
+    TXM_SET_MAX_LDS(sampler_tree_kernel<1024>, 160 * 1024);
+    hipLaunchKernelGGL(sampler_tree_kernel<1024>, grid, dim3(1024), lds, st, k0, k1, (uint32_t)nsamp, g, (uint32_t)sp->rep0, D, M, counts);
+  } else {
+    TXM_SET_MAX_LDS(sampler_tree_kernel<256>, 160 * 1024);
+    hipLaunchKernelGGL(sampler_tree_kernel<256>, grid, dim3(256), lds, st, k0, k1, (uint32_t)nsamp, g, (uint32_t)sp->rep0, D, M, counts);
+  }
   TXM_LAUNCH_CHECK();
   return TXM_OK;
 }
