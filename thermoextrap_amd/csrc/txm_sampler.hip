@@ -153,31 +153,50 @@ __device__ __forceinline__ double u52(uint32_t hi, uint32_t lo) {
 
 // x ~ Binomial(n, p), p <= 1/2, n p >= 10: Hormann (1993), algorithm BTRS.  Attempt `att` of node h, replicate r takes
 // its two uniforms from Philox(ctr = (h, att, r, 7)).  ~86 % of the attempts end in the first test.
+// (the constants of a node, and ONE attempt: the walk below interleaves the attempts of different nodes across the lanes)
+struct Btrs {
+  double dn, p, q, spq, b, a, c, vr;
+};
+__device__ __forceinline__ Btrs btrs_setup(uint32_t n, double p) {
+  Btrs t;
+  t.dn = (double)n;
+  t.p = p;
+  t.q = 1.0 - p;
+  t.spq = det_sqrt(t.dn * p * t.q);
+  t.b = 1.15 + 2.53 * t.spq;
+  t.a = -0.0873 + 0.0248 * t.b + 0.01 * p;
+  t.c = t.dn * p + 0.5;
+  t.vr = 0.92 - 4.2 / t.b;
+  return t;
+}
+// -> accepted?; *x = the variate
+__device__ __forceinline__ bool btrs_attempt(const Btrs &t, uint32_t k0, uint32_t k1, uint32_t h, uint32_t r, uint32_t att, uint32_t *x) {
+  const Philox4 o = philox4x32_10<true>(h, att, r, 7u, k0, k1);
+  const double u = u52(o.w[0], o.w[1]) - 0.5;
+  double v = u52(o.w[2], o.w[3]);
+  const double us = 0.5 - (u < 0.0 ? -u : u);
+  const double kf = __builtin_floor((2.0 * t.a / us + t.b) * u + t.c);
+  if (us >= 0.07 && v <= t.vr) {
+    *x = (uint32_t)kf;
+    return true;
+  }
+  if (kf < 0.0 || kf > t.dn) return false;
+  *x = (uint32_t)kf;
+  const double alpha = (2.83 + 5.1 / t.b) * t.spq;
+  const double rr = t.p / t.q;
+  const double m = __builtin_floor((t.dn + 1.0) * t.p);
+  v = det_log(v * alpha / (t.a / (us * us) + t.b));
+  const double bound = (m + 0.5) * det_log((m + 1.0) / (rr * (t.dn - m + 1.0))) +
+                       (t.dn + 1.0) * det_log((t.dn - m + 1.0) / (t.dn - kf + 1.0)) +
+                       (kf + 0.5) * det_log(rr * (t.dn - kf + 1.0) / (kf + 1.0)) +
+                       ((stirling_tail(m) + stirling_tail(t.dn - m)) - (stirling_tail(kf) + stirling_tail(t.dn - kf)));
+  return v <= bound;
+}
 __device__ __forceinline__ uint32_t btrs(uint32_t k0, uint32_t k1, uint32_t h, uint32_t r, uint32_t n, double p) {
-  const double dn = (double)n;
-  const double q = 1.0 - p;
-  const double spq = det_sqrt(dn * p * q);
-  const double b = 1.15 + 2.53 * spq;
-  const double a = -0.0873 + 0.0248 * b + 0.01 * p;
-  const double c = dn * p + 0.5;
-  const double vr = 0.92 - 4.2 / b;
+  const Btrs t = btrs_setup(n, p);
   for (uint32_t att = 0;; ++att) {
-    const Philox4 o = philox4x32_10<true>(h, att, r, 7u, k0, k1);
-    const double u = u52(o.w[0], o.w[1]) - 0.5;
-    double v = u52(o.w[2], o.w[3]);
-    const double us = 0.5 - (u < 0.0 ? -u : u);
-    const double kf = __builtin_floor((2.0 * a / us + b) * u + c);
-    if (us >= 0.07 && v <= vr) return (uint32_t)kf;
-    if (kf < 0.0 || kf > dn) continue;
-    const double alpha = (2.83 + 5.1 / b) * spq;
-    const double rr = p / q;
-    const double m = __builtin_floor((dn + 1.0) * p);
-    v = det_log(v * alpha / (a / (us * us) + b));
-    const double bound = (m + 0.5) * det_log((m + 1.0) / (rr * (dn - m + 1.0))) +
-                         (dn + 1.0) * det_log((dn - m + 1.0) / (dn - kf + 1.0)) +
-                         (kf + 0.5) * det_log(rr * (dn - kf + 1.0) / (kf + 1.0)) +
-                         ((stirling_tail(m) + stirling_tail(dn - m)) - (stirling_tail(kf) + stirling_tail(dn - kf)));
-    if (v <= bound) return (uint32_t)kf;
+    uint32_t x;
+    if (btrs_attempt(t, k0, k1, h, r, att, &x)) return x;
   }
 }
 
@@ -254,26 +273,78 @@ __global__ __launch_bounds__(THREADS) void sampler_tree_kernel(uint32_t k0, uint
     __syncthreads();
   }
 
+  // The subtrees: every lane walks its own (depth first), ONE BTRS attempt per turn of the loop.  A lane whose attempt is accepted
+  // moves on to its next node in the same turn; one whose attempt is rejected tries again in the next -- no lane waits for the
+  // slowest of its wave (a loop over the nodes with the rejection loop inside ran max-over-64-lanes attempts a node, ~3.5 where a
+  // lane needs 1.16).  The variates are those of split_left: same constants, same attempts, same order per node.
   const uint32_t nroots = 1u << L0, nleaf = 1u << D;
-  for (uint32_t sub0 = 0; sub0 < nroots; sub0 += THREADS) {
-    const uint32_t sub = sub0 + (uint32_t)tid;
-    const bool act = sub < nroots;
-    uint32_t cur = act ? heap[nroots + sub] : 0u;
+  uint32_t sub = (uint32_t)tid, c = 0, cur = 0, att = 0, h = 0;
+  int d = 0;
+  bool run = sub < nroots, fresh = true, flip = false;
+  Btrs bt = {};
+  if (run) cur = heap[nroots + sub];
 #pragma unroll 1
-    for (uint32_t c = 0; c < nleaf; ++c) {
-      // the node entered at leaf c: depth dmin = D - ctz(c) (the root for c = 0), its count = the pending right sibling
-      const int dmin = c == 0u ? 0 : D - __builtin_ctz(c);
-      if (c != 0u) cur = stk[dmin * THREADS + tid];
-#pragma unroll 1
-      for (int d = dmin; d < D; ++d) {
-        const int64_t gi = (part << (L0 + d)) + ((int64_t)sub << d) + (int64_t)(c >> (D - d));
-        const uint32_t left = split_left(k0, k1key, g, M + L0 + d, gi, r, cur);
-        stk[(d + 1) * THREADS + tid] = cur - left;
-        cur = left;
-      }
+  for (;;) {
+    // leaves: store the count, back up to the pending right sibling (the next subtree of this lane behind the last leaf)
+    while (run && d == D) {
       const int64_t leaf = (part << k) + ((int64_t)sub << D) + c;
       const int64_t lo = (leaf * g.ntiles) >> g.k, hi = ((leaf + 1) * g.ntiles) >> g.k;
-      if (act && hi > lo) counts[(size_t)blockIdx.x * g.ntiles + lo] = cur;
+      if (hi > lo) counts[(size_t)blockIdx.x * g.ntiles + lo] = cur;
+      ++c;
+      if (c == nleaf) {
+        sub += THREADS;
+        run = sub < nroots;
+        c = 0;
+        d = 0;
+        if (run) cur = heap[nroots + sub];
+      } else {
+        d = D - __builtin_ctz(c);
+        cur = stk[d * THREADS + tid];
+      }
+    }
+    if (__ballot(run) == 0ull) break;
+    if (run) {
+      uint32_t left = 0;
+      bool have = false;
+      if (fresh) {  // a new node: the cases split_left decides without a variate, the bitwise rule, or the constants of BTRS
+        const int l = M + L0 + d;
+        const int64_t gi = (part << (L0 + d)) + ((int64_t)sub << d) + (int64_t)(c >> (D - d));
+        const int64_t A = tree_node_size(g.ndat, g.ntiles, l + 1, 2 * gi), B = tree_node_size(g.ndat, g.ntiles, l + 1, 2 * gi + 1);
+        h = (1u << l) + (uint32_t)gi;
+        if (cur == 0u || A == 0) {
+          have = true;
+        } else if (B == 0) {
+          left = cur;
+          have = true;
+        } else {
+          const int64_t S = A <= B ? A : B;
+          const double p = (double)S / (double)(A + B);
+          if ((double)cur * p >= 10.0) {
+            bt = btrs_setup(cur, p);
+            flip = !(A <= B);
+            att = 0;
+            fresh = false;
+          } else {
+            left = split_left_bits(k0, k1key, h, r, cur, A, B);
+            have = true;
+          }
+        }
+      }
+      if (!have) {
+        uint32_t x;
+        if (btrs_attempt(bt, k0, k1key, h, r, att, &x)) {
+          left = flip ? cur - x : x;
+          have = true;
+          fresh = true;
+        } else {
+          ++att;
+        }
+      }
+      if (have) {
+        stk[(d + 1) * THREADS + tid] = cur - left;
+        cur = left;
+        ++d;
+      }
     }
   }
 }
