@@ -227,6 +227,23 @@ def test_device_sampler_tile_counts_bit_exact_at_size(eng, orc, ndat, nrep, nsam
     assert (counts.sum(axis=1, dtype=np.int64) == (nsamp or ndat)).all()
 
 
+def test_device_sampler_table_does_not_depend_on_the_launch_shape(eng, orc):
+    """A node's variate is a function of (level, index, replicate) alone: calls with >= 1024 replicates walk the tile tree with 256
+    lanes a replicate, smaller ones with 1024 (and the subtree depth follows the lanes) -- the rows are the same bits, and the
+    oracle's."""
+    ndat, seed = 2_500_000, 4242
+    big = eng.DeviceSampler(seed, 1100, ndat)
+    for a in (0, 517, 1095):
+        small = eng.DeviceSampler(seed, 5, ndat, rep0=a)
+        assert torch.equal(big.counts[a:a + 5], small.counts), a
+    ref = orc.sampler_tile_counts(seed, 3, ndat)
+    assert np.array_equal(big.counts[:3].cpu().numpy().view(np.uint32), ref)
+    for nd in (1500, 70_000):            # shallow trees: fewer subtree roots than lanes, depth-0 subtrees
+        b = eng.DeviceSampler(seed + nd, 1024, nd)
+        assert np.array_equal(b.counts[:4].cpu().numpy().view(np.uint32), orc.sampler_tile_counts(seed + nd, 4, nd))
+        assert torch.equal(b.counts[1000:1003], eng.DeviceSampler(seed + nd, 3, nd, rep0=1000).counts)
+
+
 def test_device_sampler_matches_committed_stream_vectors(eng):
     """GPU tables vs tests/golden/sampler_stream_v3.json (no oracle in between)."""
     import json
