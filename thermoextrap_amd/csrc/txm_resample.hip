@@ -778,7 +778,10 @@ static I8Plan plan_i8(int64_t N, int64_t C, int64_t nrep, int K) {
   // summation, so a replicate's bits must not depend on nrep / the chunking (txm_sampler_spec.rep0: replicate slabs of
   // a multi-GPU run equal the one-GPU rows bit for bit).
   p.win_tiles = I8_WIN_TILES;
-  while (p.win_tiles > 4 && p.ntiles < 256 * p.win_tiles) p.win_tiles /= 4;  // >= 256 windows where N allows
+#ifndef TXM_WIN_MIN  // (A/B builds: fewer, longer windows on short series)
+#define TXM_WIN_MIN 256
+#endif
+  while (p.win_tiles > 4 && p.ntiles < TXM_WIN_MIN * p.win_tiles) p.win_tiles /= 4;  // >= 256 windows where N allows
   p.nwin = cdiv(p.ntiles, p.win_tiles);
   // one workgroup per CU: chunks (whole windows) x replicate groups should fill the CUs once, not 1.1 times
   int64_t nc = (int64_t)num_cus() / p.n_rbg / 8 * 8;

@@ -61,6 +61,11 @@ namespace txm {
 #ifndef TXM_T_CG1
 #define TXM_T_CG1 4
 #endif
+#ifdef TXM_T_FLUSH_SERIAL  // (A/B build: the chunk groups' first flush, see the end of the window loop)
+constexpr bool T_FLUSH_SERIAL = true;
+#else
+constexpr bool T_FLUSH_SERIAL = false;
+#endif
 #define T_CG_OF(nq, jn) (((nq) == 1 && (jn) <= 4) ? TXM_T_CG1 : ((nq) == 1 || ((nq) == 2 && (jn) <= 6) || ((nq) == 4 && (jn) <= 4)) ? 2 : 1)
 
 // K = order + 1 is a run-time argument (it only enters the flush addresses); one launch slices the JN powers
@@ -422,7 +427,11 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       }
       dsc *= (double)((int64_t)1 << (8 * (tdg < I8_NSL ? tdg : 0)));
       const int bias = tdg == I8_NSL - 1 ? T_D6_BIAS : 0;
+#ifdef TXM_T_NO_FLUSH_STORE  // (ablation build: one row of a tile is written)
+      if (valid && tdg == 0) {
+#else
       if (valid) {
+#endif
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = (r >> 2) * 8 + (r & 3);
@@ -671,47 +680,100 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (wave == 0) fsum[lane] = fdraws;
     fdraws = 0;
     __syncthreads();
-    if constexpr (CG > 1) {
-      // chunk groups: the second group hands its int32 accumulators to the first through the (now idle) count tile, four tiles
-      // per wave and round; the sums are exact, so what is flushed is what one group contracting all 32 chunks would have flushed
-      constexpr int NT = 2 * NS + 1;  // tiles of a wave: NS row sets x 2 replicate halves + the u-row tile
-      uint32_t *xch = cntw + (size_t)((wave % WPG) * 4) * 16 * 64 + lane;
+    if constexpr (CG > 1 && !T_FLUSH_SERIAL) {
+      // chunk groups: the groups' int32 accumulators are added up in the (now idle) count tile -- group 0 stores its tiles, the
+      // others add theirs with LDS atomics (exact, whatever the order: what is flushed is what one group contracting all 32 chunks
+      // would have flushed) -- and the CG waves that share a role (wave % WPG: same quad, same powers, same u-row half) then SPLIT
+      // the summed tiles between them for the write-out.  Three barriers a round whatever the number of groups, and all eight
+      // waves store.  (Round 6, phase clocks of config 5's state: the first cut -- group after group through group 0's registers,
+      // two barriers per source and round, group 0's two waves alone converting and storing five tiles each -- took 19 000 cycles
+      // per window next to 24 000 per TILE, and a window of a short series is four tiles.)
+      constexpr int NT = 2 * NS + 1;                          // tiles of a wave: NS row sets x 2 replicate halves + the u-row tile
+      constexpr int RT = 16 / WPG < NT ? 16 / WPG : NT;       // tiles per wave and round: WPG x RT x 4 KiB <= the 64 KiB count tile
+      static_assert(WPG * RT * 16 * 64 * 4 <= T_CNT_BYTES, "exchange slots");
+      uint32_t *xch = cntw + (size_t)((wave % WPG) * RT) * 16 * 64 + lane;
       auto tile_of = [&](int tt) -> v16i & { return tt < 2 * NS ? acc[tt >> 1][tt & 1] : accu; };
+      t_static_for<(NT + RT - 1) / RT>([&](auto rc) {
+        constexpr int t0 = decltype(rc)::value * RT;
+        if (cgrp == 0) {
+#pragma unroll
+          for (int k = 0; k < RT; ++k)
+            if (t0 + k < NT) {
+              v16i &T = tile_of(t0 + k);
+#pragma unroll
+              for (int r = 0; r < 16; ++r) xch[(k * 16 + r) * 64] = (uint32_t)T[r];
+            }
+        }
+        __syncthreads();
+        if (cgrp != 0) {
+#pragma unroll
+          for (int k = 0; k < RT; ++k)
+            if (t0 + k < NT) {
+              v16i &T = tile_of(t0 + k);
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                __hip_atomic_fetch_add(&xch[(k * 16 + r) * 64], (uint32_t)T[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __syncthreads();
+        t_static_for<RT>([&](auto kc) {
+          constexpr int k = decltype(kc)::value, tt = t0 + k;
+          if constexpr (tt < NT) {
+            if (cgrp == tt % CG) {  // wave-uniform: this group's share of the role's tiles
+              v16i T;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) T[r] = (int)xch[(k * 16 + r) * 64];
+              if constexpr (tt < 2 * NS) flush_tile(T, (tt & 1) ? 1 - hswap : hswap, tt >> 1, -1);
+              else if (has_ut) flush_tile(T, uh, 0, fu);  // wave-uniform
+            }
+          }
+        });
+        if constexpr (t0 + RT < NT) __syncthreads();  // (the next round overwrites the slots)
+      });
+#pragma unroll
+      for (int fi = 0; fi < NS; ++fi) acc[fi][0] = acc[fi][1] = (v16i)(0);
+    } else {
+      if constexpr (CG > 1) {
+        // (A/B build -DTXM_T_FLUSH_SERIAL: the first cut -- group after group into group 0's registers, which flushes alone)
+        constexpr int NT = 2 * NS + 1;
+        uint32_t *xch = cntw + (size_t)((wave % WPG) * 4) * 16 * 64 + lane;
+        auto tile_of = [&](int tt) -> v16i & { return tt < 2 * NS ? acc[tt >> 1][tt & 1] : accu; };
 #pragma unroll 1
-      for (int src = 1; src < CG; ++src) {  // group src -> group 0, wave for wave (same quad, same powers)
+        for (int src = 1; src < CG; ++src) {  // group src -> group 0, wave for wave (same quad, same powers)
 #pragma unroll
-        for (int t0 = 0; t0 < NT; t0 += 4) {
-          if (cgrp == src) {
+          for (int t0 = 0; t0 < NT; t0 += 4) {
+            if (cgrp == src) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-              if (t0 + k < NT) {
-                v16i &T = tile_of(t0 + k);
+              for (int k = 0; k < 4; ++k)
+                if (t0 + k < NT) {
+                  v16i &T = tile_of(t0 + k);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) xch[(k * 16 + r) * 64] = (uint32_t)T[r];
-                T = (v16i)(0);
-              }
+                  for (int r = 0; r < 16; ++r) xch[(k * 16 + r) * 64] = (uint32_t)T[r];
+                  T = (v16i)(0);
+                }
+            }
+            __syncthreads();
+            if (cgrp == 0) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                if (t0 + k < NT) {
+                  v16i &T = tile_of(t0 + k);
+#pragma unroll
+                  for (int r = 0; r < 16; ++r) T[r] += (int)xch[(k * 16 + r) * 64];
+                }
+            }
+            if (t0 + 4 < NT || src + 1 < CG) __syncthreads();  // (the next round overwrites the slots)
           }
-          __syncthreads();
-          if (cgrp == 0) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-              if (t0 + k < NT) {
-                v16i &T = tile_of(t0 + k);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) T[r] += (int)xch[(k * 16 + r) * 64];
-              }
-          }
-          if (t0 + 4 < NT || src + 1 < CG) __syncthreads();  // (the next round overwrites the slots)
         }
       }
-    }
-    if (CG == 1 || cgrp == 0) {  // wave-uniform
+      if (CG == 1 || cgrp == 0) {  // wave-uniform
 #pragma unroll
-      for (int fi = 0; fi < NS; ++fi) {
-        flush_tile(acc[fi][0], hswap, fi, -1);
-        flush_tile(acc[fi][1], 1 - hswap, fi, -1);
+        for (int fi = 0; fi < NS; ++fi) {
+          flush_tile(acc[fi][0], hswap, fi, -1);
+          flush_tile(acc[fi][1], 1 - hswap, fi, -1);
+        }
+        if (has_ut) flush_tile(accu, uh, 0, fu);  // wave-uniform
       }
-      if (has_ut) flush_tile(accu, uh, 0, fu);  // wave-uniform
     }
     accu = (v16i)(0);
     __syncthreads();  // fsum is rewritten by the next window

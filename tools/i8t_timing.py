@@ -20,10 +20,11 @@ with eng.forced_path("int8"):
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); eng.resample_vals(x, u, order, sampler=s, prep=prep); e1.record(); torch.cuda.synchronize()
-print(f"call {e0.elapsed_time(e1):.2f} ms", eng.resample_info())
+print(f"call {e0.elapsed_time(e1):.3f} ms", eng.resample_info())
 ntiles = -(-N // 1024)
 win = 256
-while win > 4 and ntiles < 256 * win: win //= 4
+WMIN = int(os.environ.get("TXM_WIN_MIN", 256))  # the variant's -DTXM_WIN_MIN
+while win > 4 and ntiles < WMIN * win: win //= 4
 nwin = -(-ntiles // win)
 g0 = -(-(1 + C) * 8 // 256) * 256
 off = g0 + nwin * 80 * 8
