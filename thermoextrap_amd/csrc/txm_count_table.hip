@@ -50,7 +50,28 @@ __global__ __launch_bounds__(T_BLOCK) void count_table_kernel(const uint32_t *__
 #else
     if (any_live) {
 #endif
-      if (tsize == (uint32_t)SM_T) {
+      // live replicates of this half group; <= 32 -- the call's last one: 8 of 64 at nrep = 200 -- and FP = fill_pack lanes share
+      // a replicate and take FP consecutive Philox calls of it: 1 / FP of the wave instructions of the lane-per-replicate fill for
+      // the same draws (which lane runs a call of the stream is free: the count words are atomics).  The fill phase of
+      // resample_i8t_kernel has had this since round 4; BASELINE config 2 (200 replicates) lost it when its call moved to the
+      // table-fed kernel (round 6: generator 0.90 ms for 256 replicates' worth of Philox calls)
+      const int64_t live_reps = nrep - rep0;
+      const int fill_pack = live_reps <= 8 ? 8 : live_reps <= 16 ? 4 : live_reps <= 32 ? 2 : 1;  // uniform
+      if (tsize == (uint32_t)SM_T && fill_pack > 1) {
+        const int rp = lane & (I8_REPS / fill_pack - 1), slot = lane / (I8_REPS / fill_pack);
+        const uint32_t np = rep0 + rp < nrep ? counts[(size_t)(rep0 + rp) * ntiles + t] : 0u;
+        uint32_t nmx = np;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const uint32_t hi = (uint32_t)__shfl_xor((int)nmx, o);
+          nmx = hi > nmx ? hi : nmx;
+        }
+        nmx = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmx);
+        const uint32_t rsp = rep_base + (uint32_t)(rep0 + rp);
+#pragma unroll 1
+        for (uint32_t c0 = (uint32_t)wave * (uint32_t)fill_pack; c0 * 12u < nmx; c0 += (uint32_t)(T_WAVES * fill_pack))
+          t_fill_call<false>(cntw, k0, k1, rsp, (uint32_t)t, c0 + (uint32_t)slot, np, (uint32_t)rp * 4u);
+      } else if (tsize == (uint32_t)SM_T) {
         // dead lanes (replicates past nrep) draw like the smallest live lane; their rows are written as zeros below
         uint32_t nmin = rep_live ? n : 0xffffffffu, nmax = rep_live ? n : 0u;
 #pragma unroll
@@ -119,8 +140,11 @@ int launch_count_table(const uint32_t *counts, int64_t nrep, int64_t N, uint32_t
   }
   // runs of tiles per workgroup: enough workgroups to fill the chip several times over, long enough runs to stream
   // the tile counts (32 per cache line)
+#ifndef TXM_CT_ROUNDS  // (A/B builds)
+#define TXM_CT_ROUNDS 4
+#endif
   int tpb = 32;
-  while (tpb > 1 && cdiv(ntiles, tpb) * 2 * n_groups < 4 * (int64_t)num_cus()) tpb /= 2;
+  while (tpb > 1 && cdiv(ntiles, tpb) * 2 * n_groups < TXM_CT_ROUNDS * (int64_t)num_cus()) tpb /= 2;
   const dim3 grid((unsigned)cdiv(ntiles, tpb), (unsigned)(2 * n_groups));
   TXM_SET_MAX_LDS(count_table_kernel, T_CNT_BYTES);
   hipLaunchKernelGGL(count_table_kernel, grid, dim3(T_BLOCK), T_CNT_BYTES, st, counts, nrep, ntiles, N,
