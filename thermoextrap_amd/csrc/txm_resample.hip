@@ -600,7 +600,9 @@ __global__ __launch_bounds__(256) void resample_finalize_i8_kernel(
     const uint32_t *__restrict__ wflag, int64_t nrep_pad, int64_t nrep, int64_t C,
     const double *__restrict__ pivot, double *__restrict__ out, int64_t c_off, int64_t C_total,
     const double *__restrict__ fb_x, const double *__restrict__ fb_u, int fb_chunks, int64_t fb_cpad,
-    const uint32_t *__restrict__ n_list, const I8State *__restrict__ states = nullptr) {
+    const uint32_t *__restrict__ n_list, const I8State *__restrict__ states = nullptr, const int summed = 0) {
+  // summed != 0: the slots hold the digit sums already -- [window][replicate][power][column] and [window][replicate][power],
+  // written by the chunk-group instances of resample_i8t_kernel with the expression below (i8t_partials_summed)
   if (states != nullptr) {  // batched int8 call: state blockIdx.y
     const I8State e = states[blockIdx.y];
     part_x = e.part_x; part_u = e.part_u; wflag = e.wflag; pivot = e.pivot; out = e.out;
@@ -623,6 +625,16 @@ __global__ __launch_bounds__(256) void resample_finalize_i8_kernel(
   if (c < C) {
     for (int64_t w = seg; w < nwin; w += nseg) {
       if (wflag[w] != 0u) continue;
+      if (summed) {  // (uniform)
+        const double *pu_ = part_u + ((size_t)w * nrep_pad + r) * K;
+        const double *px_ = part_x + ((size_t)w * nrep_pad + r) * K * cpad + c;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          S0[j] += pu_[j];
+          S1[j] += px_[j * cpad];
+        }
+        continue;
+      }
       const double *pu_ = part_u + ((size_t)w * nrep_pad + r) * K * 8;
       const double *px_ = part_x + ((size_t)w * nrep_pad + r) * K * 8 * cpad + c;
 #pragma unroll
@@ -1309,10 +1321,12 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
         const int rc2 = run_listed(f, q.fb, K, w != nullptr, st);
         if (rc2 != TXM_OK) return rc2;
       }
+      // (the slots' layout: digit sums where the fused narrow kernel with chunk groups wrote them, per-digit slots otherwise)
+      const int fin_summed = (!table_kernel && i8t_partials_summed(b.C_call, K)) ? 1 : 0;
 #define TXM_I8_FIN2(KK, CP)                                                                            \
   hipLaunchKernelGGL((resample_finalize_i8_kernel<KK, CP>), dim3((unsigned)nrep), dim3(256), 0, st,      \
                      b.part_x, b.part_u, q.nwin, b.wflag, q.nrep_pad, nrep, b.C, piv, out, col0, C,        \
-                     f.part_x, f.part_u, q.fb.n_chunks, q.fb.C_pad, b.n_list)
+                     f.part_x, f.part_u, q.fb.n_chunks, q.fb.C_pad, b.n_list, (const I8State *)nullptr, fin_summed)
 #define TXM_I8_FIN(KK)                                                                                 \
   do {                                                                                                 \
     if (b.cpad == 32) TXM_I8_FIN2(KK, 32);                                                             \
@@ -1657,10 +1671,11 @@ static int resample_batched_i8(const txm_state_ptrs *states_host, int64_t S, int
   TXM_REQUIRE(q.fb.nrep_pad == q.nrep_pad, "resample_vals_batched: replicate padding of the two kernels differs");
   rc = run_listed(f, q.fb, K, weighted, st, S);
   if (rc != TXM_OK) return rc;
+  const int bfin_summed = i8t_partials_summed(C, K) ? 1 : 0;  // (batched launches always run the fused narrow kernel)
 #define TXM_I8_BFIN2(KK, CP)                                                                                        \
   hipLaunchKernelGGL((resample_finalize_i8_kernel<KK, CP>), dim3((unsigned)nrep, (unsigned)S), dim3(256), 0, st, nullptr, \
                      nullptr, q.nwin, nullptr, q.nrep_pad, nrep, C, nullptr, nullptr, (int64_t)0, C, nullptr, nullptr,      \
-                     q.fb.n_chunks, q.fb.C_pad, nullptr, states)
+                     q.fb.n_chunks, q.fb.C_pad, nullptr, states, bfin_summed)
 #define TXM_I8_BFIN(KK)                                  \
   do {                                                   \
     if (b.cpad == 16) TXM_I8_BFIN2(KK, 16);              \

@@ -113,5 +113,6 @@ bool i8t_applicable(const double *x, int64_t ldx_s, int64_t C);  // C = all colu
 // the shape is not served by it; i8_cpad = the columns of a row of I8Args::part_x for the shape (4, 8, 16 or 32)
 int i8t_narrow_nq(int64_t C_call, int K);
 int i8_cpad(int64_t C_call, int K);
+bool i8t_partials_summed(int64_t C_call, int K);  // the fused narrow kernel stores digit-summed slots for this shape
 
 }  // namespace txm

@@ -688,11 +688,69 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       // waves store.  (Round 6, phase clocks of config 5's state: the first cut -- group after group through group 0's registers,
       // two barriers per source and round, group 0's two waves alone converting and storing five tiles each -- took 19 000 cycles
       // per window next to 24 000 per TILE, and a window of a short series is four tiles.)
+      // The write-out adds the seven digit sums of an element up itself -- ((((((d0 + d1) + d2) + d3) + d4) + d5) + d6), each
+      // (double)(int32 sum) x its scale: the expression and the order resample_finalize_i8_kernel applies to the per-digit slots
+      // the other kernels store -- so the window's slot holds ONE double per (replicate, power, column): an eighth of the bytes
+      // written here and read by the finalize (a short series has a window every four tiles: config 5's call wrote and re-read
+      // 2.5 GB of slots, as much as its samples; finalize 0.46 ms of a 5.8 ms call).  Same bits (I8Args::cpad rows without the
+      // digit dimension: i8t_partials_summed() tells the host which layout a launch writes).
       constexpr int NT = 2 * NS + 1;                          // tiles of a wave: NS row sets x 2 replicate halves + the u-row tile
-      constexpr int RT = 16 / WPG < NT ? 16 / WPG : NT;       // tiles per wave and round: WPG x RT x 4 KiB <= the 64 KiB count tile
-      static_assert(WPG * RT * 16 * 64 * 4 <= T_CNT_BYTES, "exchange slots");
-      uint32_t *xch = cntw + (size_t)((wave % WPG) * RT) * 16 * 64 + lane;
+      constexpr int XS = 65;                                  // words per register row of an exchanged tile (64 lanes + 1: see the reads)
+      constexpr int XT = 16 * XS;                             // words per tile
+      constexpr int RT0 = T_CNT_BYTES / 4 / (WPG * XT);       // tiles per wave and round that fit the 64 KiB count tile
+      constexpr int RT = RT0 < NT ? RT0 : NT;
+      static_assert(RT >= 1 && WPG * RT * XT * 4 <= T_CNT_BYTES, "exchange slots");
+      uint32_t *xrole = cntw + (size_t)((wave % WPG) * RT) * XT;  // this role's tiles of the round
+      uint32_t *xch = xrole + lane;
       auto tile_of = [&](int tt) -> v16i & { return tt < 2 * NS ? acc[tt >> 1][tt & 1] : accu; };
+      // element (replicate row m, column / monomial q4) of a summed tile: its digit d sits in register 4 (m >> 3) + (m & 3) of
+      // lane 16 (d >> 2) + 4 q4 + (d & 3) + 32 ((m >> 2) & 1) (the D layout of v_mfma_i32_32x32x32_i8; tile column -> (column,
+      // digit) as tcl / tdg above).  Lane L takes the elements L and L + 64 of the tile's 32 x 4.  With rows of 65 words the
+      // lanes of one read spread over rr + 4 q4 (+ const): four-way bank conflicts; rows of 64 put all sixteen replicate rows of
+      // a lane quartet on one bank.
+      auto flush_summed = [&](const uint32_t *tl, int h, int rs, int ufrag) {
+        uint32_t z = 0;
+        asm volatile("" : "+v"(z));  // (addresses formed here, not hoisted out of the window loop and spilled: see flush_tile)
+        const int64_t opq = (int64_t)z;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int o = lane + 64 * i, m = o >> 2, q4 = o & 3;
+          const int rr = ((m >> 3) << 2) | (m & 3), hh = (m >> 2) & 1;
+          bool valid;
+          int j;
+          double dsc0;
+          double *dst;
+          if (ufrag < 0) {
+            const int c = 4 * quad + q4;
+            valid = c < a.C && row_live(rs);
+            j = J0 + (row_live(rs) ? g + rs * GS : 0);
+            dsc0 = wt[I8_WT_DSP + j] * wt[I8_WT_DSC + (c < a.C ? c : 0)];
+            dst = a.part_x + (((size_t)win * a.nrep_pad + rep0 + 32 * h + m) * K + j) * a.cpad + c + opq;
+          } else {
+            const int mm = 4 * ufrag + q4;
+            valid = mm < JN;
+            j = J0 + (mm < JN ? mm : 0);
+            dsc0 = wt[I8_WT_DSP + j] * 0x1p-50;
+            dst = a.part_u + ((size_t)win * a.nrep_pad + rep0 + 32 * h + m) * K + j + opq;
+          }
+          if (valid) {
+            const uint32_t *src = tl + rr * XS + 32 * hh + 4 * q4;
+            const int fs = (int)fsum[32 * h + m];
+            int v[I8_NSL];
+#pragma unroll
+            for (int d = 0; d < I8_NSL; ++d) v[d] = (int)src[16 * (d >> 2) + (d & 3)];
+            v[I8_NSL - 1] -= T_D6_BIAS * fs;
+            double sum = 0.0;
+#pragma unroll
+            for (int d = 0; d < I8_NSL; ++d) {
+              double pd = (double)v[d] * (dsc0 * (double)((int64_t)1 << (8 * d)));
+              asm volatile("" : "+v"(pd));  // (a product rounded on its own, as the stored slot was: no fused multiply-add with the sum)
+              sum = d == 0 ? pd : sum + pd;
+            }
+            *dst = sum;
+          }
+        }
+      };
       t_static_for<(NT + RT - 1) / RT>([&](auto rc) {
         constexpr int t0 = decltype(rc)::value * RT;
         if (cgrp == 0) {
@@ -701,7 +759,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
             if (t0 + k < NT) {
               v16i &T = tile_of(t0 + k);
 #pragma unroll
-              for (int r = 0; r < 16; ++r) xch[(k * 16 + r) * 64] = (uint32_t)T[r];
+              for (int r = 0; r < 16; ++r) xch[k * XT + r * XS] = (uint32_t)T[r];
             }
         }
         __syncthreads();
@@ -712,7 +770,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
               v16i &T = tile_of(t0 + k);
 #pragma unroll
               for (int r = 0; r < 16; ++r)
-                __hip_atomic_fetch_add(&xch[(k * 16 + r) * 64], (uint32_t)T[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&xch[k * XT + r * XS], (uint32_t)T[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         __syncthreads();
@@ -720,11 +778,8 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
           constexpr int k = decltype(kc)::value, tt = t0 + k;
           if constexpr (tt < NT) {
             if (cgrp == tt % CG) {  // wave-uniform: this group's share of the role's tiles
-              v16i T;
-#pragma unroll
-              for (int r = 0; r < 16; ++r) T[r] = (int)xch[(k * 16 + r) * 64];
-              if constexpr (tt < 2 * NS) flush_tile(T, (tt & 1) ? 1 - hswap : hswap, tt >> 1, -1);
-              else if (has_ut) flush_tile(T, uh, 0, fu);  // wave-uniform
+              if constexpr (tt < 2 * NS) flush_summed(xrole + k * XT, (tt & 1) ? 1 - hswap : hswap, tt >> 1, -1);
+              else if (has_ut) flush_summed(xrole + k * XT, uh, 0, fu);  // wave-uniform
             }
           }
         });
@@ -842,6 +897,17 @@ int i8t_narrow_nq(int64_t C_call, int K) {
 int i8_cpad(int64_t C_call, int K) {
   const int nq = i8t_narrow_nq(C_call, K);
   return nq ? 4 * nq : I8_CPAD;
+}
+
+// Which layout the launches of launch_resample_i8t leave in I8Args::part_x / part_u for a shape: instances with chunk groups
+// (every pass of the narrow call) add the digit sums up in their flush and store [window][replicate][power][column] (u-row:
+// [window][replicate][power]); everything else stores the per-digit slots [...][power][8 digit slots][column].  The finalize is
+// told which (resample_finalize_i8_kernel's SUMMED).
+bool i8t_partials_summed(int64_t C_call, int K) {
+  const int nq = i8t_narrow_nq(C_call, K);
+  if (nq == 0 || T_FLUSH_SERIAL) return false;
+  if (nq == 4 && K >= 7) return T_CG_OF(4, 4) > 1 && T_CG_OF(4, K - 4) > 1;  // the two passes of launch_resample_i8t
+  return T_CG_OF(nq, K) > 1;
 }
 
 template <int NQ>
