@@ -334,6 +334,32 @@ def pmc_call_traffic(shape, int8_kernel, prepass=False):
     return None, None, stale
 
 
+def pmc_narrow_call_traffic(cfg, workload, int8_kernel=None):
+    """(total, {kernel: bytes}, source) of ONE bootstrap call of a narrow configuration ("c2" / "c5") from the newest committed
+    profiles/*_pmc_narrow.json (tools/narrow_pmc.sh: FETCH_SIZE / WRITE_SIZE passes over every kernel of the call, summed as
+    call_traffic does) measured on THIS checkout's kernel sources and on the same workload and int8 kernel; (None, None, reason)
+    otherwise.  NOT measured in this run."""
+    import glob
+
+    sha = csrc_sha()
+    stale = None
+    for f in sorted(glob.glob(str(ROOT / "profiles" / "*_pmc_narrow.json")), reverse=True):
+        try:
+            d = json.loads(Path(f).read_text())
+            c = d["configs"][cfg]
+        except Exception:  # noqa: BLE001
+            continue
+        if any(int(c.get("workload", {}).get(k, -1)) != int(v) for k, v in workload.items()) or c.get("call_hbm_bytes") is None:
+            continue
+        if int8_kernel is not None and c.get("call_kernel") != int8_kernel:
+            continue
+        if d.get("csrc_sha") != sha:
+            stale = stale or f"profiles/{Path(f).name} was measured on other kernel sources (csrc_sha {d.get('csrc_sha')} != {sha})"
+            continue
+        return c["call_hbm_bytes"], c.get("call_kernels"), f"profiles/{Path(f).name} [{cfg}] (csrc_sha {sha})"
+    return None, None, stale
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -601,6 +627,10 @@ def main():
                                   "(finalize and memsets included); profiles/*_kernel_stats.csv has the rocprofv3 per-kernel durations"}
         # HBM bytes of the timed CALL: the sum over its kernels (generator + every contraction pass + finalize ...), not one launch
         tr, tr_kernels, src = pmc_call_traffic(shape, info.get("kernel") or "int8_fused", prepass=not info.get("prep_reused"))
+        if tr is None and C <= 16:  # narrow states: the counters of tools/narrow_pmc.sh (config 2's shape)
+            tr, tr_kernels, src2 = pmc_narrow_call_traffic("c2", {"states": 1, "n_samp": N, "n_obs": C, "order": order, "nrep": nrep_rank},
+                                                           info.get("kernel") or "int8_fused")
+            src = src2 or src
         roofline = {
             "kernel": f"{kname} ({kdesc}) + pre-pass (unless reused) and finalize kernels",
             "bound": "mfma-i8", "pipe": "int8",

@@ -88,9 +88,11 @@ def test_narrow_table_rows_equal_offset_call_and_padded_rows(eng):
 
 
 def test_rule_takes_the_narrow_table_from_two_replicate_groups_on(eng):
-    """Left to the library (path=None) a long narrow series rides the table kernel from two 128-replicate groups on, the fused one
-    below (tools/narrow_table_sweep.py; txm_resample.hip narrow_table_pays) -- and the choice does not move a bit."""
-    N, C, order = 1_000_000, 8, 4                 # BASELINE config 2's state shape, a tenth of its length
+    """Left to the library (path=None) a LONG narrow series (>= 4096 sampler tiles) rides the table kernel from two 128-replicate
+    groups on -- except at order 3 and, with four column quads, below order 5, where the sweeps measure a tie -- and a shorter one
+    only with two quads at orders 6-7 (tools/narrow_table_sweep.py; txm_resample.hip narrow_table_pays).  The choice does not
+    move a bit."""
+    N, C, order = 4_200_000, 8, 4                 # BASELINE config 2's state shape, 0.42 of its length
     x, u = data(N, C, 41)
     s = eng.DeviceSampler(5, 200, N)
     auto = eng.resample_vals(x, u, order, sampler=s)
@@ -98,5 +100,13 @@ def test_rule_takes_the_narrow_table_from_two_replicate_groups_on(eng):
     assert torch.equal(auto, eng.resample_vals(x, u, order, sampler=s, path="int8_fused"))
     eng.resample_vals(x, u, order, sampler=eng.DeviceSampler(5, 128, N))
     assert eng.resample_info()["kernel"] == "int8_fused"
-    eng.resample_vals(x[:500_000], u[:500_000], order, sampler=eng.DeviceSampler(5, 200, 500_000))
+    eng.resample_vals(x, u, 3, sampler=s)
+    assert eng.resample_info()["kernel"] == "int8_fused"
+    M = 1_000_000
+    sm = eng.DeviceSampler(5, 200, M)
+    eng.resample_vals(x[:M], u[:M], order, sampler=sm)
+    assert eng.resample_info()["kernel"] == "int8_fused"
+    eng.resample_vals(x[:M], u[:M], 6, sampler=sm)
+    assert eng.resample_info()["kernel"] == "int8_table"
+    eng.resample_vals(x[:500_000], u[:500_000], 6, sampler=eng.DeviceSampler(5, 200, 500_000))
     assert eng.resample_info()["kernel"] == "int8_fused"

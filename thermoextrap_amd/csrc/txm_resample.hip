@@ -885,14 +885,22 @@ static bool table_kernel_pays(int64_t nrep, int K, bool has_y) {
 // override, `applicable` = i8g_applicable() of the operands.  The call additionally needs the table's bytes in its workspace.
 // Narrow states (C <= 16): the table-fed kernel of txm_resample_i8gn.hip (128 replicates per workgroup, no fill phase) against the
 // quad-sharing variant of the kernel that draws in place -- bit for bit the same sums, so again a rule on speed alone.  Measured on
-// MI355X (tools/narrow_table_sweep.py: N = 1e6 and 1e7, C = 4 .. 16, orders 1 .. 6, 64 .. 1000 replicates;
-// profiles/r06_narrow_table_sweep.txt): 0.6 - 0.9 x at 64 replicates (the padding to 128 doubles the work), 0.9 - 1.2 x with ONE
-// group of 128 (the generator is a launch of its own there: 100 and 128 replicates), 1.0 - 1.27 x from two groups on -- except where
-// the table kernel takes two passes over the counts and the fused one a single pass (four column quads at order 4: 0.92 - 1.0 x).
+// MI355X (tools/narrow_table_sweep.py: N = 1e6 .. 3e7, C = 4 .. 16, orders 1 .. 6, 64 .. 1000 replicates), fused ms / table ms:
+//   first sweep (profiles/r06_narrow_table_sweep.txt): 0.6 - 0.9 at 64 replicates (the padding to 128 doubles the work), 0.9 - 1.2
+//   with ONE group of 128, 1.0 - 1.27 from two groups on -- the rule took the table kernel there for every long series.
+//   Re-swept (profiles/r06_narrow_table_sweep2.txt, _sweep3.txt) after the fused kernel's chunk groups got their cheaper flush and
+//   digit-summed slots (6 % faster at the median, 12 % on short series whose windows are four tiles) and the generator its packed
+//   last half group: from two groups on the two kernels are within +- 5 % of each other on most shapes, and the table kernel is
+//   clearly ahead only on LONG series (>= 4096 tiles: windows of 16 tiles and more) where the fused kernel's waves hold several
+//   row sets -- one or two column quads at every order but 3 (order 1: 1.0 - 1.3, 2: 1.0 - 1.17, 4: 1.0 - 1.27, 6: 1.0 - 1.38;
+//   order 3: 0.90 - 1.08), four quads from order 5 on (order 6: 1.04 - 1.22; orders 1 - 4: 0.86 - 1.08) -- and, on series of any
+//   length, for two quads at orders 6 and 7 (N = 1e6 .. 3e6: 1.07 - 1.20).
 static bool narrow_table_pays(int64_t N, int64_t C, int64_t nrep, int K) {
   const int64_t pad128 = cdiv(nrep, G_REPS) * G_REPS, pad64 = cdiv(nrep, I8_REPS) * I8_REPS;
   if (N < 786432 || nrep <= G_REPS || pad128 > pad64) return false;
-  return !(i8t_narrow_nq(C, K) == 4 && K == 5);
+  const int nq = i8t_narrow_nq(C, K);
+  if (N < 4194304) return nq == 2 && K >= 7;
+  return nq == 4 ? K >= 6 : K != 4;
 }
 static bool table_call_rule(size_t table_bytes, int eff, int64_t N, int64_t C, int64_t nrep, int K, bool has_y, bool applicable) {
   if (eff == TXM_PATH_FP64 || eff == TXM_PATH_INT8_FUSED || table_bytes == 0 || !applicable) return false;

@@ -206,10 +206,17 @@ def _c5_roofline(info, flops, t_k, S, N, C, K, nrep):
         n_mfma = 2 * nq * K + 2 * -(-K // 4)
         ops = 2.0 * 32 * 32 * 32 * n_mfma * S * -(-nrep // 64) * (-(-N // 1024) * 32)
         tops = ops / (t_k * 1e-3) / 1e12
+        import bench
+        tr, tr_kernels, src = bench.pmc_narrow_call_traffic("c5", {"states": S, "n_samp": N, "n_obs": C, "order": K - 1, "nrep": nrep}, "int8_fused")
+        alg_bytes = 8.0 * S * N * (C + 1)
         return {"kernel": "txm::resample_i8t_kernel, narrow-state variant with the state on the grid (int8 MFMA, Philox stage 3 fused) "
                           "+ batched pre-pass and finalize",
                 "bound": "mfma-i8", "pipe": "int8", "achieved": tops, "peak": 5000.0, "unit": "TOP/s", "frac": tops / 5000.0,
-                "traffic": None, "ms": t_k, "executed_int8_ops": ops, "algorithmic_flops": flops,
+                "traffic": tr, "traffic_source": src, "traffic_ratio": (tr / alg_bytes) if tr else None, "kernels": tr_kernels,
+                "algorithmic_bytes": alg_bytes, "hbm_executed_GBs": (tr / (t_k * 1e-3) / 1e9) if tr else None,
+                "traffic_note": "HBM bytes of ONE batched bootstrap call (pre-pass block reused) = the sum over its kernels of the FETCH_SIZE x2 + "
+                                "WRITE_SIZE figures of tools/narrow_pmc.sh's committed summary",
+                "ms": t_k, "executed_int8_ops": ops, "algorithmic_flops": flops,
                 "fp64_equiv_tflops": flops / (t_k * 1e-3) / 1e12,
                 "guard_windows_fp64": info.get("windows_fp64"),
                 "prepass_reused": info.get("prep_reused"),

@@ -8,6 +8,9 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 TAG=${1:-r06_pmc_narrow}
 RX="resample_i8[a-z]*_kernel"
+# FETCH_SIZE / WRITE_SIZE: every kernel of the bootstrap call (generator, contraction, listed FP64 launch, finalize, info word), so that
+# the call's traffic can be summed as bench.call_traffic does for the north star
+RXALL="resample_i8[a-z]*_kernel|count_table_kernel|resample_finalize|i8_info_kernel|resample_kernel"
 declare -A CMD
 CMD[c2]="tools/prof_driver.py 1e7 200 8 4 1"
 CMD[c5]="tools/prof_driver_states.py 64 1e6 4 3 100 1"
@@ -22,7 +25,8 @@ for cfg in c2 c5; do
     i=$((i+1))
     D=gpurun_out/${TAG}_${cfg}_$i
     rm -rf $D
-    timeout -k 10 300 rocprofv3 --pmc $set --kernel-include-regex "$RX" -d $D -o pmc --output-format csv -- \
+    R="$RX"; if [ "$set" = FETCH_SIZE ] || [ "$set" = WRITE_SIZE ]; then R="$RXALL"; fi
+    timeout -k 10 300 rocprofv3 --pmc $set --kernel-include-regex "$R" -d $D -o pmc --output-format csv -- \
         python3 ${CMD[$cfg]} > $D.log 2>&1 || { echo "$cfg pass $i failed"; tail -5 $D.log; }
   done
   rm -rf gpurun_out/${TAG}_${cfg}_t
@@ -43,11 +47,23 @@ shapes = {"c2": {"states": 1, "n_samp": 10_000_000, "n_obs": 8, "order": 4, "nre
 for cfg in ("c2", "c5"):
     agg = collections.OrderedDict()
     names = set()
+    perk = {}   # FETCH_SIZE / WRITE_SIZE of every kernel of the call: name -> counter -> [values]
     for f in sorted(glob.glob(f"gpurun_out/{tag}_{cfg}_[0-9]/**/*counter_collection.csv", recursive=True)):
         for r in csv.DictReader(open(f)):
+            kn = r["Kernel_Name"].replace("void ", "").split("(")[0]
+            if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                perk.setdefault(kn, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            if "resample_i8" not in kn:
+                continue
             agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-            names.add(r["Kernel_Name"].replace("void ", "").split("(")[0])
+            names.add(kn)
     c = {k: sum(v) / len(v) for k, v in agg.items()}
+    kt = {}
+    for kn, d_ in perk.items():
+        fk = sum(d_.get("FETCH_SIZE", [0.0])) / max(len(d_.get("FETCH_SIZE", [0.0])), 1) * 1024
+        wk = sum(d_.get("WRITE_SIZE", [0.0])) / max(len(d_.get("WRITE_SIZE", [0.0])), 1) * 1024
+        kt[kn] = {"read_bytes_corrected_x2": 2 * fk, "write_bytes": wk, "hbm_bytes_per_launch": 2 * fk + wk,
+                  "launches": len(d_.get("FETCH_SIZE", []))}
     ms = None
     for f in glob.glob(f"gpurun_out/{tag}_{cfg}_t/**/*kernel_stats.csv", recursive=True):
         for r in csv.DictReader(open(f)):
@@ -61,6 +77,15 @@ for cfg in ("c2", "c5"):
         d["hbm_bytes_per_launch"] = 2 * fetch + write
         d["algorithmic_bytes"] = alg
         d["traffic_ratio"] = (2 * fetch + write) / alg
+        # the whole call (prep block reused): the sum bench.call_traffic forms from the per-kernel figures
+        import bench
+        info_kernel = "int8_table" if any("i8gn" in n or "i8g_" in n for n in names) else "int8_fused"
+        tot, per = bench.call_traffic(kt, info_kernel, w["n_obs"])
+        d["kernels_traffic"] = kt
+        d["call_kernel"] = info_kernel
+        d["call_hbm_bytes"] = tot
+        d["call_traffic_ratio"] = tot / alg
+        d["call_kernels"] = per
         wave = max(c.get("SQ_WAVE_CYCLES", 1), 1)
         d["derived"] = {
             "valu_instructions_per_mfma": c.get("SQ_INSTS_VALU", 0) / max(c.get("SQ_INSTS_MFMA", 1), 1),

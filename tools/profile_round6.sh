@@ -3,7 +3,7 @@
 #   1. rocprofv3 kernel stats + FETCH/WRITE passes of the default bench command (tools/profile_round.sh)
 #   2. the same trace for config 4
 #   3. the bench lines: north star (its `traffic` = the SUM over the call's kernels from step 1's PMC file), configs 2-5
-#   4. SQ counter passes: the table kernel at the north star
+#   4. SQ counter passes: the table kernel at the north star; the narrow launches of configs 2 and 5 (tools/narrow_pmc.sh, before step 3)
 #   5. both int8 kernels over the orders (tools/profile_shapes.py) and what every rank of a 2 / 4 / 8-rank run does (tools/scaling_shapes.py)
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
@@ -23,6 +23,9 @@ if fs:
         for r in rows:
             w.writerow([r["Name"].replace("void ", "").split("(")[0], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["Percentage"]])
 PY
+# narrow states: SQ counters of the contraction launches and FETCH / WRITE of every kernel of the call (configs 2 and 5) -- before the
+# bench lines, which read the call's traffic from the summary
+bash tools/narrow_pmc.sh ${TAG}_pmc_narrow > gpurun_out/${TAG}_pmc_narrow.log 2>&1 || echo "narrow pmc failed"
 python3 bench.py --steps 10 --warmup 2 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err || exit 1
 for c in c2 c4 c3 c5; do
   python3 bench.py --config $c --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_$c.json 2>> gpurun_out/${TAG}_bench.err || echo "bench $c failed"
