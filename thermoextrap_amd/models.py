@@ -90,7 +90,8 @@ class _DeviceTable:
         self._L = L
 
     def run(self, srcs: list[torch.Tensor], nrep: int, nval: int) -> torch.Tensor:
-        ptrs = torch.tensor([t.data_ptr() for t in srcs], dtype=torch.int64, device="cuda")
+        # (the pointer table from a cache / a pinned non-blocking upload: no host wait in the middle of a step -- engine.const_tensor)
+        ptrs = engine.const_tensor([t.data_ptr() for t in srcs], torch.int64)
         out = torch.empty((self.n_funcs, nrep, nval), dtype=torch.float64, device="cuda")
         _lib.check(
             self._L.txm_eval_poly(ct.byref(self.struct), ct.c_void_p(ptrs.data_ptr()), len(srcs), nrep, nval,
@@ -289,8 +290,7 @@ class Derivatives(_Params):
                 self._tables[key] = _DeviceTable(t, specs)
             vals = self._tables[key].run([vals], src.nrep, src.nval)
         if norm:
-            fac = torch.tensor([1.0 / math.factorial(i) for i in range(order + 1)], dtype=torch.float64,
-                               device="cuda")
+            fac = engine.const_tensor([1.0 / math.factorial(i) for i in range(order + 1)], torch.float64)
             vals = vals * fac[:, None, None]
         if _device:
             return vals, src

@@ -17,6 +17,7 @@ from functools import lru_cache
 
 import torch
 
+from . import engine
 from . import moments as cmomy
 from . import symbolic as S
 from .data import DataCallbackABC, DataValues, xrwrap_xv
@@ -100,7 +101,7 @@ class VolumeDataCallback(DataCallbackABC):
         lead = [self._rep_dim] if (self._sampler is not None and self._rep_dim in st.val_dims) else []
         rest = [d for d in st.val_dims if d not in lead]
         t = st.transpose(*lead, *rest, *st.mom_dims).device_values.contiguous()  # (rep?, val..., 2, 1)
-        consts = torch.tensor([self.volume, float(self.ndim)], dtype=torch.float64, device="cuda")
+        consts = engine.const_tensor([float(self.volume), float(self.ndim)], torch.float64)
         i_dx, i_c = len(srcs), len(srcs) + 1
         srcs.extend([t, consts])
         s_rep = src.nval * 2 if lead else 0
