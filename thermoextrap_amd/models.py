@@ -583,16 +583,19 @@ class StateCollection(_Params):
         nsamp = spec.get("nsamp")
         if rep_dim is None:
             rep_dim = spec.get("rep_dim", "rep")
-        xs, us, ws = [], [], []
-        for st in self.states:
-            xt, _ = cm._dev_and_dims(st.data.xv)
-            ut, _ = cm._dev_and_dims(st.data.uv)
-            xs.append(xt.reshape(N, -1))
-            us.append(ut)
-            if st.data.weight is not None:
-                w = st.data.weight
-                ws.append(cm._dev_and_dims(w)[0] if (is_labelled(w) or isinstance(w, cm.DeviceDataArray))
-                          else engine.to_device(np.asarray(w)))
+        def gather():
+            xs, us, ws = [], [], []
+            for st in self.states:
+                xt, _ = cm._dev_and_dims(st.data.xv)
+                ut, _ = cm._dev_and_dims(st.data.uv)
+                xs.append(xt.reshape(N, -1))
+                us.append(ut)
+                if st.data.weight is not None:
+                    w = st.data.weight
+                    ws.append(cm._dev_and_dims(w)[0] if (is_labelled(w) or isinstance(w, cm.DeviceDataArray))
+                              else engine.to_device(np.asarray(w)))
+            return xs, us, ws
+
         use_device = spec.get("device")
         if use_device is None:
             # the serial loop's rule, per state (reference draws below that size): the batched call must not change
@@ -608,13 +611,19 @@ class StateCollection(_Params):
             per = max(1, min(S, self._BATCH_MAX_REPS // max(nrep, 1)))
             # ... and whose workspace stays bounded: on the int8 path every state has its own per-window partial-sum slots
             # and fallback buffers (75 MB per state at config 5's shape -- a thousand states would ask for 75 GB at once)
-            C_all = int(xs[0].shape[1])
+            C_all = int(cm._dev_and_dims(d0.xv)[0].reshape(N, -1).shape[1])
             ws1 = int(engine._L().txm_resample_vals_batched_ws_bytes(1, N, C_all, nrep, d0.order))
             per = max(1, min(per, self._BATCH_MAX_WS // max(ws1, 1)))
+            # the tile counts first: their kernel (0.2 - 0.4 ms for 64 x 100 replicates) runs while the host walks the states
+            # for their tensors, keys and checks -- a step starts on an idle device (the previous one ended in a copy to the host)
+            # (the first group's: further groups -- collections beyond _BATCH_MAX_REPS replicates -- draw theirs in turn, one table alive at a time)
+            smp0 = engine.DeviceSampler(seed, min(S, per) * nrep, N, ns, rep0=rep0)
+            xs, us, ws = gather()
             parts = []
             for a in range(0, S, per):
                 b = min(S, a + per)
-                smp = engine.DeviceSampler(seed, (b - a) * nrep, N, ns, rep0=rep0 + a * nrep)
+                smp = smp0 if a == 0 else engine.DeviceSampler(seed, (b - a) * nrep, N, ns, rep0=rep0 + a * nrep)
+                smp0 = None
                 # the int8 path's pre-pass block of this group of states lives with the group's first data object (the
                 # reference caches per data object: data.py:285); its key is the whole group's tensors, so another
                 # collection that merely starts with the same state recomputes it
@@ -633,6 +642,7 @@ class StateCollection(_Params):
             # the reference's draws, state after state from the same generator (what the serial loop consumes)
             # -- in groups of states whose index / frequency tables stay within EXPLICIT_SAMPLER_MAX elements per launch
             # (the rule above is per state: a collection just under it would otherwise build S such tables at once)
+            xs, us, ws = gather()
             rng = cm.validate_rng(spec.get("rng"))
             per = max(1, min(S, cm.EXPLICIT_SAMPLER_MAX // max(nrep * (nsamp or N), 1)))
             parts = []
