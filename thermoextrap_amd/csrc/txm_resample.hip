@@ -1330,7 +1330,7 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
         if (rc2 != TXM_OK) return rc2;
       }
       // (the slots' layout: digit sums where the fused narrow kernel with chunk groups wrote them, per-digit slots otherwise)
-      const int fin_summed = (!table_kernel && i8t_partials_summed(b.C_call, K)) ? 1 : 0;
+      const int fin_summed = (table_kernel ? C <= 16 : i8t_partials_summed(b.C_call, K)) ? 1 : 0;  // (txm_resample_i8gn.hip: always)
 #define TXM_I8_FIN2(KK, CP)                                                                            \
   hipLaunchKernelGGL((resample_finalize_i8_kernel<KK, CP>), dim3((unsigned)nrep), dim3(256), 0, st,      \
                      b.part_x, b.part_u, q.nwin, b.wflag, q.nrep_pad, nrep, b.C, piv, out, col0, C,        \

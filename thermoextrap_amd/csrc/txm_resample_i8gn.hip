@@ -479,42 +479,60 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // ================= flush: int32 accumulators of the window -> its slot of the partial sums =================
   // D layout of v_mfma_i32_32x32x32_i8: column = lane & 31, row = 8 * (reg / 4) + 4 * (lane >> 5) + reg % 4
   if (pg != nullptr && threadIdx.x == 0) __hip_atomic_store(&pg[grp & 15], 0xfffffff0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // The slot of a window holds ONE double per (replicate, power, column) -- the seven digit sums of an element added up here,
+  // ((((((d0 + d1) + d2) + d3) + d4) + d5) + d6) of (double)(int32 sum) x scale: the expression and the order
+  // resample_finalize_i8_kernel applies to per-digit slots, and what the chunk-group instances of resample_i8t_kernel store (same
+  // bits; an eighth of the bytes written here and read by the finalize: config 2's finalize 0.10 -> 0.03 ms).  A tile goes through a
+  // wave-private scratch in the (now idle) count ring -- rows of 65 words, see resample_i8t_kernel -- because an element's digits sit
+  // in seven different lanes: digit d of (replicate row m, column q4) in register 4 (m >> 3) + (m & 3) of lane
+  // 16 (d >> 2) + 4 q4 + (d & 3) + 32 ((m >> 2) & 1).
+  constexpr int XS = 65, XT = 16 * XS;
+  static_assert(T_WAVES * XT * 4 <= Geo::NB * G_BS * Geo::A_STEP, "flush scratch inside the count ring");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // no DMA piece in flight, no wave still reading the rings
+  uint32_t *xw = reinterpret_cast<uint32_t *>(lds + Geo::OFF_A) + wave * XT;
   auto flush_tile = [&](v16i &T, int q, int s) {
     uint32_t z = 0;
     asm volatile("" : "+v"(z));  // opaque zero: the addresses are formed where they are used, not hoisted and spilled
     const int64_t opq = (int64_t)z;
-    const int64_t rrow = rep0 + 32 * q + 4 * half;
-    bool valid = tdg < I8_NSL;
-    int j;
-    double dsc;
-    double *base;
-    size_t stride;
-    const int64_t cpad = a.cpad;
-    if (s < nrows) {  // a power row
-      const int c = 4 * quad + tcl;
-      valid = valid && c < a.C;
-      j = J0 + g + s * GS;
-      dsc = wt[I8_WT_DSP + j] * wt[I8_WT_DSC + (c < a.C ? c : 0)];
-      base = a.part_x + ((((size_t)win * a.nrep_pad + rrow) * K + j) * 8 + tdg) * cpad + c + opq;
-      stride = (size_t)K * cpad * 8;
-    } else {  // the u-row fragment
-      const int m = 4 * fu + tcl;
-      valid = valid && m < JN;
-      j = J0 + (m < JN ? m : 0);
-      dsc = wt[I8_WT_DSP + j] * 0x1p-50;
-      base = a.part_u + (((size_t)win * a.nrep_pad + rrow) * K + j) * 8 + tdg + opq;
-      stride = (size_t)K * 8;
-    }
-    dsc *= (double)((int64_t)1 << (8 * (tdg < I8_NSL ? tdg : 0)));
-    const int bias = tdg == I8_NSL - 1 ? T_D6_BIAS : 0;
-    if (valid) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = (r >> 2) * 8 + (r & 3);
-        if (rrow + m < a.nrep) {
-          const int v = T[r] - bias * (int)fsum[32 * q + m + 4 * half];
-          base[(size_t)m * stride] = (double)v * dsc;
+    for (int r = 0; r < 16; ++r) xw[r * XS + lane] = (uint32_t)T[r];
+    // (the wave's own LDS operations execute in order: the reads below see the stores above)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int o = lane + 64 * i, m = o >> 2, q4 = o & 3;
+      const int rr = ((m >> 3) << 2) | (m & 3), hh = (m >> 2) & 1;
+      const int64_t rrow = rep0 + 32 * q + m;
+      bool valid = rrow < a.nrep;
+      int j;
+      double dsc0;
+      double *dst;
+      if (s < nrows) {  // a power row
+        const int c = 4 * quad + q4;
+        valid = valid && c < a.C;
+        j = J0 + g + s * GS;
+        dsc0 = wt[I8_WT_DSP + j] * wt[I8_WT_DSC + (c < a.C ? c : 0)];
+        dst = a.part_x + (((size_t)win * a.nrep_pad + rrow) * K + j) * a.cpad + c + opq;
+      } else {  // the u-row fragment
+        const int mm = 4 * fu + q4;
+        valid = valid && mm < JN;
+        j = J0 + (mm < JN ? mm : 0);
+        dsc0 = wt[I8_WT_DSP + j] * 0x1p-50;
+        dst = a.part_u + ((size_t)win * a.nrep_pad + rrow) * K + j + opq;
+      }
+      if (valid) {
+        const uint32_t *src = xw + rr * XS + 32 * hh + 4 * q4;
+        int v[I8_NSL];
+#pragma unroll
+        for (int d = 0; d < I8_NSL; ++d) v[d] = (int)src[16 * (d >> 2) + (d & 3)];
+        v[I8_NSL - 1] -= T_D6_BIAS * (int)fsum[32 * q + m];
+        double sum = 0.0;
+#pragma unroll
+        for (int d = 0; d < I8_NSL; ++d) {
+          double pd = (double)v[d] * (dsc0 * (double)((int64_t)1 << (8 * d)));
+          asm volatile("" : "+v"(pd));  // (a product rounded on its own, as the stored slot was: no fused multiply-add with the sum)
+          sum = d == 0 ? pd : sum + pd;
         }
+        *dst = sum;
       }
     }
   };
