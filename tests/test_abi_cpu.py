@@ -229,18 +229,15 @@ def test_dispatch_rule_matches_the_header_thresholds(lib):
     assert W(N, 32, 130, 2, AUTO, 0) == W(N, 32, 130, 2, FUSED, 0)      # 130 -> 256 against 192
     assert W(N, 32, 100, 2, AUTO, 0) == W(N, 32, 100, 2, TABLE, 0)      # 100 -> 128 either way
     assert W(N, 32, 260, 2, AUTO, 0) == W(N, 32, 260, 2, TABLE, 0)      # 260 -> 384 against 320
-    # narrow states: the table kernel of txm_resample_i8gn.hip (order >= 1) from two replicate groups on where 128s pad no worse than 64s
+    # narrow states: the table kernel of txm_resample_i8gn.hip (order >= 1) from 65 replicates on where 128s pad no worse than 64s
     assert table(1000) <= W(N, 8, 1000, 2, TABLE, 0) - W(N, 8, 1000, 2, FUSED, 0) < table(1000) + 4096
     assert W(N, 8, 1000, 2, AUTO, 0) == W(N, 8, 1000, 2, TABLE, 0) and W(N, 8, 200, 4, AUTO, 0) == W(N, 8, 200, 4, TABLE, 0)
-    assert W(N, 8, 128, 2, AUTO, 0) == W(N, 8, 128, 2, FUSED, 0) and W(N, 8, 130, 2, AUTO, 0) == W(N, 8, 130, 2, FUSED, 0)
-    assert W(N, 16, 1000, 4, AUTO, 0) == W(N, 16, 1000, 4, FUSED, 0)    # four column quads at order 4: two table passes against one
-    assert W(N, 16, 1000, 2, AUTO, 0) == W(N, 16, 1000, 2, FUSED, 0) and W(N, 16, 1000, 5, AUTO, 0) == W(N, 16, 1000, 5, TABLE, 0)  # ... from order 5 on
-    assert W(N, 8, 1000, 3, AUTO, 0) == W(N, 8, 1000, 3, FUSED, 0) and W(N, 4, 1000, 3, AUTO, 0) == W(N, 4, 1000, 3, FUSED, 0)  # order 3, one / two quads: a tie
-    assert W(N, 4, 1000, 4, AUTO, 0) == W(N, 4, 1000, 4, TABLE, 0) and W(N, 8, 1000, 1, AUTO, 0) == W(N, 8, 1000, 1, TABLE, 0)
+    assert W(N, 8, 128, 2, AUTO, 0) == W(N, 8, 128, 2, TABLE, 0) and W(N, 8, 100, 2, AUTO, 0) == W(N, 8, 100, 2, TABLE, 0)  # one group of 128
+    assert W(N, 8, 64, 2, AUTO, 0) == W(N, 8, 64, 2, FUSED, 0) and W(N, 8, 130, 2, AUTO, 0) == W(N, 8, 130, 2, FUSED, 0)   # 64; 130 -> 256 against 192
+    for C_, o_ in ((4, 3), (8, 3), (16, 4), (16, 2), (12, 6), (4, 1)):                       # every width and order (the sweep's ties included)
+        assert W(N, C_, 1000, o_, AUTO, 0) == W(N, C_, 1000, o_, TABLE, 0), (C_, o_)
+    assert W(786432, 8, 1000, 4, AUTO, 0) == W(786432, 8, 1000, 4, TABLE, 0) and W(786431, 8, 1000, 4, AUTO, 0) == W(786431, 8, 1000, 4, FUSED, 0)
     assert W(500_000, 8, 1000, 2, AUTO, 0) == W(500_000, 8, 1000, 2, FUSED, 0)  # short series
-    M = 4_194_304                                                        # below 4096 tiles (windows of four tiles): two quads at orders 6-7 only
-    assert W(M, 8, 1000, 4, AUTO, 0) == W(M, 8, 1000, 4, TABLE, 0) and W(M - 1, 8, 1000, 4, AUTO, 0) == W(M - 1, 8, 1000, 4, FUSED, 0)
-    assert W(1_000_000, 8, 1000, 6, AUTO, 0) == W(1_000_000, 8, 1000, 6, TABLE, 0) and W(1_000_000, 4, 1000, 6, AUTO, 0) == W(1_000_000, 4, 1000, 6, FUSED, 0)
     assert W(N, 8, 1000, 0, TABLE, 0) == W(N, 8, 1000, 0, FUSED, 0)     # order 0 of a narrow state: no int8 kernel at all
     assert W(N, 32, 1000, 2, FP64, 0) <= W(N, 32, 1000, 2, FUSED, 0)
     assert lib.txm_sampler_count_table_bytes(N, 1000) == table(1000)
@@ -264,8 +261,8 @@ def test_kernel_word_is_what_a_prep_block_is_keyed_on(lib):
     # never rides a narrow call (txm_resample_i8gn.hip)
     assert Kn(N, 32, 40, 4, TABLE, 1, 1) == TABLE | WY and Kn(N, 32, 1000, 4, FUSED, 1, 1) == FUSED
     assert Kn(N, 32, 1000, 4, -1, 1, 0) == FUSED and Kn(N, 32, 1000, 4, TABLE, 0, 0) == FUSED
-    assert Kn(N, 8, 1000, 4, -1, 1, 1) == TABLE and Kn(N, 8, 100, 4, -1, 0, 1) == FUSED and Kn(N, 8, 1000, 4, FUSED, 0, 1) == FUSED
-    assert Kn(N, 8, 1000, 3, -1, 0, 1) == FUSED      # (order 3 on one or two column quads: a measured tie, the rule keeps the fused kernel)
+    assert Kn(N, 8, 1000, 4, -1, 1, 1) == TABLE and Kn(N, 8, 64, 4, -1, 0, 1) == FUSED and Kn(N, 8, 1000, 4, FUSED, 0, 1) == FUSED
+    assert Kn(N, 8, 1000, 3, -1, 0, 1) == TABLE and Kn(N, 8, 100, 3, -1, 0, 1) == TABLE
     assert Kn(N, 8, 40, 3, TABLE, 0, 1) == TABLE and Kn(N, 8, 1000, 3, TABLE, 1, 1) == TABLE and Kn(N, 8, 1000, 4, -1, 0, 0) == FUSED
     assert Kn(N, 8, 1000, 3, TABLE, 0, 0) == FUSED and Kn(N, 8, 1000, 0, TABLE, 0, 1) == FUSED  # (order 0: no narrow variant)
     assert Kn(N, 32, 16, 4, -1, 0, 1) == FP64 and Kn(N, 32, 1000, 4, FP64, 1, 1) == FP64 and Kn(N, 32, 1000, 8, -1, 0, 1) == FP64

@@ -88,25 +88,22 @@ def test_narrow_table_rows_equal_offset_call_and_padded_rows(eng):
 
 
 def test_rule_takes_the_narrow_table_from_two_replicate_groups_on(eng):
-    """Left to the library (path=None) a LONG narrow series (>= 4096 sampler tiles) rides the table kernel from two 128-replicate
-    groups on -- except at order 3 and, with four column quads, below order 5, where the sweeps measure a tie -- and a shorter one
-    only with two quads at orders 6-7 (tools/narrow_table_sweep.py; txm_resample.hip narrow_table_pays).  The choice does not
-    move a bit."""
-    N, C, order = 4_200_000, 8, 4                 # BASELINE config 2's state shape, 0.42 of its length
+    """Left to the library (path=None) a narrow series of at least 786432 samples rides the table kernel from 65 replicates on
+    wherever 128-replicate groups pad no worse than 64s, the fused one below and on shorter series (tools/narrow_table_sweep.py,
+    profiles/r06_narrow_table_sweep4.txt; txm_resample.hip narrow_table_pays).  The choice does not move a bit."""
+    N, C, order = 1_000_000, 8, 4                 # BASELINE config 2's state shape, a tenth of its length
     x, u = data(N, C, 41)
     s = eng.DeviceSampler(5, 200, N)
     auto = eng.resample_vals(x, u, order, sampler=s)
     assert eng.resample_info()["kernel"] == "int8_table"
     assert torch.equal(auto, eng.resample_vals(x, u, order, sampler=s, path="int8_fused"))
-    eng.resample_vals(x, u, order, sampler=eng.DeviceSampler(5, 128, N))
-    assert eng.resample_info()["kernel"] == "int8_fused"
-    eng.resample_vals(x, u, 3, sampler=s)
-    assert eng.resample_info()["kernel"] == "int8_fused"
-    M = 1_000_000
-    sm = eng.DeviceSampler(5, 200, M)
-    eng.resample_vals(x[:M], u[:M], order, sampler=sm)
-    assert eng.resample_info()["kernel"] == "int8_fused"
-    eng.resample_vals(x[:M], u[:M], 6, sampler=sm)
+    s1 = eng.DeviceSampler(5, 100, N)             # one group of 128
+    one = eng.resample_vals(x, u, 3, sampler=s1)
     assert eng.resample_info()["kernel"] == "int8_table"
-    eng.resample_vals(x[:500_000], u[:500_000], 6, sampler=eng.DeviceSampler(5, 200, 500_000))
+    assert torch.equal(one, eng.resample_vals(x, u, 3, sampler=s1, path="int8_fused"))
+    eng.resample_vals(x, u, order, sampler=eng.DeviceSampler(5, 64, N))
+    assert eng.resample_info()["kernel"] == "int8_fused"
+    eng.resample_vals(x, u, order, sampler=eng.DeviceSampler(5, 130, N))      # 130 -> 256 against 192
+    assert eng.resample_info()["kernel"] == "int8_fused"
+    eng.resample_vals(x[:500_000], u[:500_000], order, sampler=eng.DeviceSampler(5, 200, 500_000))
     assert eng.resample_info()["kernel"] == "int8_fused"

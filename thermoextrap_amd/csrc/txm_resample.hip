@@ -888,19 +888,20 @@ static bool table_kernel_pays(int64_t nrep, int K, bool has_y) {
 // MI355X (tools/narrow_table_sweep.py: N = 1e6 .. 3e7, C = 4 .. 16, orders 1 .. 6, 64 .. 1000 replicates), fused ms / table ms:
 //   first sweep (profiles/r06_narrow_table_sweep.txt): 0.6 - 0.9 at 64 replicates (the padding to 128 doubles the work), 0.9 - 1.2
 //   with ONE group of 128, 1.0 - 1.27 from two groups on -- the rule took the table kernel there for every long series.
-//   Re-swept (profiles/r06_narrow_table_sweep2.txt, _sweep3.txt) after the fused kernel's chunk groups got their cheaper flush and
-//   digit-summed slots (6 % faster at the median, 12 % on short series whose windows are four tiles) and the generator its packed
-//   last half group: from two groups on the two kernels are within +- 5 % of each other on most shapes, and the table kernel is
-//   clearly ahead only on LONG series (>= 4096 tiles: windows of 16 tiles and more) where the fused kernel's waves hold several
-//   row sets -- one or two column quads at every order but 3 (order 1: 1.0 - 1.3, 2: 1.0 - 1.17, 4: 1.0 - 1.27, 6: 1.0 - 1.38;
-//   order 3: 0.90 - 1.08), four quads from order 5 on (order 6: 1.04 - 1.22; orders 1 - 4: 0.86 - 1.08) -- and, on series of any
-//   length, for two quads at orders 6 and 7 (N = 1e6 .. 3e6: 1.07 - 1.20).
+//   Re-swept twice in round 6's second session, because both kernels' window boundary got cheaper in turn:
+//   (profiles/r06_narrow_table_sweep2.txt, _sweep3.txt) after the FUSED kernel's chunk groups got their cheaper flush and digit-summed
+//   slots (6 % faster at the median, 12 % on short series whose windows are four tiles): from two groups on the two kernels were within
+//   +- 5 % on most shapes, the table kernel clearly ahead only on long series at some orders -- a rule of four cases followed;
+//   (profiles/r06_narrow_table_sweep4.txt: 560 shapes, N = 1e6, 3e6, 4.5e6, 1e7) after the TABLE kernel got digit-summed slots too
+//   (one workgroup per window: a short series' call wrote and re-read as many bytes of per-digit slots as of counts): 0.65 - 1.04 at
+//   64 replicates, 0.91 - 1.33 with ONE group of 128 (100, 128 replicates: below 1 only for low orders of the widest states around
+//   N = 4.5e6), 0.92 - 1.40 from two groups on (median 1.10; N = 1e6: 0.95 - 1.38) -- four column quads at order 4 included (1e6:
+//   1.15 - 1.36, 1e7: 0.96 - 1.11).  The simple rule below picks the slower kernel by more than 3 % on 41 of the 560 shapes (worst
+//   10 %), mean regret 0.5 %; the four-case rule it replaces: 264 shapes, mean 6.3 %.
 static bool narrow_table_pays(int64_t N, int64_t C, int64_t nrep, int K) {
+  (void)C; (void)K;
   const int64_t pad128 = cdiv(nrep, G_REPS) * G_REPS, pad64 = cdiv(nrep, I8_REPS) * I8_REPS;
-  if (N < 786432 || nrep <= G_REPS || pad128 > pad64) return false;
-  const int nq = i8t_narrow_nq(C, K);
-  if (N < 4194304) return nq == 2 && K >= 7;
-  return nq == 4 ? K >= 6 : K != 4;
+  return N >= 786432 && nrep > I8_REPS && pad128 <= pad64;
 }
 static bool table_call_rule(size_t table_bytes, int eff, int64_t N, int64_t C, int64_t nrep, int K, bool has_y, bool applicable) {
   if (eff == TXM_PATH_FP64 || eff == TXM_PATH_INT8_FUSED || table_bytes == 0 || !applicable) return false;
