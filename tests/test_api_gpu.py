@@ -1161,3 +1161,31 @@ def test_from_raw_and_from_data_directly(fixture, xtrap, orc):
     m = xtrap.beta.factory_extrapmodel(fixture.beta0, xtrap.DataCentralMoments.from_raw(
         DataArray(raw, dims=("val", "xmom", "umom")), central=False))
     np.testing.assert_allclose(m.derivs(norm=False).values, fixture.legacy["derivs"][: order + 1], rtol=1e-7)
+
+
+def test_step_constants_come_from_a_cache_without_a_host_wait(fixture, xtrap):
+    """engine.const_tensor: pointer tables and small constants of the derivative evaluation are uploaded once (pinned memory, a
+    non-blocking copy) and then served from a cache -- `torch.tensor(..., device="cuda")` in the middle of a step held the host
+    until the bootstrap queued before it had run (round 6: 0.4 ms of config 5's step).  Same values, same object on a repeat,
+    one entry per (values, dtype); and a resample + derivs step evaluated twice gives the same numbers as before the cache."""
+    import torch
+
+    from thermoextrap_amd import engine
+
+    a = engine.const_tensor([1.0, 0.5, 1.0 / 6.0], torch.float64)
+    b = engine.const_tensor([1.0, 0.5, 1.0 / 6.0], torch.float64)
+    assert a is b and a.is_cuda and a.dtype == torch.float64
+    torch.cuda.synchronize()
+    assert a.cpu().tolist() == [1.0, 0.5, 1.0 / 6.0]
+    p = engine.const_tensor([a.data_ptr(), 12345], torch.int64)
+    assert p.dtype == torch.int64 and p.cpu().tolist() == [a.data_ptr(), 12345]
+    assert engine.const_tensor([1, 2], torch.int64) is not engine.const_tensor([1.0, 2.0], torch.float64)
+    n0 = len(engine._const_cache)
+    for i in range(600):                                   # bounded: the oldest entries go
+        engine.const_tensor([i, i + 1], torch.int64)
+    assert len(engine._const_cache) <= 512 and len(engine._const_cache) >= min(n0, 512)
+    m = xtrap.beta.factory_extrapmodel(fixture.beta0, fixture.xdata)
+    d1 = m.derivs(norm=True).values
+    d2 = m.derivs(norm=True).values
+    np.testing.assert_array_equal(d1, d2)
+    np.testing.assert_allclose(m.derivs(norm=False).values, fixture.legacy["derivs"][: fixture.order + 1], rtol=1e-7)
