@@ -601,8 +601,8 @@ __global__ __launch_bounds__(256) void resample_finalize_i8_kernel(
     const double *__restrict__ pivot, double *__restrict__ out, int64_t c_off, int64_t C_total,
     const double *__restrict__ fb_x, const double *__restrict__ fb_u, int fb_chunks, int64_t fb_cpad,
     const uint32_t *__restrict__ n_list, const I8State *__restrict__ states = nullptr, const int summed = 0) {
-  // summed != 0: the slots hold the digit sums already -- [window][replicate][power][column] and [window][replicate][power],
-  // written by the chunk-group instances of resample_i8t_kernel with the expression below (i8t_partials_summed)
+  // summed != 0: the x slots hold the digit sums already -- [window][replicate][power][column] -- written by the narrow kernels and
+  // resample_i8g_kernel with the expression below; summed == 1: the u slots too ([window][replicate][power])
   if (states != nullptr) {  // batched int8 call: state blockIdx.y
     const I8State e = states[blockIdx.y];
     part_x = e.part_x; part_u = e.part_u; wflag = e.wflag; pivot = e.pivot; out = e.out;
@@ -625,13 +625,24 @@ __global__ __launch_bounds__(256) void resample_finalize_i8_kernel(
   if (c < C) {
     for (int64_t w = seg; w < nwin; w += nseg) {
       if (wflag[w] != 0u) continue;
-      if (summed) {  // (uniform)
-        const double *pu_ = part_u + ((size_t)w * nrep_pad + r) * K;
+      if (summed) {  // (uniform) 1: x and u slots digit-summed; 2: x summed, u per digit (resample_i8g_kernel: its u-row digits ride
+        // in other waves' columns)
         const double *px_ = part_x + ((size_t)w * nrep_pad + r) * K * cpad + c;
+        if (summed == 1) {
+          const double *pu_ = part_u + ((size_t)w * nrep_pad + r) * K;
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-          S0[j] += pu_[j];
-          S1[j] += px_[j * cpad];
+          for (int j = 0; j < K; ++j) {
+            S0[j] += pu_[j];
+            S1[j] += px_[j * cpad];
+          }
+        } else {
+          const double *pu_ = part_u + ((size_t)w * nrep_pad + r) * K * 8;
+#pragma unroll
+          for (int j = 0; j < K; ++j) {
+            const double4 ua = *reinterpret_cast<const double4 *>(pu_ + j * 8), ub = *reinterpret_cast<const double4 *>(pu_ + j * 8 + 4);
+            S0[j] += ((((((ua.x + ua.y) + ua.z) + ua.w) + ub.x) + ub.y) + ub.z);  // digit slots 0..6, ascending
+            S1[j] += px_[j * cpad];
+          }
         }
         continue;
       }
@@ -1331,7 +1342,8 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
         if (rc2 != TXM_OK) return rc2;
       }
       // (the slots' layout: digit sums where the fused narrow kernel with chunk groups wrote them, per-digit slots otherwise)
-      const int fin_summed = (table_kernel ? C <= 16 : i8t_partials_summed(b.C_call, K)) ? 1 : 0;  // (txm_resample_i8gn.hip: always)
+      // (table-fed kernels: always -- txm_resample_i8gn.hip both x and u, txm_resample_i8g.hip x only; the fused kernel: its chunk-group instances)
+      const int fin_summed = table_kernel ? (C <= 16 ? 1 : 2) : (i8t_partials_summed(b.C_call, K) ? 1 : 0);
 #define TXM_I8_FIN2(KK, CP)                                                                            \
   hipLaunchKernelGGL((resample_finalize_i8_kernel<KK, CP>), dim3((unsigned)nrep), dim3(256), 0, st,      \
                      b.part_x, b.part_u, q.nwin, b.wflag, q.nrep_pad, nrep, b.C, piv, out, col0, C,        \

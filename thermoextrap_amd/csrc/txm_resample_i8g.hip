@@ -791,53 +791,81 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
   // ================= flush: int32 accumulators of the window -> its slot of the partial sums =================
   // D layout of v_mfma_i32_32x32x32_i8: column = lane & 31, row = 8 * (reg / 4) + 4 * (lane >> 5) + reg % 4
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // x slots: ONE double per (replicate, power, column) -- the seven digit sums of an element added up here,
+  // ((((((d0 + d1) + d2) + d3) + d4) + d5) + d6) of (double)(int32 sum) x scale: the expression and the order
+  // resample_finalize_i8_kernel applies to per-digit slots, and what the narrow kernels store (same bits; an eighth of the x slots'
+  // bytes written here and read by the finalize: on a short wide series -- N = 1e6, 32 observables, 1000 replicates: 245 windows --
+  // the slots were 2.6 GB around a 2.9 ms call, the finalize 0.44 ms of it).  A tile goes through a wave-private scratch in the (now
+  // idle) count / x rings, rows of 65 words (see resample_i8t_kernel): digit d of (replicate row m, column q4) sits in register
+  // 4 (m >> 3) + (m & 3) of lane 16 (d >> 2) + 4 q4 + (d & 3) + 32 ((m >> 2) & 1).  The u-row digits that ride in the dead eighth
+  // byte of OTHER waves' columns stay per-digit slots (part_u), and so does the second matrix's row set (part_y): the finalize is told
+  // (mode 2: x summed, u per digit).
+  constexpr int XS = 65, XT = 16 * XS;
+  static_assert(OFF_A + T_WAVES * XT * 4 <= OFF_RAW, "flush scratch inside the count and x rings");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // no DMA piece in flight, no wave still reading the rings
   if (pg != nullptr && threadIdx.x == 0) __hip_atomic_store(&pg[grp & 15], 0xfffffff0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   auto odig_of = [](int w, int c) { return 4 * (w & 1) + c; };  // the u-row digit column c of wave w carries in its dead byte
+  uint32_t *xw = reinterpret_cast<uint32_t *>(lds + OFF_A) + wave * XT;
   auto flush_tile = [&](v16i &T, int q, int rs) {
     uint32_t z = 0;
     asm volatile("" : "+v"(z));  // opaque zero: the addresses are formed where they are used, not hoisted and spilled
     const int64_t opq = (int64_t)z;
-    const int64_t rrow = rep0 + 32 * q + 4 * half;
-    bool valid = tdg < I8_NSL;
-    int dgt = tdg < I8_NSL ? tdg : 0;
-    int j = 0;
-    double dsc;
-    double *base;
-    size_t stride;
-    const int64_t cpad = a.cpad;
     const bool is_y = YS && rs == JN;
-    if (tdg == 7 && !is_y && ofi == rs && odig_of(wave, tcl) < 7) {
-      // the u-row digit this column's dead byte carried: [window][replicate][power][digit slot]
-      dgt = odig_of(wave, tcl);
-      valid = true;
-      j = J0 + rs;
-      dsc = wt[I8_WT_DSP + j] * 0x1p-50;
-      base = a.part_u + ((size_t)win * a.nrep_pad + rrow) * K * 8 + (size_t)j * 8 + dgt + opq;
-      stride = (size_t)K * 8;
-    } else if (is_y) {
+    if (is_y) {  // the second matrix's row set: per-digit slots [window][replicate][digit slot][column], as before
+      const int64_t rrow = rep0 + 32 * q + 4 * half;
       const int c = 4 * wave + tcl;
-      valid = valid && c < a.C;
-      dsc = wty[I8_WT_DSP + 0] * wty[I8_WT_DSC + (c < a.C ? c : 0)];
-      base = a.part_y + (((size_t)win * a.nrep_pad + rrow) * 8 + dgt) * cpad + c + opq;
-      stride = (size_t)8 * cpad;
-    } else {
-      const int c = 4 * wave + tcl;
-      valid = valid && c < a.C;
-      j = J0 + rs;
-      dsc = wt[I8_WT_DSP + j] * wt[I8_WT_DSC + (c < a.C ? c : 0)];
-      base = a.part_x + ((((size_t)win * a.nrep_pad + rrow) * K + j) * 8 + dgt) * cpad + c + opq;
-      stride = (size_t)K * cpad * 8;
-    }
-    dsc *= (double)((int64_t)1 << (8 * dgt));
-    const int bias = dgt == I8_NSL - 1 ? T_D6_BIAS : 0;
-    if (valid) {
+      const bool valid = tdg < I8_NSL && c < a.C;
+      const int dgt = tdg < I8_NSL ? tdg : 0;
+      double dsc = wty[I8_WT_DSP + 0] * wty[I8_WT_DSC + (c < a.C ? c : 0)];
+      double *base = a.part_y + (((size_t)win * a.nrep_pad + rrow) * 8 + dgt) * a.cpad + c + opq;
+      const size_t stride = (size_t)8 * a.cpad;
+      dsc *= (double)((int64_t)1 << (8 * dgt));
+      const int bias = dgt == I8_NSL - 1 ? T_D6_BIAS : 0;
+      if (valid) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = (r >> 2) * 8 + (r & 3);
-        if (rrow + m < a.nrep) {
-          const int v = T[r] - bias * (int)fsum[32 * q + m + 4 * half];
-          base[(size_t)m * stride] = (double)v * dsc;
+        for (int r = 0; r < 16; ++r) {
+          const int m = (r >> 2) * 8 + (r & 3);
+          if (rrow + m < a.nrep) {
+            const int v = T[r] - bias * (int)fsum[32 * q + m + 4 * half];
+            base[(size_t)m * stride] = (double)v * dsc;
+          }
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xw[r * XS + lane] = (uint32_t)T[r];
+    // (the wave's own LDS operations execute in order: the reads below see the stores above)
+    const int j = J0 + rs;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int o = lane + 64 * i, m = o >> 2, q4 = o & 3;
+      const int rr = ((m >> 3) << 2) | (m & 3), hh = (m >> 2) & 1;
+      const int64_t rrow = rep0 + 32 * q + m;
+      if (rrow < a.nrep) {
+        const uint32_t *src = xw + rr * XS + 32 * hh + 4 * q4;
+        const int fs = (int)fsum[32 * q + m];
+        const int c = 4 * wave + q4;
+        if (c < a.C) {
+          int v[I8_NSL];
+#pragma unroll
+          for (int d = 0; d < I8_NSL; ++d) v[d] = (int)src[16 * (d >> 2) + (d & 3)];
+          v[I8_NSL - 1] -= T_D6_BIAS * fs;
+          const double dsc0 = wt[I8_WT_DSP + j] * wt[I8_WT_DSC + c];
+          double sum = 0.0;
+#pragma unroll
+          for (int d = 0; d < I8_NSL; ++d) {
+            double pd = (double)v[d] * (dsc0 * (double)((int64_t)1 << (8 * d)));
+            asm volatile("" : "+v"(pd));  // (a product rounded on its own, as the stored slot was: no fused multiply-add with the sum)
+            sum = d == 0 ? pd : sum + pd;
+          }
+          a.part_x[(((size_t)win * a.nrep_pad + rrow) * K + j) * a.cpad + c + opq] = sum;
+        }
+        const int dgt = odig_of(wave, q4);
+        if (ofi == rs && dgt < 7) {  // the u-row digit this column's dead byte carried: [window][replicate][power][digit slot]
+          const int v7 = (int)src[16 + 3] - (dgt == I8_NSL - 1 ? T_D6_BIAS * fs : 0);
+          const double dsc = (wt[I8_WT_DSP + j] * 0x1p-50) * (double)((int64_t)1 << (8 * dgt));
+          a.part_u[((size_t)win * a.nrep_pad + rrow) * K * 8 + (size_t)j * 8 + dgt + opq] = (double)v7 * dsc;
         }
       }
     }
