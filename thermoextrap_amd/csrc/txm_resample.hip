@@ -1282,6 +1282,7 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
     b.ldy_s = ldy_s;
     b.ypivot = ypiv;
     b.part_y = (double *)((char *)ws + q.off_py);
+    b.part_summed = with_y ? 0 : 1;  // (read by the wide fused kernel: digit-summed slots unless the second matrix's finalize needs per-digit u slots)
     b.progress = (throttle_on() && q.n_rbg > 1) ? (uint32_t *)((char *)ws + q.off_prog) : nullptr;
     // the FP64 kernel in listed mode: contracts the windows the precision guard flags (none on ordinary data)
     ResampleArgs f;
@@ -1343,7 +1344,9 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
       }
       // (the slots' layout: digit sums where the fused narrow kernel with chunk groups wrote them, per-digit slots otherwise)
       // (table-fed kernels: always -- txm_resample_i8gn.hip both x and u, txm_resample_i8g.hip x only; the fused kernel: its chunk-group instances)
-      const int fin_summed = table_kernel ? (C <= 16 ? 1 : 2) : (i8t_partials_summed(b.C_call, K) ? 1 : 0);
+      // the fused kernel: narrow instances always, the wide one unless a second matrix rides the call (its finalize reads per-digit u slots)
+      const int fin_summed = table_kernel ? (C <= 16 ? 1 : 2)
+                                          : (i8t_narrow_nq(b.C_call, K) != 0 ? (i8t_partials_summed(b.C_call, K) ? 1 : 0) : b.part_summed);
 #define TXM_I8_FIN2(KK, CP)                                                                            \
   hipLaunchKernelGGL((resample_finalize_i8_kernel<KK, CP>), dim3((unsigned)nrep), dim3(256), 0, st,      \
                      b.part_x, b.part_u, q.nwin, b.wflag, q.nrep_pad, nrep, b.C, piv, out, col0, C,        \
@@ -1657,6 +1660,7 @@ static int resample_batched_i8(const txm_state_ptrs *states_host, int64_t S, int
   a.x = vec_ok ? states_host[0].x : reinterpret_cast<const double *>((uintptr_t)8);  // (the pre-pass reads its alignment only)
   a.ldx_s = ldx_s; a.u = states_host[0].u; a.w = states_host[0].w; a.N = N; a.C = C; a.nrep = nrep;
   a.col0 = 0; a.C_call = C;
+  a.part_summed = 1;  // (narrow instances always store digit-summed slots; the field is the wide instance's)
   a.counts = counts;
   a.k0 = (uint32_t)spec->seed;
   a.k1 = (uint32_t)(spec->seed >> 32);

@@ -71,6 +71,8 @@ struct I8Args {
   double *part_x;          // [nwin][nrep_pad][K][8 digit slots][cpad columns]
   int cpad;                // columns of a row of part_x: 32, or 4 / 8 where the narrow-state kernel runs (i8_cpad)
   double *part_u;          // [nwin][nrep_pad][K][8 digit slots]
+  int part_summed;         // wide fused kernel: 1 = store digit-summed slots [nwin][nrep_pad][K][cpad] / [nwin][nrep_pad][K] (the narrow
+                           // kernels always do, the wide table-fed kernel for x only: see resample_finalize_i8_kernel's `summed`)
   // optional second sample matrix (txm_resample_opts.y): order-0 sums sum_i f w (y_c - py_c) of its 32 columns, carried
   // as one more row set of the LAST pass of the transposing-read kernel (nullptr: none)
   const double *y;

@@ -98,7 +98,9 @@ constexpr bool T_FLUSH_SERIAL = false;
 // copy of the arguments from the I8State table behind `if (a.states)`, and that copy cost the SINGLE-state narrow kernel 18 %
 // (config 2: 3.70 vs 3.09 ms per step, same box, gpurun_out/r4_c2_ab3.log) -- its fields live in scalar registers the kernel
 // does not have, where kernel arguments are re-loaded on demand.  The batched instances read a per-state argument block instead.
-template <int J0, int JN, bool WEIGHTED, bool YS = false, int NQ = 8, bool BATCHED = false>
+// PD (wide instance only): per-digit slots although the launch has no second matrix -- the FIRST pass of a two-pass call that carries one
+// in its last pass (the call's finalize reads one layout).
+template <int J0, int JN, bool WEIGHTED, bool YS = false, int NQ = 8, bool BATCHED = false, bool PD = false>
 __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void resample_i8t_kernel(const I8Args a_in, const int K) {
   static_assert(NQ == 8 || NQ == 4 || NQ == 2 || NQ == 1, "column quads");
   static_assert(!BATCHED || NQ < 8, "batched launches: narrow states");
@@ -680,6 +682,56 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (wave == 0) fsum[lane] = fdraws;
     fdraws = 0;
     __syncthreads();
+    constexpr int XS = 65;        // words per register row of a tile in the LDS (64 lanes + 1: see the reads of flush_summed)
+    constexpr int XT = 16 * XS;   // words per tile
+    // element (replicate row m, column / monomial q4) of a summed tile: its digit d sits in register 4 (m >> 3) + (m & 3) of
+    // lane 16 (d >> 2) + 4 q4 + (d & 3) + 32 ((m >> 2) & 1) (the D layout of v_mfma_i32_32x32x32_i8; tile column -> (column,
+    // digit) as tcl / tdg above).  Lane L takes the elements L and L + 64 of the tile's 32 x 4.  With rows of 65 words the
+    // lanes of one read spread over rr + 4 q4 (+ const): four-way bank conflicts; rows of 64 put all sixteen replicate rows of
+    // a lane quartet on one bank.
+    auto flush_summed = [&](const uint32_t *tl, int h, int rs, int ufrag) {
+      uint32_t z = 0;
+      asm volatile("" : "+v"(z));  // (addresses formed here, not hoisted out of the window loop and spilled: see flush_tile)
+      const int64_t opq = (int64_t)z;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int o = lane + 64 * i, m = o >> 2, q4 = o & 3;
+        const int rr = ((m >> 3) << 2) | (m & 3), hh = (m >> 2) & 1;
+        bool valid;
+        int j;
+        double dsc0;
+        double *dst;
+        if (ufrag < 0) {
+          const int c = 4 * quad + q4;
+          valid = c < a.C && row_live(rs);
+          j = J0 + (row_live(rs) ? g + rs * GS : 0);
+          dsc0 = wt[I8_WT_DSP + j] * wt[I8_WT_DSC + (c < a.C ? c : 0)];
+          dst = a.part_x + (((size_t)win * a.nrep_pad + rep0 + 32 * h + m) * K + j) * a.cpad + c + opq;
+        } else {
+          const int mm = 4 * ufrag + q4;
+          valid = mm < JN;
+          j = J0 + (mm < JN ? mm : 0);
+          dsc0 = wt[I8_WT_DSP + j] * 0x1p-50;
+          dst = a.part_u + ((size_t)win * a.nrep_pad + rep0 + 32 * h + m) * K + j + opq;
+        }
+        if (valid) {
+          const uint32_t *src = tl + rr * XS + 32 * hh + 4 * q4;
+          const int fs = (int)fsum[32 * h + m];
+          int v[I8_NSL];
+#pragma unroll
+          for (int d = 0; d < I8_NSL; ++d) v[d] = (int)src[16 * (d >> 2) + (d & 3)];
+          v[I8_NSL - 1] -= T_D6_BIAS * fs;
+          double sum = 0.0;
+#pragma unroll
+          for (int d = 0; d < I8_NSL; ++d) {
+            double pd = (double)v[d] * (dsc0 * (double)((int64_t)1 << (8 * d)));
+            asm volatile("" : "+v"(pd));  // (a product rounded on its own, as the stored slot was: no fused multiply-add with the sum)
+            sum = d == 0 ? pd : sum + pd;
+          }
+          *dst = sum;
+        }
+      }
+    };
     if constexpr (CG > 1 && !T_FLUSH_SERIAL) {
       // chunk groups: the groups' int32 accumulators are added up in the (now idle) count tile -- group 0 stores its tiles, the
       // others add theirs with LDS atomics (exact, whatever the order: what is flushed is what one group contracting all 32 chunks
@@ -695,62 +747,12 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       // 2.5 GB of slots, as much as its samples; finalize 0.46 ms of a 5.8 ms call).  Same bits (I8Args::cpad rows without the
       // digit dimension: i8t_partials_summed() tells the host which layout a launch writes).
       constexpr int NT = 2 * NS + 1;                          // tiles of a wave: NS row sets x 2 replicate halves + the u-row tile
-      constexpr int XS = 65;                                  // words per register row of an exchanged tile (64 lanes + 1: see the reads)
-      constexpr int XT = 16 * XS;                             // words per tile
       constexpr int RT0 = T_CNT_BYTES / 4 / (WPG * XT);       // tiles per wave and round that fit the 64 KiB count tile
       constexpr int RT = RT0 < NT ? RT0 : NT;
       static_assert(RT >= 1 && WPG * RT * XT * 4 <= T_CNT_BYTES, "exchange slots");
       uint32_t *xrole = cntw + (size_t)((wave % WPG) * RT) * XT;  // this role's tiles of the round
       uint32_t *xch = xrole + lane;
       auto tile_of = [&](int tt) -> v16i & { return tt < 2 * NS ? acc[tt >> 1][tt & 1] : accu; };
-      // element (replicate row m, column / monomial q4) of a summed tile: its digit d sits in register 4 (m >> 3) + (m & 3) of
-      // lane 16 (d >> 2) + 4 q4 + (d & 3) + 32 ((m >> 2) & 1) (the D layout of v_mfma_i32_32x32x32_i8; tile column -> (column,
-      // digit) as tcl / tdg above).  Lane L takes the elements L and L + 64 of the tile's 32 x 4.  With rows of 65 words the
-      // lanes of one read spread over rr + 4 q4 (+ const): four-way bank conflicts; rows of 64 put all sixteen replicate rows of
-      // a lane quartet on one bank.
-      auto flush_summed = [&](const uint32_t *tl, int h, int rs, int ufrag) {
-        uint32_t z = 0;
-        asm volatile("" : "+v"(z));  // (addresses formed here, not hoisted out of the window loop and spilled: see flush_tile)
-        const int64_t opq = (int64_t)z;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int o = lane + 64 * i, m = o >> 2, q4 = o & 3;
-          const int rr = ((m >> 3) << 2) | (m & 3), hh = (m >> 2) & 1;
-          bool valid;
-          int j;
-          double dsc0;
-          double *dst;
-          if (ufrag < 0) {
-            const int c = 4 * quad + q4;
-            valid = c < a.C && row_live(rs);
-            j = J0 + (row_live(rs) ? g + rs * GS : 0);
-            dsc0 = wt[I8_WT_DSP + j] * wt[I8_WT_DSC + (c < a.C ? c : 0)];
-            dst = a.part_x + (((size_t)win * a.nrep_pad + rep0 + 32 * h + m) * K + j) * a.cpad + c + opq;
-          } else {
-            const int mm = 4 * ufrag + q4;
-            valid = mm < JN;
-            j = J0 + (mm < JN ? mm : 0);
-            dsc0 = wt[I8_WT_DSP + j] * 0x1p-50;
-            dst = a.part_u + ((size_t)win * a.nrep_pad + rep0 + 32 * h + m) * K + j + opq;
-          }
-          if (valid) {
-            const uint32_t *src = tl + rr * XS + 32 * hh + 4 * q4;
-            const int fs = (int)fsum[32 * h + m];
-            int v[I8_NSL];
-#pragma unroll
-            for (int d = 0; d < I8_NSL; ++d) v[d] = (int)src[16 * (d >> 2) + (d & 3)];
-            v[I8_NSL - 1] -= T_D6_BIAS * fs;
-            double sum = 0.0;
-#pragma unroll
-            for (int d = 0; d < I8_NSL; ++d) {
-              double pd = (double)v[d] * (dsc0 * (double)((int64_t)1 << (8 * d)));
-              asm volatile("" : "+v"(pd));  // (a product rounded on its own, as the stored slot was: no fused multiply-add with the sum)
-              sum = d == 0 ? pd : sum + pd;
-            }
-            *dst = sum;
-          }
-        }
-      };
       t_static_for<(NT + RT - 1) / RT>([&](auto rc) {
         constexpr int t0 = decltype(rc)::value * RT;
         if (cgrp == 0) {
@@ -821,7 +823,25 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
           }
         }
       }
-      if (CG == 1 || cgrp == 0) {  // wave-uniform
+      // instances without chunk groups: every wave writes its own tiles out -- digit-summed as above, a tile at a time through a
+      // wave-private scratch in the idle count tile (narrow instances always; the wide instance unless the CALL carries a second
+      // matrix, whose finalize reads per-digit u slots: YS launches, and PD = the first pass of such a call)
+      constexpr bool summed1 = CG == 1 && !T_FLUSH_SERIAL && (NQ < 8 || (!YS && !PD));
+      if constexpr (summed1) {
+        uint32_t *xw = cntw + (size_t)wave * XT;
+        auto via_lds = [&](v16i &T, int h, int rs, int ufrag) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) xw[r * XS + lane] = (uint32_t)T[r];
+          flush_summed(xw, h, rs, ufrag);  // (the wave's own LDS operations execute in order)
+          T = (v16i)(0);
+        };
+#pragma unroll
+        for (int fi = 0; fi < NS; ++fi) {
+          via_lds(acc[fi][0], hswap, fi, -1);
+          via_lds(acc[fi][1], 1 - hswap, fi, -1);
+        }
+        if (has_ut) via_lds(accu, uh, 0, fu);  // wave-uniform
+      } else if (CG == 1 || cgrp == 0) {  // wave-uniform
 #pragma unroll
         for (int fi = 0; fi < NS; ++fi) {
           flush_tile(acc[fi][0], hswap, fi, -1);
@@ -844,7 +864,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 }
 
 // ---------------------------------------------------------------------------
-template <int J0, int JN, bool WEIGHTED, bool YS = false, int NQ = 8>
+template <int J0, int JN, bool WEIGHTED, bool YS = false, int NQ = 8, bool PD = false>
 static int launch_pass_t(const I8Args &a, int K, size_t prog_bytes, hipStream_t st) {
   if (a.progress != nullptr) TXM_HIP(hipMemsetAsync(a.progress, 0, prog_bytes, st));
   constexpr int gs = 8 / NQ / T_CG_OF(NQ, JN), ns = (JN + gs - 1) / gs + (YS ? 1 : 0), npt = JN + ((YS && WEIGHTED && J0 > 0) ? 1 : 0);
@@ -865,8 +885,8 @@ static int launch_pass_t(const I8Args &a, int K, size_t prog_bytes, hipStream_t 
     return TXM_ERR_INVALID;
   }
   const dim3 grid((unsigned)(a.n_chunks * a.n_rbg));
-  TXM_SET_MAX_LDS((&resample_i8t_kernel<J0, JN, WEIGHTED, YS, NQ>), lds);
-  hipLaunchKernelGGL((resample_i8t_kernel<J0, JN, WEIGHTED, YS, NQ>), grid, block, lds, st, a, K);
+  TXM_SET_MAX_LDS((&resample_i8t_kernel<J0, JN, WEIGHTED, YS, NQ, false, PD>), lds);
+  hipLaunchKernelGGL((resample_i8t_kernel<J0, JN, WEIGHTED, YS, NQ, false, PD>), grid, block, lds, st, a, K);
   TXM_LAUNCH_CHECK();
   return TXM_OK;
 }
@@ -899,15 +919,12 @@ int i8_cpad(int64_t C_call, int K) {
   return nq ? 4 * nq : I8_CPAD;
 }
 
-// Which layout the launches of launch_resample_i8t leave in I8Args::part_x / part_u for a shape: instances with chunk groups
-// (every pass of the narrow call) add the digit sums up in their flush and store [window][replicate][power][column] (u-row:
-// [window][replicate][power]); everything else stores the per-digit slots [...][power][8 digit slots][column].  The finalize is
-// told which (resample_finalize_i8_kernel's SUMMED).
+// Which layout the launches of launch_resample_i8t leave in I8Args::part_x / part_u for a NARROW shape: every narrow instance adds
+// the digit sums up in its flush and stores [window][replicate][power][column] (u-row: [window][replicate][power]) -- the per-digit
+// slots [...][power][8 digit slots][column] only in the A/B build of the serial flush.  The wide instance does what
+// I8Args::part_summed says (0 when the call carries a second matrix).  The finalize is told which (its `summed` argument).
 bool i8t_partials_summed(int64_t C_call, int K) {
-  const int nq = i8t_narrow_nq(C_call, K);
-  if (nq == 0 || T_FLUSH_SERIAL) return false;
-  if (nq == 4 && K >= 7) return T_CG_OF(4, 4) > 1 && T_CG_OF(4, K - 4) > 1;  // the two passes of launch_resample_i8t
-  return T_CG_OF(nq, K) > 1;
+  return i8t_narrow_nq(C_call, K) != 0 && !T_FLUSH_SERIAL;   // (wide states: I8Args::part_summed, set by the caller)
 }
 
 template <int NQ>
@@ -953,6 +970,11 @@ int launch_resample_i8t(const I8Args &a, int K, bool weighted, size_t prog_bytes
     return TXM_ERR_INVALID;
   }
 #define T_PASS(J0_, JN_) (weighted ? launch_pass_t<J0_, JN_, true>(a, K, prog_bytes, st) : launch_pass_t<J0_, JN_, false>(a, K, prog_bytes, st))
+  // the first pass of a two-pass call whose LAST pass carries a second matrix: per-digit slots like that pass (one layout per call)
+#define T_FIRST(J0_, JN_)                                                                                                      \
+  (ys ? (weighted ? launch_pass_t<J0_, JN_, true, false, 8, true>(a, K, prog_bytes, st)                                        \
+                  : launch_pass_t<J0_, JN_, false, false, 8, true>(a, K, prog_bytes, st))                                      \
+      : T_PASS(J0_, JN_))
 #define T_LAST(J0_, JN_)                                                                                                   \
   (ys ? (weighted ? launch_pass_t<J0_, JN_, true, true>(a, K, prog_bytes, st) : launch_pass_t<J0_, JN_, false, true>(a, K, prog_bytes, st)) \
       : T_PASS(J0_, JN_))
@@ -962,12 +984,13 @@ int launch_resample_i8t(const I8Args &a, int K, bool weighted, size_t prog_bytes
     case 3: rc = T_LAST(0, 3); break;
     case 4: rc = T_LAST(0, 4); break;
     case 5: rc = T_PASS(0, 5); break;
-    case 6: rc = T_PASS(0, 3); if (rc == TXM_OK) rc = T_LAST(3, 3); break;
-    case 7: rc = T_PASS(0, 4); if (rc == TXM_OK) rc = T_LAST(4, 3); break;
-    case 8: rc = T_PASS(0, 4); if (rc == TXM_OK) rc = T_LAST(4, 4); break;
+    case 6: rc = T_FIRST(0, 3); if (rc == TXM_OK) rc = T_LAST(3, 3); break;
+    case 7: rc = T_FIRST(0, 4); if (rc == TXM_OK) rc = T_LAST(4, 3); break;
+    case 8: rc = T_FIRST(0, 4); if (rc == TXM_OK) rc = T_LAST(4, 4); break;
     default: set_error("resample_i8t: order out of range"); return TXM_ERR_INVALID;
   }
 #undef T_PASS
+#undef T_FIRST
 #undef T_LAST
   return rc;
 }
