@@ -216,8 +216,9 @@ int txm_sampler_count_table(const txm_sampler_spec *spec_host, const uint32_t *c
  *     - the kernel that draws the per-sample counts in place (64 replicates per workgroup; orders 0-4 one pass over the
  *       sampler stream, 5-7 two): wide states at orders 3 and 4 without a second matrix at nrep <= 128, replicate counts that
  *       pad badly to 128 (4 * ceil128(nrep) > 5 * ceil64(nrep)), misaligned operands (x not 16-byte aligned or an odd row
- *       pitch); narrow states at nrep <= 64, where 128s pad worse than 64s (ceil128(nrep) > ceil64(nrep)), N < 786432, a row
- *       shorter than a whole column quad (C = 1..3 in a tight array) (txm_resample.hip narrow_table_pays: the sweep it is read from);
+ *       pitch); narrow states at nrep <= 64, where 128s pad worse than 64s (ceil128(nrep) > ceil64(nrep)), N < 786432, 13-16
+ *       observables at order 4 (one fused pass against two table passes), a row shorter than a whole column quad (C = 1..3 in a
+ *       tight array) (txm_resample.hip narrow_table_pays: the sweeps it is read from);
  *     - the count-table kernels (128 replicates per workgroup over ONE table of per-sample counts, txm_sampler_count_table --
  *       wide states: at most three row sets per pass, every call with a second matrix rides it; narrow states: the column
  *       quads and powers of the state in one pass, two for four quads from order 4): all other calls whose workspace holds the

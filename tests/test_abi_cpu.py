@@ -234,7 +234,8 @@ def test_dispatch_rule_matches_the_header_thresholds(lib):
     assert W(N, 8, 1000, 2, AUTO, 0) == W(N, 8, 1000, 2, TABLE, 0) and W(N, 8, 200, 4, AUTO, 0) == W(N, 8, 200, 4, TABLE, 0)
     assert W(N, 8, 128, 2, AUTO, 0) == W(N, 8, 128, 2, TABLE, 0) and W(N, 8, 100, 2, AUTO, 0) == W(N, 8, 100, 2, TABLE, 0)  # one group of 128
     assert W(N, 8, 64, 2, AUTO, 0) == W(N, 8, 64, 2, FUSED, 0) and W(N, 8, 130, 2, AUTO, 0) == W(N, 8, 130, 2, FUSED, 0)   # 64; 130 -> 256 against 192
-    for C_, o_ in ((4, 3), (8, 3), (16, 4), (16, 2), (12, 6), (4, 1)):                       # every width and order (the sweep's ties included)
+    assert W(N, 16, 1000, 4, AUTO, 0) == W(N, 16, 1000, 4, FUSED, 0) and W(N, 12, 200, 4, AUTO, 0) == W(N, 12, 200, 4, FUSED, 0)  # four quads at order 4: one fused pass against two
+    for C_, o_ in ((4, 3), (8, 3), (16, 5), (16, 2), (12, 6), (4, 1), (8, 4)):                # every other width and order (the sweep's ties included)
         assert W(N, C_, 1000, o_, AUTO, 0) == W(N, C_, 1000, o_, TABLE, 0), (C_, o_)
     assert W(786432, 8, 1000, 4, AUTO, 0) == W(786432, 8, 1000, 4, TABLE, 0) and W(786431, 8, 1000, 4, AUTO, 0) == W(786431, 8, 1000, 4, FUSED, 0)
     assert W(500_000, 8, 1000, 2, AUTO, 0) == W(500_000, 8, 1000, 2, FUSED, 0)  # short series

@@ -907,12 +907,15 @@ static bool table_kernel_pays(int64_t nrep, int K, bool has_y) {
 //   (one workgroup per window: a short series' call wrote and re-read as many bytes of per-digit slots as of counts): 0.65 - 1.04 at
 //   64 replicates, 0.91 - 1.33 with ONE group of 128 (100, 128 replicates: below 1 only for low orders of the widest states around
 //   N = 4.5e6), 0.92 - 1.40 from two groups on (median 1.10; N = 1e6: 0.95 - 1.38) -- four column quads at order 4 included (1e6:
-//   1.15 - 1.36, 1e7: 0.96 - 1.11).  The simple rule below picks the slower kernel by more than 3 % on 41 of the 560 shapes (worst
-//   10 %), mean regret 0.5 %; the four-case rule it replaces: 264 shapes, mean 6.3 %.
+//   1.15 - 1.36, 1e7: 0.96 - 1.11).  A one-line rule followed (mean regret 0.5 % on that sweep; the four-case rule: 6.3 %);
+//   (profiles/r06_narrow_table_sweep5.txt: 420 shapes) after the fused instances WITHOUT chunk groups got digit-summed slots as well:
+//   four column quads at order 4 -- one fused pass against two table passes -- 16 - 19 % faster on the fused kernel, 0.88 - 1.05 now:
+//   the exception of the first rule is back.  The rule below picks the slower kernel by more than 3 % on 19 of the 420 shapes (worst
+//   10 %), mean regret 0.4 %.
 static bool narrow_table_pays(int64_t N, int64_t C, int64_t nrep, int K) {
-  (void)C; (void)K;
   const int64_t pad128 = cdiv(nrep, G_REPS) * G_REPS, pad64 = cdiv(nrep, I8_REPS) * I8_REPS;
-  return N >= 786432 && nrep > I8_REPS && pad128 <= pad64;
+  if (N < 786432 || nrep <= I8_REPS || pad128 > pad64) return false;
+  return !(i8t_narrow_nq(C, K) == 4 && K == 5);
 }
 static bool table_call_rule(size_t table_bytes, int eff, int64_t N, int64_t C, int64_t nrep, int K, bool has_y, bool applicable) {
   if (eff == TXM_PATH_FP64 || eff == TXM_PATH_INT8_FUSED || table_bytes == 0 || !applicable) return false;

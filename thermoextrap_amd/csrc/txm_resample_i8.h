@@ -68,7 +68,7 @@ struct I8Args {
   // partial sums: ONE SLOT PER SCALING WINDOW, written once (no read-modify-write, no zeroing; the finalize kernel
   // skips the windows the guard flagged and adds the rest in window order, so a replicate's sums do not depend on the
   // launch geometry)
-  double *part_x;          // [nwin][nrep_pad][K][8 digit slots][cpad columns]
+  double *part_x;          // [nwin][nrep_pad][K][8 digit slots][cpad columns], or digit-summed [nwin][nrep_pad][K][cpad] (part_summed)
   int cpad;                // columns of a row of part_x: 32, or 4 / 8 where the narrow-state kernel runs (i8_cpad)
   double *part_u;          // [nwin][nrep_pad][K][8 digit slots]
   int part_summed;         // wide fused kernel: 1 = store digit-summed slots [nwin][nrep_pad][K][cpad] / [nwin][nrep_pad][K] (the narrow

@@ -29,8 +29,10 @@
 // with ONE LANE PER REPLICATE (lane = replicate, the eight waves split the Philox calls): all 64 lanes of a ds_add hit
 // 64 consecutive words -- no bank conflict by construction (a [replicate][word] layout lost 11 cycles per ds_add).
 // Partial sums: one slot per SCALING WINDOW (a fixed block of samples: the window size depends on N only),
-// part[window][replicate][power][digit slot][column], stored once -- no read-modify-write, no zeroing -- and added up
-// by the finalize kernel in window order.  A replicate's result therefore does not depend on how many replicates,
+// part[window][replicate][power][column] -- an element's seven digit sums added up in the flush, in the fixed order the
+// finalize kernel used to apply to per-digit slots part[window][replicate][power][digit slot][column] (round 6; calls that
+// carry a second matrix still store those) -- stored once -- no read-modify-write, no zeroing -- and added up by the finalize
+// kernel in window order.  A replicate's result therefore does not depend on how many replicates,
 // chunks or workgroups the launch had: rows [a, b) of a bootstrap equal the (b - a)-replicate call with rep0 = a
 // bit for bit (multi-GPU slabs, txm_sampler_spec.rep0).
 #include "txm_i8t_common.h"
