@@ -1285,7 +1285,7 @@ static int resample_vals_impl(const double *x, int64_t ldx_s, const double *u, c
     b.ldy_s = ldy_s;
     b.ypivot = ypiv;
     b.part_y = (double *)((char *)ws + q.off_py);
-    b.part_summed = with_y ? 0 : 1;  // (read by the wide fused kernel: digit-summed slots unless the second matrix's finalize needs per-digit u slots)
+    b.part_summed = i8t_wide_summed(with_y) ? 1 : 0;  // (what the wide fused kernel's instances of this call store: the finalize's mode below)
     b.progress = (throttle_on() && q.n_rbg > 1) ? (uint32_t *)((char *)ws + q.off_prog) : nullptr;
     // the FP64 kernel in listed mode: contracts the windows the precision guard flags (none on ordinary data)
     ResampleArgs f;

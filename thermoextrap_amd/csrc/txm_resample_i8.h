@@ -116,5 +116,6 @@ bool i8t_applicable(const double *x, int64_t ldx_s, int64_t C);  // C = all colu
 int i8t_narrow_nq(int64_t C_call, int K);
 int i8_cpad(int64_t C_call, int K);
 bool i8t_partials_summed(int64_t C_call, int K);  // the fused narrow kernel stores digit-summed slots for this shape
+bool i8t_wide_summed(bool call_carries_y);         // ... and the fused wide kernel for a call with / without a second matrix
 
 }  // namespace txm

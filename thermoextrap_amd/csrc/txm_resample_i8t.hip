@@ -926,8 +926,10 @@ int i8_cpad(int64_t C_call, int K) {
 // slots [...][power][8 digit slots][column] only in the A/B build of the serial flush.  The wide instance does what
 // I8Args::part_summed says (0 when the call carries a second matrix).  The finalize is told which (its `summed` argument).
 bool i8t_partials_summed(int64_t C_call, int K) {
-  return i8t_narrow_nq(C_call, K) != 0 && !T_FLUSH_SERIAL;   // (wide states: I8Args::part_summed, set by the caller)
+  return i8t_narrow_nq(C_call, K) != 0 && !T_FLUSH_SERIAL;   // (wide states: i8t_wide_summed)
 }
+// ... and the wide instance: digit-summed slots unless the CALL carries a second matrix (whose finalize reads per-digit u slots)
+bool i8t_wide_summed(bool call_carries_y) { return !call_carries_y && !T_FLUSH_SERIAL; }
 
 template <int NQ>
 static int launch_narrow_t(const I8Args &a, int K, bool weighted, size_t prog_bytes, hipStream_t st) {
