@@ -305,16 +305,21 @@ _CALL_PREPASS = ("txm::pivot_kernel", "txm::i8_stats_kernel", "txm::i8_table_ker
 _ONCE_PER_CALL = ("txm::count_table_kernel", "txm::i8_info_kernel", "txm::pivot_kernel")
 
 
-def call_traffic(kernels: dict, int8_kernel: str, n_obs: int, prepass: bool = False):
+def call_traffic(kernels: dict, int8_kernel: str, n_obs: int, prepass: bool = False, has_y: bool = False):
     """HBM bytes ONE bootstrap call moves, from a traffic summary's per-kernel per-launch figures: the SUM over the
     kernels of the call (round-5 verdict: the bench line carried one launch's 132 GB where the call moves 370).
-    -> (total, {kernel: bytes per call})."""
+    -> (total, {kernel: bytes per call}).  ``has_y``: the call carries a second matrix (config 4) -- its last pass is the
+    `<J0, JN, w, true>` instance of the contraction kernel; a `<J0, JN, w, false>` sibling in the same summary belongs to another
+    leg of the profiled command (the parity check bootstraps without the second matrix) and is left out."""
     groups = -(-int(n_obs) // 32)
     names = _CALL_KERNELS[int8_kernel] + _CALL_COMMON + (_CALL_PREPASS if prepass else ())
+    ys_siblings = {k[: k.rfind(",")] for k in kernels if has_y and k.rstrip(">").endswith(", true") and "resample_i8" in k}
     per = {}
     for k, v in kernels.items():
         b = v.get("hbm_bytes_per_launch")
         if b is None:
+            continue
+        if has_y and "resample_i8" in k and k.rstrip(">").endswith(", false") and k[: k.rfind(",")] in ys_siblings:
             continue
         listed = k.startswith("txm::resample_kernel<") and k.rstrip(">").split(",")[-2].strip() == "1"  # RS_LISTED
         if not (listed or any(k.startswith(n) for n in names)):
@@ -323,10 +328,10 @@ def call_traffic(kernels: dict, int8_kernel: str, n_obs: int, prepass: bool = Fa
     return sum(per.values()), per
 
 
-def pmc_call_traffic(shape, int8_kernel, prepass=False):
+def pmc_call_traffic(shape, int8_kernel, prepass=False, has_y=False):
     hits, stale = _traffic_files(shape)
     for d, src in hits:
-        total, per = call_traffic(d.get("kernels", {}), int8_kernel, shape[1], prepass)
+        total, per = call_traffic(d.get("kernels", {}), int8_kernel, shape[1], prepass, has_y)
         # (wide states: txm_resample_i8g.hip; narrow states, C <= 16: txm_resample_i8gn.hip)
         main_kernel = ("txm::resample_i8gn_kernel" if shape[1] <= 16 else "txm::resample_i8g_kernel") if int8_kernel == "int8_table" else "txm::resample_i8t_kernel"
         if any(k.startswith(main_kernel) for k in per):   # (a summary of this shape that saw the call's contraction kernel)
@@ -626,7 +631,8 @@ def main():
                            "how": "generator timed alone with HIP events after the timed region; contraction = the call minus it "
                                   "(finalize and memsets included); profiles/*_kernel_stats.csv has the rocprofv3 per-kernel durations"}
         # HBM bytes of the timed CALL: the sum over its kernels (generator + every contraction pass + finalize ...), not one launch
-        tr, tr_kernels, src = pmc_call_traffic(shape, info.get("kernel") or "int8_fused", prepass=not info.get("prep_reused"))
+        tr, tr_kernels, src = pmc_call_traffic(shape, info.get("kernel") or "int8_fused", prepass=not info.get("prep_reused"),
+                                               has_y=dxdq is not None)
         if tr is None and C <= 16:  # narrow states: the counters of tools/narrow_pmc.sh (config 2's shape)
             tr, tr_kernels, src2 = pmc_narrow_call_traffic("c2", {"states": 1, "n_samp": N, "n_obs": C, "order": order, "nrep": nrep_rank},
                                                            info.get("kernel") or "int8_fused")

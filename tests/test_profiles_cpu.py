@@ -36,7 +36,7 @@ def test_call_traffic_of_the_round5_summary_is_the_verdicts_370_GB():
     assert abs((two - gen) - 2 * (total - gen - per["txm::i8_info_kernel"]) - per["txm::i8_info_kernel"]) < 1.0
 
 
-@pytest.mark.parametrize("name", sorted(p.name for p in PROF.glob("r06*_bench.json")))
+@pytest.mark.parametrize("name", sorted(p.name for p in list(PROF.glob("r06*_bench.json")) + list(PROF.glob("r06*_bench_c4.json"))))
 def test_bench_line_traffic_is_the_sum_over_the_calls_kernels(name):
     import bench
 
@@ -50,7 +50,7 @@ def test_bench_line_traffic_is_the_sum_over_the_calls_kernels(name):
     assert (d["workload"]["n_samp"], d["workload"]["n_obs"], d["workload"]["order"], d["workload"]["nrep"]) == \
         (cfg["n_samp"], cfg["n_obs"], cfg["order"], cfg["nrep"])
     total, per = bench.call_traffic(d["kernels"], rec["step_breakdown_ms"]["int8_kernel"], cfg["n_obs"],
-                                    prepass=not rec["step_breakdown_ms"]["prepass_reused"])
+                                    prepass=not rec["step_breakdown_ms"]["prepass_reused"], has_y="dx/dq" in cfg["workload"])
     assert total == pytest.approx(r["traffic"], rel=1e-12) and per == pytest.approx(r["kernels"], rel=1e-12)
     assert sum(r["kernels"].values()) == pytest.approx(r["traffic"], rel=1e-12)
     assert r["traffic_ratio"] == pytest.approx(r["traffic"] / r["algorithmic_bytes"], rel=1e-12)

@@ -30,6 +30,8 @@ python3 bench.py --steps 10 --warmup 2 > gpurun_out/${TAG}_bench.json 2> gpurun_
 for c in c2 c4 c3 c5; do
   python3 bench.py --config $c --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_$c.json 2>> gpurun_out/${TAG}_bench.err || echo "bench $c failed"
 done
+# config 4's FETCH / WRITE passes and its bench line again, now with the call's traffic (three passes over one table + the second matrix)
+bash tools/profile_c4_traffic.sh $TAG > gpurun_out/${TAG}_c4_traffic.log 2>&1 || echo "c4 traffic failed"
 KREGEX=resample_i8g_kernel PMC_ORDER=4 PMC_TAG=${TAG}_pmc_i8g PMC_N=1e8 PMC_NREP=1000 bash tools/i8_pmc.sh 1e8 1000 > gpurun_out/${TAG}_pmc_g.log 2>&1 || echo "pmc g failed"
 timeout -k 10 900 python3 tools/profile_shapes.py 1e8 > gpurun_out/${TAG}_shapes.jsonl 2> gpurun_out/${TAG}_shapes.err || echo "shapes failed"
 timeout -k 10 600 python3 tools/scaling_shapes.py 1e8 > gpurun_out/${TAG}_scaling_shapes.jsonl 2> gpurun_out/${TAG}_scaling.err || echo "scaling shapes failed"
