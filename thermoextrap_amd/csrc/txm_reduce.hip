@@ -25,6 +25,23 @@
 
 namespace txm {
 
+// Streaming loads of the sample matrix: every element is read exactly once, so the loads are marked non-temporal (no allocation in
+// the caches; what IS re-read -- u, w, the pivots -- keeps its place).  Same box, N = 1e8, 32 observables, order 4: 4.46 - 4.55 ms
+// (5.8 - 5.9 TB/s) -> 4.09 - 4.14 ms (6.4 - 6.5 TB/s = 0.80 of the 8 TB/s peak) -- profiles/r06_reduce_nt_ab.txt; -DTXM_RED_NO_NT is
+// the A/B build; more rows in flight per lane (-DTXM_RED_UNR=8) or fewer (2) are slower (4.76 / 4.69 ms).  The 1-D reduction over
+// (state, rec) series (BASELINE config 3): 0.222 -> 0.197 ms (5.8 -> 6.5 TB/s).
+typedef double red_v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 red_ld2(const double *p) {
+#ifdef TXM_RED_NO_NT
+  return *reinterpret_cast<const double2 *>(p);
+#else
+  const red_v2d t = __builtin_nontemporal_load(reinterpret_cast<const red_v2d *>(p));
+  return make_double2(t.x, t.y);
+#endif
+}
+// (the 8-byte path of odd or unaligned row pitches keeps plain loads: its rows share cache lines with their neighbours, which
+// other wave instructions load -- non-temporal there re-fetches them: N = 1e8, 33 observables: 8.94 -> 9.23 ms)
+__device__ __forceinline__ double red_ld1(const double *p) { return *p; }
 
 // ---------------------------------------------------------------------------
 // Row-major reduction.  Thread layout inside a 256-thread block:
@@ -49,7 +66,10 @@ __global__ __launch_bounds__(RED_BLOCK) void reduce_rowmajor_kernel(
     partial += (size_t)blockIdx.z * gridDim.y * gridDim.x * (LPR * VEC) * 2 * K;
   }
   constexpr int ROWS = RED_BLOCK / LPR;
-  constexpr int UNR = 4;
+#ifndef TXM_RED_UNR  // (A/B builds: rows in flight per lane)
+#define TXM_RED_UNR 4
+#endif
+  constexpr int UNR = TXM_RED_UNR;
   const int tid = threadIdx.x;
   const int lir = tid & (LPR - 1);
   const int rib = tid >> LPR_LOG2;
@@ -92,11 +112,11 @@ __global__ __launch_bounds__(RED_BLOCK) void reduce_rowmajor_kernel(
       for (int q = 0; q < UNR; ++q) {
         const int64_t r = i + q * stride;
         if constexpr (VEC == 2) {
-          const double2 t2 = *reinterpret_cast<const double2 *>(x + r * ldx_s + col0);
+          const double2 t2 = red_ld2(x + r * ldx_s + col0);
           xv[q][0] = t2.x;
           xv[q][1] = t2.y;
         } else {
-          xv[q][0] = x[r * ldx_s + col0];
+          xv[q][0] = red_ld1(x + r * ldx_s + col0);
         }
         ui[q] = u[r];
         wi[q] = WEIGHTED ? w[r] : 1.0;
@@ -107,11 +127,11 @@ __global__ __launch_bounds__(RED_BLOCK) void reduce_rowmajor_kernel(
     for (; i < N; i += stride) {
       double xv[VEC];
       if constexpr (VEC == 2) {
-        const double2 t2 = *reinterpret_cast<const double2 *>(x + i * ldx_s + col0);
+        const double2 t2 = red_ld2(x + i * ldx_s + col0);
         xv[0] = t2.x;
         xv[1] = t2.y;
       } else {
-        xv[0] = x[i * ldx_s + col0];
+        xv[0] = red_ld1(x + i * ldx_s + col0);
       }
       body(u[i], WEIGHTED ? w[i] : 1.0, xv);
     }
@@ -247,7 +267,7 @@ __global__ __launch_bounds__(RED_BLOCK) void reduce_colmajor_kernel(
 #pragma unroll
       for (int q = 0; q < UNR; ++q) {
         const int64_t pp = p + q * nthreads;
-        xv[q] = reinterpret_cast<const double2 *>(xs)[pp];
+        xv[q] = red_ld2(xs + 2 * pp);  // (the series itself: read once; u and w are shared by the series of a state and stay cached)
         if (COV) uv[q] = reinterpret_cast<const double2 *>(u)[pp];
         if (WEIGHTED) wv[q] = reinterpret_cast<const double2 *>(w)[pp];
       }
@@ -258,7 +278,7 @@ __global__ __launch_bounds__(RED_BLOCK) void reduce_colmajor_kernel(
       }
     }
     for (; p < npair; p += nthreads) {
-      const double2 xv = reinterpret_cast<const double2 *>(xs)[p];
+      const double2 xv = red_ld2(xs + 2 * p);
       double2 uv = {0, 0}, wv = {1, 1};
       if (COV) uv = reinterpret_cast<const double2 *>(u)[p];
       if (WEIGHTED) wv = reinterpret_cast<const double2 *>(w)[p];
