@@ -35,6 +35,19 @@ __device__ __forceinline__ void g_dma16(const void *sbase, uint32_t voff, uint32
 #endif
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_dst) : "memory", "m0");
 }
+// ... the same with the non-temporal hint: the count words of the table, which ONE workgroup reads once per pass (x, which the
+// replicate groups of a window share through the L2, keeps the plain form).  Same box, north-star call, three rounds: 159.9 / 160.8 /
+// 161.0 ms plain against 159.4 / 159.0 / 160.2 ms (profiles/r06_table_nt_ab.txt); -DTXM_G_TABLE_PLAIN is the A/B build.
+__device__ __forceinline__ void g_dma16_stream(const void *sbase, uint32_t voff, uint32_t lds_dst) {
+#ifdef TXM_G_NO_DMA
+  return;
+#endif
+#ifdef TXM_G_TABLE_PLAIN  // (A/B build)
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_dst) : "memory", "m0");
+#else
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0 nt" ::"s"(sbase), "v"(voff), "s"(lds_dst) : "memory", "m0");
+#endif
+}
 __device__ __forceinline__ void g_dma4(const void *sbase, uint32_t voff, uint32_t lds_dst) {
 #ifdef TXM_G_NO_DMA
   return;

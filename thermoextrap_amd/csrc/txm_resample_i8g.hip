@@ -222,13 +222,13 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       const uint32_t dst = (uint32_t)(OFF_A + (B & 1) * (G_BS * A_STEP) + wave * A_STEP);
 #pragma unroll
       for (int Q = 0; Q < NQ; ++Q)
-        if (piece < 0 || piece == Q) g_dma16(src + q_off(Q), g_lane_now() * 16u, dst + (uint32_t)(Q * 1024));
+        if (piece < 0 || piece == Q) g_dma16_stream(src + q_off(Q), g_lane_now() * 16u, dst + (uint32_t)(Q * 1024));
     } else {  // every wave PPW of the block's G_BS x NQ pieces
       const uint32_t l16 = g_lane_now() * 16u;
 #pragma unroll
       for (int k = 0; k < PPW; ++k) {
         const int i = wave * PPW + k, st = i / NQ, Q = i % NQ;
-        g_dma16(tab + (size_t)(Bc * G_BS + st) * G_KSTEP_BYTES + q_off(Q), l16,
+        g_dma16_stream(tab + (size_t)(Bc * G_BS + st) * G_KSTEP_BYTES + q_off(Q), l16,
                 (uint32_t)(OFF_A + (B & 1) * (G_BS * A_STEP) + st * A_STEP + Q * 1024));
       }
     }
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
     auto a_piece = [&](int Q) {
 #ifndef TXM_G_NO_ADMA
       if constexpr (!ADIR)
-        if (loader) g_dma16(blk_asrc + qoff[Q], blk_l16, blk_adst + (uint32_t)(Q * 1024));
+        if (loader) g_dma16_stream(blk_asrc + qoff[Q], blk_l16, blk_adst + (uint32_t)(Q * 1024));
 #endif
     };
     // (ADIR) the next block's count words: this lane's 16 bytes of every (step, quarter) piece

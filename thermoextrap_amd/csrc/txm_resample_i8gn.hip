@@ -230,7 +230,7 @@ __global__ __launch_bounds__(T_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
       const unsigned char *src = tab + (size_t)(Bc * G_BS + st) * G_KSTEP_BYTES;
       const uint32_t dst = (uint32_t)(OFF_A + (B % NB) * (G_BS * A_STEP) + st * A_STEP);
 #pragma unroll
-      for (int Q = 0; Q < NQ; ++Q) g_dma16(src + (size_t)Q * 1024, l16, dst + (uint32_t)(Q * 1024));
+      for (int Q = 0; Q < NQ; ++Q) g_dma16_stream(src + (size_t)Q * 1024, l16, dst + (uint32_t)(Q * 1024));  // (count words: read once)
     }
   };
   // raw u / w of factor block B (the chunks B * G_BS + W .. B * G_BS + W + G_BS - 1: what block B's k-steps slice)
