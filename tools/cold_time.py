@@ -9,7 +9,7 @@ from thermoextrap_amd import engine
 from bench import make_data
 txa.require_gpu(0)
 tag = os.path.basename(os.environ.get("TXM_LIBRARY", "default"))
-for N, C, nrep, order in ((100_000_000, 32, 1000, 4), (10_000_000, 8, 200, 4), (1_000_000, 32, 100, 4)):
+for N, C, nrep, order in ((100_000_000, 32, 1000, 4), (10_000_000, 8, 200, 4), (1_000_000, 32, 100, 4), (1_000_000, 4, 100, 3), (300_000, 32, 200, 4), (3_000_000, 16, 100, 2)):
     x, u = make_data(N, C, 5, torch)
     s = engine.DeviceSampler(0, nrep, N)
     o = torch.empty((nrep, C, 2, order + 1), dtype=torch.float64, device="cuda")
